@@ -1,0 +1,220 @@
+"""Regenerate the golden fixtures in this directory by IMPORTING the real reference.
+
+Runs only in the build container (needs /root/reference); nothing here is used at test
+time.  The reference's Python never travels: only inputs and expected outputs (data) are
+written.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+In-process shims (none touches arithmetic):
+  * `turtle` stub module            - reference utils.py:1 imports it, tkinter is absent
+  * `np.bool8 = np.bool_`           - reference truss.py:321, removed in numpy 2
+  * `plt.style.use("seaborn")`      - reference plot.py:9, renamed in matplotlib >= 3.6
+Dense (un-sparsified) results are obtained by running the reference's own `Truss.Solve()`
+with its `IsZero` / `IsZeroVector` names rebound to "never zero" inside the reference's
+truss module, so every joint and member lands in the result dicts.
+
+Written files:
+  data/*.json            verbatim copies of the reference's data/ and generate/ JSON files
+  dense_data.npz         dense u / f_ext / N / weight (+ K_ff up to 120 bars) per data case
+  cube_ragged.npz        12 seeded GenerateRandomCubeTrusses cases (inputs + dense outputs)
+  edge_cases.json        synthetic edge cases (inputs + dense outputs or expected exception)
+  ga_trace.json          seeded GA run on bar-120 (generation-0 fitness triples, history)
+"""
+import glob
+import json
+import os
+import random
+import shutil
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    turtle = types.ModuleType("turtle")
+    turtle.position = None
+    sys.modules.setdefault("turtle", turtle)
+    if not hasattr(np, "bool8"):
+        np.bool8 = np.bool_
+    import matplotlib.pyplot as plt
+    real_use = plt.style.use
+    plt.style.use = lambda name: real_use("seaborn-v0_8" if name == "seaborn" else name)
+    sys.path.insert(0, REF)
+    import slientruss3d.truss as rt
+    import slientruss3d.type as rty
+    import slientruss3d.generate as rg
+    import slientruss3d.ga as rga
+    return rt, rty, rg, rga
+
+
+def dense_solve(rt, truss):
+    """Run the reference Solve() with sparsification disabled -> dense arrays."""
+    keep_zero, keep_vec = rt.IsZero, rt.IsZeroVector
+    rt.IsZero = lambda *a, **k: False
+    rt.IsZeroVector = lambda *a, **k: False
+    try:
+        truss.Solve()
+    finally:
+        rt.IsZero, rt.IsZeroVector = keep_zero, keep_vec
+    dim, nJ, nM = truss.dim, truss.nJoint, truss.nMember
+    u = np.array([truss.GetDisplacements()[j] for j in range(nJ)]).reshape(nJ, dim)
+    f = np.array([truss.GetExternalForces()[j] for j in range(nJ)]).reshape(nJ, dim)
+    n = np.array([truss.GetInternalForces()[m] for m in range(nM)])
+    return u, f, n
+
+
+def capture_data_cases(rt):
+    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    out = {}
+    for path in sorted(glob.glob(os.path.join(REF, "data", "*.json"))
+                       + glob.glob(os.path.join(REF, "generate", "*.json"))):
+        shutil.copyfile(path, os.path.join(HERE, "data", os.path.basename(path)))
+        os.chmod(os.path.join(HERE, "data", os.path.basename(path)), 0o644)
+    for path in sorted(glob.glob(os.path.join(REF, "data", "*_input_*.json"))):
+        name = os.path.basename(path)[:-5]
+        with open(path) as fh:
+            data = json.load(fh)
+        dim = len(data["joint"][0][0])
+        truss = rt.Truss(dim).LoadFromJSON(path)
+        u, f, n = dense_solve(rt, truss)
+        out[f"{name}/u"], out[f"{name}/f_ext"], out[f"{name}/N"] = u, f, n
+        out[f"{name}/weight"] = np.array(truss.weight)
+        if truss.nMember <= 120:
+            mask = truss.GetDisplacementUnknownMask()
+            out[f"{name}/K_ff"] = truss.GetKMatrix()[mask, :][:, mask]
+    np.savez_compressed(os.path.join(HERE, "dense_data.npz"), **out)
+    print("dense_data.npz:", len(out), "arrays")
+
+
+SUPPORT_CODE = {"NO": 0, "PIN": 1, "ROLLER_X": 2, "ROLLER_Y": 3, "ROLLER_Z": 4}
+
+
+def capture_cube_ragged(rt, rty, rg):
+    out = {}
+    cube_counts = [8, 12, 20, 30, 45, 60, 80, 100, 130, 160, 190, 216]
+    for idx, num in enumerate(cube_counts):
+        trusses = rg.GenerateRandomCubeTrusses(
+            gridRange=(6, 6, 6), numCubeRange=(num, num), numEachRange=(1, 1),
+            lengthRange=(50, 150), isDoStructuralAnalysis=False, isPrintMessage=False,
+            seed=1000 + idx)
+        truss = trusses[0]
+        data = truss.Serialize()
+        u, f, n = dense_solve(rt, truss)
+        key = f"cube{idx:02d}"
+        out[f"{key}/xyz"] = np.array([p for p, _ in data["joint"]], dtype=np.float64)
+        out[f"{key}/support"] = np.array([SUPPORT_CODE[s] for _, s in data["joint"]], dtype=np.uint8)
+        loads = np.zeros([len(data["joint"]), 3])
+        for j, v in data["force"]:
+            loads[j] = v
+        out[f"{key}/loads"] = loads
+        out[f"{key}/conn"] = np.array([c for c, _ in data["member"]], dtype=np.int32)
+        out[f"{key}/mtype"] = np.array([t for _, t in data["member"]], dtype=np.float64)
+        out[f"{key}/u"], out[f"{key}/f_ext"], out[f"{key}/N"] = u, f, n
+        print(f"  {key}: numCube {num} nJ {truss.nJoint} nM {truss.nMember}")
+    np.savez_compressed(os.path.join(HERE, "cube_ragged.npz"), **out)
+
+
+def edge_case_inputs():
+    mt = [1.0, 1e7, 0.1]
+    cases = {}
+    # 2D: PIN + ROLLER_Y (roller constrains y only), triangle with a load.
+    cases["2d_pin_rollerY"] = {
+        "joint": [[[0, 0], "PIN"], [[4, 0], "ROLLER_Y"], [[2, 3], "NO"]],
+        "force": [[2, [1000.0, -2500.0]]],
+        "member": [[[0, 1], mt], [[0, 2], mt], [[1, 2], [2.0, 2e7, 0.3]]]}
+    # 2D: ROLLER_X on one support and a load on a supported joint (ignored at its
+    # constrained DOF, overwritten in `external`).
+    cases["2d_rollerX_load_on_support"] = {
+        "joint": [[[0, 0], "PIN"], [[5, 0], "ROLLER_Y"], [[5, 4], "NO"], [[0, 4], "ROLLER_X"]],
+        "force": [[2, [300.0, -700.0]], [1, [150.0, 999.0]], [3, [123.0, -50.0]]],
+        "member": [[[0, 1], mt], [[1, 2], mt], [[2, 3], mt], [[3, 0], mt], [[0, 2], mt], [[1, 3], mt]]}
+    # 3D: all three roller kinds + one pin, tetrahedron-like frame.
+    cases["3d_rollers_xyz"] = {
+        "joint": [[[0, 0, 0], "PIN"], [[3, 0, 0], "ROLLER_Z"], [[0, 3, 0], "ROLLER_Z"],
+                  [[1, 1, 4], "NO"], [[3, 3, 0], "ROLLER_X"], [[1.5, 1.5, 0], "ROLLER_Y"]],
+        "force": [[3, [500.0, -300.0, -2000.0]], [1, [10.0, 20.0, 30.0]]],
+        "member": [[[0, 1], mt], [[0, 2], mt], [[1, 2], mt], [[0, 3], mt], [[1, 3], mt], [[2, 3], mt],
+                   [[4, 3], mt], [[4, 1], mt], [[4, 2], mt], [[5, 3], mt], [[5, 0], mt], [[5, 4], mt],
+                   [[5, 1], mt]]}
+    # 3D: parallel (duplicated) members, different sections, both orientations.
+    cases["3d_parallel_members"] = {
+        "joint": [[[0, 0, 0], "PIN"], [[2, 0, 0], "PIN"], [[0, 2, 0], "PIN"], [[1, 1, 3], "NO"],
+                  [[1, 1, 6], "NO"]],
+        "force": [[3, [100.0, 200.0, -300.0]], [4, [-50.0, 75.0, -500.0]]],
+        "member": [[[0, 3], mt], [[1, 3], mt], [[2, 3], mt], [[3, 0], [2.0, 1e7, 0.2]],
+                   [[0, 3], [0.5, 3e7, 0.2]], [[3, 4], mt], [[4, 3], mt], [[0, 4], mt],
+                   [[1, 4], mt], [[2, 4], mt]]}
+    # 3D mechanism that passes the counting test: K_ff exactly singular -> LinAlgError.
+    cases["3d_mechanism_singular"] = {
+        "joint": [[[0, 0, 0], "PIN"], [[1, 0, 0], "PIN"], [[0, 1, 0], "NO"], [[5, 5, 5], "NO"]],
+        "force": [[2, [0.0, 0.0, -10.0]]],
+        "member": [[[0, 2], mt], [[1, 2], mt], [[0, 1], mt], [[0, 1], mt], [[0, 1], mt], [[0, 1], mt]]}
+    # Counting test fails -> TrussNotStableError before arithmetic.
+    cases["3d_count_unstable"] = {
+        "joint": [[[0, 0, 0], "PIN"], [[1, 0, 0], "NO"], [[0, 1, 0], "NO"]],
+        "force": [[1, [1.0, 0.0, 0.0]]],
+        "member": [[[0, 1], mt], [[0, 2], mt]]}
+    return cases
+
+
+def capture_edge_cases(rt):
+    out = {}
+    for name, data in edge_case_inputs().items():
+        dim = len(data["joint"][0][0])
+        entry = {"input": data}
+        try:
+            truss = rt.Truss(dim).LoadFromJSON(data=data)
+            u, f, n = dense_solve(rt, truss)
+            entry.update(u=u.tolist(), f_ext=f.tolist(), N=n.tolist(), weight=truss.weight,
+                         resist={str(k): v.tolist() for k, v in truss.GetResistances().items()})
+            # also the genuine sparse views, for dict-semantics tests
+            truss2 = rt.Truss(dim).LoadFromJSON(data=data)
+            truss2.Solve()
+            entry["sparse"] = {k: truss2.Serialize()[k] for k in ("displace", "external", "internal")}
+        except Exception as exc:  # noqa: BLE001 - the exception type IS the golden value
+            entry["raises"] = type(exc).__name__
+        out[name] = entry
+        print(f"  {name}: {'raises ' + entry['raises'] if 'raises' in entry else 'ok'}")
+    with open(os.path.join(HERE, "edge_cases.json"), "w") as fh:
+        json.dump(out, fh)
+
+
+def capture_ga_trace(rt, rty, rga):
+    """Seeded GA on bar-120 with the 20 member types of example.py:186."""
+    random.seed(0)
+    types_ = [rty.MemberType(inch, random.uniform(1e7, 3e7), random.uniform(0.1, 1.0))
+              for inch in range(1, 21)]
+    truss = rt.Truss(3).LoadFromJSON(os.path.join(REF, "data", "bar-120_input_0.json"))
+    ga = rga.GA(truss, types_, 30000., 10., nIteration=5, nPatience=50, nPop=64, nElite=16)
+    state = random.getstate()
+    pop0 = ga.Initialize()
+    gen0 = [list(ga.GetFitness(g)) for g in pop0]
+    random.setstate(state)
+    minGene, minInfo, pop, history = ga.Evolve(isPrintMessage=False)
+    out = {"seed": 0, "memberTypes": [t.Serialize() for t in types_],
+           "nPop": 64, "nElite": 16, "nIteration": 5, "allowStress": 30000., "allowDisplace": 10.,
+           "pop0": pop0, "gen0": gen0, "bestFitnessHistory": history,
+           "minGene": minGene, "minInfo": list(minInfo), "finalPop": pop}
+    with open(os.path.join(HERE, "ga_trace.json"), "w") as fh:
+        json.dump(out, fh)
+    print("  ga history:", history)
+
+
+def main():
+    rt, rty, rg, rga = import_reference()
+    capture_data_cases(rt)
+    capture_cube_ragged(rt, rty, rg)
+    capture_edge_cases(rt)
+    capture_ga_trace(rt, rty, rga)
+
+
+if __name__ == "__main__":
+    main()

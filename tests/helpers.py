@@ -1,0 +1,56 @@
+"""Shared loaders / comparators for the test-suite (test infrastructure)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SUPPORT_NAME = {0: "NO", 1: "PIN", 2: "ROLLER_X", 3: "ROLLER_Y", 4: "ROLLER_Z"}
+
+
+def data_case_names():
+    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "data", "bar-*_input_*.json")))
+
+
+def load_json(name):
+    with open(os.path.join(GOLDEN, "data", name + ".json")) as fh:
+        return json.load(fh)
+
+
+def cube7_case_names():
+    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "data", "cube-7_case_*.json")))
+
+
+def dense_golden():
+    return np.load(os.path.join(GOLDEN, "dense_data.npz"))
+
+
+def edge_cases():
+    with open(os.path.join(GOLDEN, "edge_cases.json")) as fh:
+        return json.load(fh)
+
+
+def ragged_cube_cases():
+    """Yield (name, data-dict, golden dict) for the seeded GenerateRandomCubeTrusses fixtures."""
+    z = np.load(os.path.join(GOLDEN, "cube_ragged.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    for name in names:
+        xyz, sup, loads = z[f"{name}/xyz"], z[f"{name}/support"], z[f"{name}/loads"]
+        conn, mtype = z[f"{name}/conn"], z[f"{name}/mtype"]
+        data = {
+            "joint": [[xyz[j].tolist(), SUPPORT_NAME[int(sup[j])]] for j in range(len(xyz))],
+            "force": [[j, loads[j].tolist()] for j in range(len(xyz)) if np.any(loads[j] != 0)],
+            "member": [[conn[m].tolist(), mtype[m].tolist()] for m in range(len(conn))],
+        }
+        yield name, data, {k: z[f"{name}/{k}"] for k in ("u", "f_ext", "N")}
+
+
+def max_scaled_err(got, ref):
+    """max|got - ref| / max|ref|  (the densified, max-scaled comparator of SURVEY.md section 4)."""
+    got, ref = np.asarray(got, dtype=float), np.asarray(ref, dtype=float)
+    scale = np.max(np.abs(ref))
+    if scale == 0:
+        return float(np.max(np.abs(got))) if got.size else 0.0
+    return float(np.max(np.abs(got - ref)) / scale)
