@@ -1,0 +1,121 @@
+/*
+ * trs_solver.h - C ABI of the MI355X (gfx950) batched direct-stiffness truss solver.
+ *
+ * The reference (leo27945875/Python_Stable_3D_Truss_Analysis, slientruss3d v2.0.3) is pure
+ * Python and has no FFI layer: its seam is the method Truss.Solve() (slientruss3d/truss.py:329-364).
+ * The entry points below are the stages of that method, batched over B independent trusses,
+ * each citing the reference lines it replaces.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller (e.g. a PyTorch-ROCm tensor's
+ *    data_ptr()); the library allocates nothing.  `stream` is a hipStream_t passed as void*.
+ *  - Every call only enqueues work on `stream` and returns; the return value is 0 or a
+ *    hipError_t for launch/argument errors.  Numerical status is reported through `info`.
+ *  - Batched arrays are padded to the batch maxima: joints to nJ_max, members to nM_max;
+ *    per-truss counts are nJ[b], nM[b].  All trusses are 3D in the kernels; a 2D truss is
+ *    packed with z = 0 and the z axis constrained at every joint.
+ *  - DOF numbering: dof = joint*3 + axis (reference truss.py:312-314,324).
+ *  - cbits[b][j]: constrained-axis bit mask of joint j (x=1, y=2, z=4): the encoding of
+ *    SupportType.GetResistanceMask (reference type.py:48-74).
+ *
+ * Stiffness slab layout (written by trs_assemble, factored in place by trs_potrf_batched)
+ *    n      = n_free[b]                  number of free DOFs of truss b
+ *    n_pad  = round_up(n, 64)
+ *    S[c][i], row-major, leading dimension ld (>= n_pad_max + 16, multiple of 16),
+ *    one slab of slab_rows*ld doubles per truss (slab_rows >= n_pad_max).
+ *      S[c][i] = K_ff[c][i]        for c < n, 16*floor(c/16) <= i < n      (upper part by 16-tiles)
+ *      S[c][c] = 1                 for n <= c < n_pad                        (identity padding)
+ *      S[c][n_pad] = f_f[c]        right-hand side, stored as one extra column
+ *      other entries with i >= 16*floor(c/16), i < n_pad + 16 are 0; entries left of the
+ *      diagonal tile are never read or written unless TRS_ASM_FULL_SYMMETRIC is given.
+ *    After trs_potrf_batched:  S[c][i] = U[c][i] (i >= c) with K_ff = U^T U (U = L^T), and
+ *    S[c][n_pad] = y[c], the forward-substituted right-hand side (L y = f_f).
+ */
+#ifndef TRS_SOLVER_H
+#define TRS_SOLVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRS_ABI_VERSION 1
+
+/* trs_assemble flags */
+#define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests) */
+
+int trs_abi_version(void);
+
+/* Leading dimension / row count of the stiffness slab for a batch whose largest reduced
+ * system has n_max free DOFs. */
+int trs_slab_ld(int n_max);
+int trs_slab_rows(int n_max);
+
+/* Free-DOF numbering.  Replaces Truss.GetDisplacementUnknownMask (truss.py:319-326) and the
+ * boolean-mask compaction of truss.py:343: free_index[b][dof] = position of the DOF in the
+ * reduced system, or -1 when constrained; n_free[b] = number of free DOFs. */
+int trs_dofmap(int B, int nJ_max, const uint8_t *cbits, const int32_t *nJ,
+               int32_t *free_index /* [B][nJ_max*3] */, int32_t *n_free /* [B] */, void *stream);
+
+/* Assembly of the reduced stiffness matrix and load vector.  Replaces Member.k/cosines/matK
+ * (truss.py:56-86), Truss.GetKMatrix (truss.py:307-316), GetExternalForceVector
+ * (truss.py:303-304) and the row/column elimination matK[mask,:][:,mask], vecF[mask]
+ * (truss.py:343). */
+int trs_assemble(int B, int nJ_max, int nM_max,
+                 const double *xyz /* [B][nJ_max][3] */, const int32_t *conn /* [B][nM_max][2] */,
+                 const double *E /* [B][nM_max] */, const double *A /* [B][nM_max] */,
+                 const double *loads /* [B][nJ_max][3] */, const int32_t *free_index,
+                 const int32_t *n_free, const int32_t *nJ, const int32_t *nM,
+                 int ld, int slab_rows, double *S /* [B][slab_rows][ld] */, int flags,
+                 void *stream);
+
+/* Batched Cholesky factorisation with fused forward substitution of the right-hand-side
+ * column.  Replaces the factorisation half of np.linalg.solve (truss.py:343; LAPACK dgesv in
+ * the reference, potrf here because K_ff is SPD for a stable truss).
+ * info[b] = 0 on success, k > 0 when the pivot of column k (1-based) is not positive
+ * (the reference raises numpy.linalg.LinAlgError for an exactly singular matrix). */
+int trs_potrf_batched(int B, const int32_t *n_free, int ld, int slab_rows, double *S,
+                      int32_t *info /* [B] */, void *stream);
+
+/* Back substitution U u_f = y.  Replaces the solve half of np.linalg.solve (truss.py:343).
+ * uf[b][c] = reduced displacement c (c < n_free[b]); entries up to n_pad are written. */
+int trs_potrs_batched(int B, const int32_t *n_free, int ld, int slab_rows, const double *S,
+                      double *uf /* [B][ld_uf] */, int ld_uf, void *stream);
+
+/* Result recovery.  Replaces the displacement scatter (truss.py:342), the reactions
+ * vecF[~mask] = K[~mask,:] @ u (truss.py:348-349) and the member-force loop
+ * (truss.py:354-359, Member.IsTension truss.py:89-91): u and f_ext are dense [nJ_max][3],
+ * N[m] is the axial force, tension positive.  f_ext holds the applied load at free DOFs and
+ * the stiffness reaction K u at constrained DOFs, as the reference's `external`. */
+int trs_recover(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
+                const double *E, const double *A, const double *loads,
+                const int32_t *free_index, const int32_t *nJ, const int32_t *nM,
+                const double *uf, int ld_uf, double *u /* [B][nJ_max][3] */,
+                double *f_ext /* [B][nJ_max][3] */, double *N /* [B][nM_max] */, void *stream);
+
+/* Constraint reductions of the GA fitness (truss.py:166-168,429-462; ga.py:139-149):
+ *   weight[b]   = sum_m A*L*rho
+ *   stress_vio[b] = sum_m max(|N|/A - allow_stress, 0) over members with |N| >= 1e-10
+ *   disp_vio[b]   = sum_j max(||u_j|| - allow_displace, 0) over joints with a component >= 1e-10 */
+int trs_fitness(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
+                const double *A, const double *rho, const int32_t *nJ, const int32_t *nM,
+                const double *u, const double *N, double allow_stress, double allow_displace,
+                double *weight /* [B] */, double *stress_vio /* [B] */, double *disp_vio /* [B] */,
+                void *stream);
+
+/* The whole Truss.Solve() pipeline (truss.py:329-364) on one stream:
+ * dofmap -> assemble -> potrf -> potrs -> recover.  Workspace pointers as above. */
+int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound,
+              const double *xyz, const int32_t *conn, const double *E, const double *A,
+              const uint8_t *cbits, const double *loads, const int32_t *nJ, const int32_t *nM,
+              int32_t *free_index, int32_t *n_free, int ld, int slab_rows, double *S,
+              double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info,
+              void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRS_SOLVER_H */

@@ -1,0 +1,263 @@
+"""Batched `Truss.Solve()`: packing of many trusses into SoA tensors, the device pipeline
+(dofmap -> assemble -> potrf -> potrs -> recover through the C ABI), and the dense results.
+
+This is the layer the reference does not have: its `Solve()` (`slientruss3d/truss.py:329-364`)
+handles one truss per call.  `Truss.Solve()` here is `solve_batch([truss])`.
+
+All device work is enqueued on the current PyTorch-ROCm stream; tensors are only the memory
+the kernels run on (plumbing).  No CPU fallback: without a GPU or the built library the calls
+raise `HipExtensionError`.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from .type import SupportType
+from .utils import HipExtensionError
+
+
+@dataclass
+class PackedBatch:
+    """B trusses as padded host arrays (numpy), ready to be uploaded.
+
+    xyz [B,nJ_max,3] f64 | conn [B,nM_max,2] i32 | E, A, rho [B,nM_max] f64 |
+    cbits [B,nJ_max] u8 (constrained-axis bits x=1,y=2,z=4) | loads [B,nJ_max,3] f64 |
+    nJ, nM [B] i32 | dim [B] (2 or 3; 2D trusses are embedded with z fixed) | n_free [B] i32.
+    """
+    xyz: np.ndarray
+    conn: np.ndarray
+    E: np.ndarray
+    A: np.ndarray
+    rho: np.ndarray
+    cbits: np.ndarray
+    loads: np.ndarray
+    nJ: np.ndarray
+    nM: np.ndarray
+    dim: np.ndarray
+    n_free: np.ndarray
+
+    @property
+    def B(self):
+        return int(self.nJ.shape[0])
+
+    @property
+    def nJ_max(self):
+        return int(self.xyz.shape[1])
+
+    @property
+    def nM_max(self):
+        return int(self.conn.shape[1])
+
+    @property
+    def n_max(self):
+        return int(self.n_free.max()) if self.B else 0
+
+    def replicate(self, times):
+        """The same trusses `times` times over, as independent problems (no sharing on device)."""
+        rep = lambda a: np.ascontiguousarray(np.tile(a, (times,) + (1,) * (a.ndim - 1)))
+        return PackedBatch(*(rep(getattr(self, f)) for f in self.__dataclass_fields__))
+
+    def take(self, index):
+        """Sub-batch (rows `index`, any numpy index) - used to shard a batch over ranks."""
+        return PackedBatch(*(np.ascontiguousarray(getattr(self, f)[index])
+                             for f in self.__dataclass_fields__))
+
+
+def count_free(cbits, nJ):
+    """n_free[b] from the constraint bits (host copy of what trs_dofmap computes)."""
+    bits = np.asarray(cbits, dtype=np.uint8)
+    valid = np.arange(bits.shape[1])[None, :] < np.asarray(nJ)[:, None]
+    constrained = ((bits & 1) + ((bits >> 1) & 1) + ((bits >> 2) & 1)) * valid
+    return (3 * np.asarray(nJ) - constrained.sum(axis=1)).astype(np.int32)
+
+
+def pack_arrays(xyz_list, conn_list, mtype_list, support_list, loads_list, dims):
+    """Pack per-truss arrays: xyz [nJ,dim], conn [nM,2], mtype [nM,3]=(a,e,density),
+    support [nJ] SupportType values, loads [nJ,dim]."""
+    B = len(xyz_list)
+    nJ = np.array([len(x) for x in xyz_list], dtype=np.int32)
+    nM = np.array([len(c) for c in conn_list], dtype=np.int32)
+    nJ_max, nM_max = max(1, int(nJ.max(initial=1))), max(1, int(nM.max(initial=1)))
+    xyz = np.zeros([B, nJ_max, 3])
+    loads = np.zeros([B, nJ_max, 3])
+    cbits = np.zeros([B, nJ_max], dtype=np.uint8)
+    conn = np.zeros([B, nM_max, 2], dtype=np.int32)
+    E = np.ones([B, nM_max])
+    A = np.ones([B, nM_max])
+    rho = np.zeros([B, nM_max])
+    for b in range(B):
+        dim = dims[b]
+        x = np.asarray(xyz_list[b], dtype=float).reshape(-1, dim)
+        xyz[b, :nJ[b], :dim] = x
+        loads[b, :nJ[b], :dim] = np.asarray(loads_list[b], dtype=float).reshape(-1, dim)
+        bits = np.array([SupportType.ConstraintBits(s, dim) for s in support_list[b]], dtype=np.uint8)
+        cbits[b, :nJ[b]] = bits | (4 if dim == 2 else 0)  # a 2D truss never moves in z
+        if nM[b]:
+            conn[b, :nM[b]] = np.asarray(conn_list[b], dtype=np.int32).reshape(-1, 2)
+            mt = np.asarray(mtype_list[b], dtype=float).reshape(-1, 3)
+            A[b, :nM[b]], E[b, :nM[b]], rho[b, :nM[b]] = mt[:, 0], mt[:, 1], mt[:, 2]
+    dims = np.asarray(dims, dtype=np.int32)
+    return PackedBatch(xyz, conn, E, A, rho, cbits, loads, nJ, nM, dims, count_free(cbits, nJ))
+
+
+def pack_trusses(trusses):
+    """`list[Truss]` -> `PackedBatch` (DOF order joint*dim + axis, reference `truss.py:312-314`)."""
+    xyz, conn, mtype, sup, loads, dims = [], [], [], [], [], []
+    for t in trusses:
+        nJ, dim = t.nJoint, t.dim
+        xyz.append(np.array([t.GetJointPosition(j) for j in range(nJ)], dtype=float).reshape(nJ, dim))
+        sup.append([t.GetSupportType(j) for j in range(nJ)])
+        loads.append(t.GetExternalForceVector().reshape(nJ, dim))
+        members = t.GetMembers(isProtect=False)
+        conn.append(np.array([[members[m][0], members[m][1]] for m in range(t.nMember)], dtype=np.int32))
+        mtype.append(np.array([[members[m][2].a, members[m][2].e, members[m][2].density]
+                               for m in range(t.nMember)], dtype=float))
+        dims.append(dim)
+    return pack_arrays(xyz, conn, mtype, sup, loads, dims)
+
+
+def pack_json(data_list):
+    """List of reference-format JSON dicts (`detail/combine_with_JSON.md:71-163`) -> PackedBatch,
+    without building `Truss` objects (bulk path)."""
+    xyz, conn, mtype, sup, loads, dims = [], [], [], [], [], []
+    for data in data_list:
+        dim = len(data["joint"][0][0])
+        nJ = len(data["joint"])
+        xyz.append(np.array([p for p, _ in data["joint"]], dtype=float))
+        sup.append([SupportType.GetFromString(s) for _, s in data["joint"]])
+        f = np.zeros([nJ, dim])
+        for j, v in data["force"]:
+            if np.any(np.abs(np.asarray(v, dtype=float)) >= 1e-10):  # zero loads are dropped (truss.py:181)
+                f[j] = v
+        loads.append(f)
+        conn.append(np.array([c for c, _ in data["member"]], dtype=np.int32).reshape(-1, 2))
+        mtype.append(np.array([t for _, t in data["member"]], dtype=float).reshape(-1, 3))
+        dims.append(dim)
+    return pack_arrays(xyz, conn, mtype, sup, loads, dims)
+
+
+@dataclass
+class BatchResult:
+    """Dense host results of a batched solve: displace/external [B,nJ_max,3], internal [B,nM_max],
+    info [B] (0 ok, k>0: pivot k of the reduced stiffness matrix is not positive)."""
+    displace: np.ndarray
+    external: np.ndarray
+    internal: np.ndarray
+    info: np.ndarray
+
+
+def _require_gpu(device):
+    try:
+        import torch
+    except ImportError as exc:  # pragma: no cover
+        raise HipExtensionError("PyTorch-ROCm is required for device memory and streams") from exc
+    if not torch.cuda.is_available():
+        raise HipExtensionError("no GPU visible: the truss solver has no CPU fallback")
+    return torch, torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+
+
+class DeviceBatch:
+    """A packed batch resident in HBM plus the workspace of the pipeline.
+
+    Build once, call `solve()` any number of times (e.g. after `set_sections`).  Every tensor
+    lives on one device; kernels run on the current stream of that device.
+    """
+
+    def __init__(self, packed: PackedBatch, device=None):
+        torch, dev = _require_gpu(device)
+        self.torch, self.device, self.packed = torch, dev, packed
+        self.lib = _capi.load()
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.B, self.nJ_max, self.nM_max = packed.B, packed.nJ_max, packed.nM_max
+        self.xyz, self.conn = up(packed.xyz), up(packed.conn)
+        self.E, self.A, self.rho = up(packed.E), up(packed.A), up(packed.rho)
+        self.cbits, self.loads = up(packed.cbits), up(packed.loads)
+        self.nJ, self.nM = up(packed.nJ), up(packed.nM)
+        self.n_max = packed.n_max
+        self.ld = self.lib.trs_slab_ld(self.n_max)
+        self.rows = self.lib.trs_slab_rows(self.n_max)
+        B = self.B
+        self.free_index = torch.empty([B, self.nJ_max * 3], dtype=torch.int32, device=dev)
+        self.n_free = torch.empty([B], dtype=torch.int32, device=dev)
+        self.S = torch.empty([B, self.rows, self.ld], dtype=torch.float64, device=dev)
+        self.uf = torch.empty([B, self.rows], dtype=torch.float64, device=dev)
+        self.u = torch.empty([B, self.nJ_max, 3], dtype=torch.float64, device=dev)
+        self.f_ext = torch.empty([B, self.nJ_max, 3], dtype=torch.float64, device=dev)
+        self.N = torch.empty([B, self.nM_max], dtype=torch.float64, device=dev)
+        self.info = torch.empty([B], dtype=torch.int32, device=dev)
+
+    # -- individual stages (used by the parity tests and the benchmark) ------------------
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def dofmap(self):
+        _capi.check(self.lib.trs_dofmap(self.B, self.nJ_max, self.cbits.data_ptr(), self.nJ.data_ptr(),
+                                        self.free_index.data_ptr(), self.n_free.data_ptr(),
+                                        self._stream()), "trs_dofmap")
+
+    def assemble(self, flags=0):
+        _capi.check(self.lib.trs_assemble(
+            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
+            self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
+            self.n_free.data_ptr(), self.nJ.data_ptr(), self.nM.data_ptr(), self.ld, self.rows,
+            self.S.data_ptr(), flags, self._stream()), "trs_assemble")
+
+    def potrf(self):
+        _capi.check(self.lib.trs_potrf_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
+                                               self.S.data_ptr(), self.info.data_ptr(),
+                                               self._stream()), "trs_potrf_batched")
+
+    def potrs(self):
+        _capi.check(self.lib.trs_potrs_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
+                                               self.S.data_ptr(), self.uf.data_ptr(), self.rows,
+                                               self._stream()), "trs_potrs_batched")
+
+    def recover(self):
+        _capi.check(self.lib.trs_recover(
+            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
+            self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
+            self.nJ.data_ptr(), self.nM.data_ptr(), self.uf.data_ptr(), self.rows, self.u.data_ptr(),
+            self.f_ext.data_ptr(), self.N.data_ptr(), self._stream()), "trs_recover")
+
+    def solve(self):
+        """The whole pipeline, one C call, asynchronous on the current stream."""
+        with self.torch.cuda.device(self.device):
+            _capi.check(self.lib.trs_solve(
+                self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), self.conn.data_ptr(),
+                self.E.data_ptr(), self.A.data_ptr(), self.cbits.data_ptr(), self.loads.data_ptr(),
+                self.nJ.data_ptr(), self.nM.data_ptr(), self.free_index.data_ptr(),
+                self.n_free.data_ptr(), self.ld, self.rows, self.S.data_ptr(), self.uf.data_ptr(),
+                self.rows, self.u.data_ptr(), self.f_ext.data_ptr(), self.N.data_ptr(),
+                self.info.data_ptr(), self._stream()), "trs_solve")
+
+    def fitness(self, allow_stress, allow_displace):
+        """(weight, stress_violation, displacement_violation) per truss, on device."""
+        t = self.torch
+        out = [t.empty([self.B], dtype=t.float64, device=self.device) for _ in range(3)]
+        _capi.check(self.lib.trs_fitness(
+            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
+            self.A.data_ptr(), self.rho.data_ptr(), self.nJ.data_ptr(), self.nM.data_ptr(),
+            self.u.data_ptr(), self.N.data_ptr(), float(allow_stress), float(allow_displace),
+            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), self._stream()), "trs_fitness")
+        return out
+
+    def set_sections(self, A, E, rho):
+        """Replace the member sections (host arrays [B,nM_max]); geometry stays resident."""
+        for dst, src in ((self.A, A), (self.E, E), (self.rho, rho)):
+            dst.copy_(self.torch.from_numpy(np.ascontiguousarray(src, dtype=np.float64)))
+
+    def result(self):
+        """Synchronise and download the dense results."""
+        self.torch.cuda.synchronize(self.device)
+        return BatchResult(self.u.cpu().numpy(), self.f_ext.cpu().numpy(), self.N.cpu().numpy(),
+                           self.info.cpu().numpy())
+
+
+def solve_batch(trusses_or_packed, device=None):
+    """Solve many trusses in one device pipeline.  Accepts `list[Truss]` or a `PackedBatch`."""
+    packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
+        else pack_trusses(list(trusses_or_packed))
+    dev = DeviceBatch(packed, device)
+    dev.solve()
+    return dev.result()

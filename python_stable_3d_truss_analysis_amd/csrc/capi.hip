@@ -1,0 +1,101 @@
+// extern "C" entry points declared in include/trs_solver.h: argument checks + kernel launches.
+#include <hip/hip_runtime.h>
+#include "../../include/trs_solver.h"
+#include "trs_common.h"
+
+extern "C" {
+int trs_dofmap_launch(int, int, const uint8_t*, const int*, int*, int*, hipStream_t);
+int trs_assemble_launch(int, int, int, const double*, const int*, const double*, const double*,
+                        const double*, const int*, const int*, const int*, const int*, int, size_t,
+                        int, double*, int, hipStream_t);
+int trs_potrf_launch(int, const int*, int, size_t, double*, int*, hipStream_t);
+int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, hipStream_t);
+int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
+                       const double*, const int*, const int*, const int*, const double*, int, double*,
+                       double*, double*, hipStream_t);
+int trs_fitness_launch(int, int, int, const double*, const int*, const double*, const double*,
+                       const int*, const int*, const double*, const double*, double, double, double*,
+                       double*, double*, hipStream_t);
+}
+
+namespace {
+inline bool bad_slab(int ld, int slab_rows) {
+    return ld < 16 + TRS_NB || ld % 16 != 0 || slab_rows < TRS_NB || slab_rows % TRS_NB != 0 ||
+           ld < slab_rows + 16;
+}
+}  // namespace
+
+extern "C" {
+
+int trs_abi_version(void) { return TRS_ABI_VERSION; }
+
+int trs_slab_rows(int n_max) { return trs_round_up(n_max < 1 ? 1 : n_max, TRS_NB); }
+
+int trs_slab_ld(int n_max) { return trs_slab_rows(n_max) + 16; }
+
+int trs_dofmap(int B, int nJ_max, const uint8_t* cbits, const int32_t* nJ, int32_t* free_index,
+               int32_t* n_free, void* stream) {
+    if (B < 0 || nJ_max <= 0) return (int)hipErrorInvalidValue;
+    return trs_dofmap_launch(B, nJ_max, cbits, nJ, free_index, n_free, (hipStream_t)stream);
+}
+
+int trs_assemble(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn,
+                 const double* E, const double* A, const double* loads, const int32_t* free_index,
+                 const int32_t* n_free, const int32_t* nJ, const int32_t* nM, int ld, int slab_rows,
+                 double* S, int flags, void* stream) {
+    if (B < 0 || nJ_max <= 0 || nM_max < 0 || bad_slab(ld, slab_rows)) return (int)hipErrorInvalidValue;
+    return trs_assemble_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM,
+                               ld, (size_t)slab_rows * ld, slab_rows, S, flags, (hipStream_t)stream);
+}
+
+int trs_potrf_batched(int B, const int32_t* n_free, int ld, int slab_rows, double* S, int32_t* info,
+                      void* stream) {
+    if (B < 0 || bad_slab(ld, slab_rows)) return (int)hipErrorInvalidValue;
+    return trs_potrf_launch(B, n_free, ld, (size_t)slab_rows * ld, S, info, (hipStream_t)stream);
+}
+
+int trs_potrs_batched(int B, const int32_t* n_free, int ld, int slab_rows, const double* S, double* uf,
+                      int ld_uf, void* stream) {
+    if (B < 0 || bad_slab(ld, slab_rows) || ld_uf < slab_rows) return (int)hipErrorInvalidValue;
+    return trs_potrs_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, uf, ld_uf,
+                            (hipStream_t)stream);
+}
+
+int trs_recover(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const double* E,
+                const double* A, const double* loads, const int32_t* free_index, const int32_t* nJ,
+                const int32_t* nM, const double* uf, int ld_uf, double* u, double* f_ext, double* N,
+                void* stream) {
+    if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
+    return trs_recover_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf,
+                              u, f_ext, N, (hipStream_t)stream);
+}
+
+int trs_fitness(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const double* A,
+                const double* rho, const int32_t* nJ, const int32_t* nM, const double* u,
+                const double* N, double allow_stress, double allow_displace, double* weight,
+                double* stress_vio, double* disp_vio, void* stream) {
+    if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
+    return trs_fitness_launch(B, nJ_max, nM_max, xyz, conn, A, rho, nJ, nM, u, N, allow_stress,
+                              allow_displace, weight, stress_vio, disp_vio, (hipStream_t)stream);
+}
+
+int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz, const int32_t* conn,
+              const double* E, const double* A, const uint8_t* cbits, const double* loads,
+              const int32_t* nJ, const int32_t* nM, int32_t* free_index, int32_t* n_free, int ld,
+              int slab_rows, double* S, double* uf, int ld_uf, double* u, double* f_ext, double* N,
+              int32_t* info, void* stream) {
+    if (n_max_bound > slab_rows) return (int)hipErrorInvalidValue;
+    int rc = trs_dofmap(B, nJ_max, cbits, nJ, free_index, n_free, stream);
+    if (rc) return rc;
+    rc = trs_assemble(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM, ld,
+                      slab_rows, S, 0, stream);
+    if (rc) return rc;
+    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, stream);
+    if (rc) return rc;
+    rc = trs_potrs_batched(B, n_free, ld, slab_rows, S, uf, ld_uf, stream);
+    if (rc) return rc;
+    return trs_recover(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf, u,
+                       f_ext, N, stream);
+}
+
+}  // extern "C"

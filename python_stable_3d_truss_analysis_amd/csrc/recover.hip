@@ -1,0 +1,155 @@
+// Result recovery for a batch of solved trusses: displacement scatter (slientruss3d/truss.py:342),
+// member axial forces (truss.py:354-359 with Member.IsTension truss.py:89-91: N = (EA/L) c.(u1-u0),
+// tension positive) and the external force vector (truss.py:348-349): applied load at free DOFs,
+// stiffness reaction K u at constrained DOFs.  The reaction is summed from member end forces
+// (N c on joint1, -N c on joint0) instead of a dense K[~mask,:] @ u.
+//
+// Also the constraint reductions the GA fitness needs (truss.py:166-168,429-462; ga.py:139-149).
+#include "trs_common.h"
+
+namespace {
+
+struct MemberGeom {
+    double len, c[3];
+};
+
+__device__ __forceinline__ MemberGeom member_geom(const double* X, int j0, int j1) {
+    MemberGeom g;
+    double d[3], len2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        d[a] = X[3 * j1 + a] - X[3 * j0 + a];
+        len2 += d[a] * d[a];
+    }
+    g.len = sqrt(len2);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g.c[a] = d[a] / g.len;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void trs_recover_kernel(
+    const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
+    const double* __restrict__ A, const double* __restrict__ loads,
+    const int* __restrict__ free_index, const int* __restrict__ nJ, const int* __restrict__ nM,
+    const int nJ_max, const int nM_max, const double* __restrict__ uf, const int ld_uf,
+    double* __restrict__ u_out, double* __restrict__ f_out, double* __restrict__ N_out) {
+    extern __shared__ double sh[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ndof = 3 * nJ[b], ndof_max = 3 * nJ_max;
+    double* u = sh;              // [ndof_max]
+    double* f = sh + ndof_max;   // [ndof_max]
+    const int* fi = free_index + (size_t)b * ndof_max;
+    const double* F = loads + (size_t)b * ndof_max;
+    const double* ufb = uf + (size_t)b * ld_uf;
+    for (int d = tid; d < ndof_max; d += 256) {
+        const int r = d < ndof ? fi[d] : -1;
+        u[d] = r >= 0 ? ufb[r] : 0.0;
+        f[d] = r >= 0 ? F[d] : 0.0;  // constrained: reaction accumulated below (load ignored)
+    }
+    __syncthreads();
+    const double* X = xyz + (size_t)b * ndof_max;
+    const int members = nM[b];
+    for (int m = tid; m < nM_max; m += 256) {
+        const size_t mm = (size_t)b * nM_max + m;
+        double axial = 0.0;
+        if (m < members) {
+            const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
+            const MemberGeom g = member_geom(X, j0, j1);
+            const double k = E[mm] * A[mm] / g.len;
+            double proj = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) proj += g.c[a] * (u[3 * j1 + a] - u[3 * j0 + a]);
+            axial = k * proj;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (fi[3 * j1 + a] < 0) atomicAdd(&f[3 * j1 + a], axial * g.c[a]);
+                if (fi[3 * j0 + a] < 0) atomicAdd(&f[3 * j0 + a], -axial * g.c[a]);
+            }
+        }
+        N_out[mm] = axial;
+    }
+    __syncthreads();
+    for (int d = tid; d < ndof_max; d += 256) {
+        u_out[(size_t)b * ndof_max + d] = u[d];
+        f_out[(size_t)b * ndof_max + d] = d < ndof ? f[d] : 0.0;
+    }
+}
+
+// Deterministic block sum of one double per thread (256 threads).
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double total = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(256) void trs_fitness_kernel(
+    const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ A,
+    const double* __restrict__ rho, const int* __restrict__ nJ, const int* __restrict__ nM,
+    const int nJ_max, const int nM_max, const double* __restrict__ u, const double* __restrict__ N,
+    const double allow_stress, const double allow_displace, double* __restrict__ weight,
+    double* __restrict__ stress_vio, double* __restrict__ disp_vio) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* X = xyz + (size_t)b * 3 * nJ_max;
+    double w = 0.0, sv = 0.0, dv = 0.0;
+    for (int m = tid; m < nM[b]; m += 256) {
+        const size_t mm = (size_t)b * nM_max + m;
+        const MemberGeom g = member_geom(X, conn[2 * mm], conn[2 * mm + 1]);
+        w += A[mm] * g.len * rho[mm];  // truss.py:52-54
+        const double force = N[mm];
+        if (fabs(force) >= 1e-10) {   // members kept in the sparse dict (truss.py:358-359)
+            const double s = fabs(force) / A[mm];
+            if (s > allow_stress) sv += s - allow_stress;  // truss.py:432
+        }
+    }
+    const double* U = u + (size_t)b * 3 * nJ_max;
+    for (int j = tid; j < nJ[b]; j += 256) {
+        const double ux = U[3 * j], uy = U[3 * j + 1], uz = U[3 * j + 2];
+        if (fabs(ux) >= 1e-10 || fabs(uy) >= 1e-10 || fabs(uz) >= 1e-10) {  // truss.py:344-345
+            const double l = sqrt(ux * ux + uy * uy + uz * uz);
+            if (l > allow_displace) dv += l - allow_displace;  // truss.py:450
+        }
+    }
+    w = block_sum(w, red);
+    sv = block_sum(sv, red);
+    dv = block_sum(dv, red);
+    if (tid == 0) {
+        weight[b] = w;
+        stress_vio[b] = sv;
+        disp_vio[b] = dv;
+    }
+}
+
+}  // namespace
+
+extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
+                                  const double* E, const double* A, const double* loads,
+                                  const int* free_index, const int* nJ, const int* nM,
+                                  const double* uf, int ld_uf, double* u, double* f_ext, double* N,
+                                  hipStream_t stream) {
+    if (B <= 0) return 0;
+    const size_t lds = (size_t)6 * nJ_max * sizeof(double);
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_recover_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(trs_recover_kernel, dim3(B), dim3(256), lds, stream, xyz, conn, E, A, loads,
+                       free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N);
+    return (int)hipGetLastError();
+}
+
+extern "C" int trs_fitness_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
+                                  const double* A, const double* rho, const int* nJ, const int* nM,
+                                  const double* u, const double* N, double allow_stress,
+                                  double allow_displace, double* weight, double* stress_vio,
+                                  double* disp_vio, hipStream_t stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(trs_fitness_kernel, dim3(B), dim3(256), 0, stream, xyz, conn, A, rho, nJ, nM,
+                       nJ_max, nM_max, u, N, allow_stress, allow_displace, weight, stress_vio,
+                       disp_vio);
+    return (int)hipGetLastError();
+}
