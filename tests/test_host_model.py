@@ -1,0 +1,179 @@
+"""CPU tests of the host-side mirror of the reference interface: Truss/Member/MemberType/SupportType,
+JSON I/O, sparse result dicts, constraint checks, packing.  Results are injected from the oracle
+(`AdoptDenseResults`) - the product's Solve() itself needs the GPU and is covered by `-m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import truss_oracle as orc
+from python_stable_3d_truss_analysis_amd import (Member, MemberType, SupportType, Truss,
+                                                 HipExtensionError, TrussNotStableError)
+from python_stable_3d_truss_analysis_amd import batch, utils
+from tests import helpers as H
+
+
+def solved_like_reference(data):
+    """A Truss loaded from `data` with the oracle's dense results installed."""
+    dim = orc.truss_dim(data)
+    truss = Truss(dim).LoadFromJSON(data=data)
+    res = orc.solve(data)
+    truss.AdoptDenseResults(res["u"], res["f_ext"], res["N"])
+    return truss, res
+
+
+def test_support_type_tables():
+    assert [SupportType.NO, SupportType.PIN, SupportType.ROLLER_X, SupportType.ROLLER_Y,
+            SupportType.ROLLER_Z] == [0, 1, 2, 3, 4]
+    assert SupportType.GetResistanceMask(SupportType.ROLLER_X, 3).tolist() == [True, False, False]
+    assert SupportType.GetResistanceMask(SupportType.ROLLER_Y, 2).tolist() == [False, True]
+    assert SupportType.GetResistanceMask(SupportType.PIN, 2).tolist() == [True, True]
+    assert SupportType.GetResistanceNumber(SupportType.PIN, 3) == 3
+    assert SupportType.GetResistanceNumber(SupportType.ROLLER_Z, 3) == 1
+    assert SupportType.GetFromString("ROLLER_Z") == 4 and SupportType.GetFromType(1) == "PIN"
+    with pytest.raises(utils.InvalidSupportTypeError):
+        SupportType.GetResistanceMask(SupportType.ROLLER_Z, 2)   # reference type.py:73-74
+    with pytest.raises(utils.InvalidSupportTypeError):
+        SupportType.GetFromString("WELD")
+    with pytest.raises(utils.DimensionError):
+        Truss(4)
+
+
+def test_member_matches_oracle_local_stiffness():
+    p0, p1 = (1.0, 2.0, 3.0), (4.0, 6.5, -1.0)
+    m = Member(p0, p1, 3, MemberType(2.0, 3e7, 0.3))
+    np.testing.assert_allclose(m.matK, orc.member_matK(p0, p1, 2.0, 3e7), rtol=1e-15)
+    assert m.length == orc.member_length(p0, p1)
+    assert m.k == 3e7 * 2.0 / m.length and m.weight == 2.0 * m.length * 0.3
+    m2 = Member((0.0, 0.0), (3.0, 4.0), 2, MemberType(1.0, 10.0, 1.0))
+    assert m2.matK.shape == (4, 4) and m2.cosines == [0.6, 0.8]
+    assert m2.IsTension(np.array([1.0, 1.0])) and not m2.IsTension(np.array([-1.0, 0.0]))
+    with pytest.raises(utils.DimensionError):
+        Member((0, 0), (1, 1, 1), 3)
+
+
+def test_member_type_aliasing_is_preserved():
+    """A MemberType instance shared by two members is mutated through either (reference
+    truss.py:16-18,44-46) - SURVEY 8b lists it as behaviour not to fix silently."""
+    t = Truss(2)
+    t.AddNewJoint((0, 0), SupportType.PIN); t.AddNewJoint((1, 0), SupportType.PIN); t.AddNewJoint((0, 1))
+    shared = MemberType(1.0, 2.0, 3.0)
+    t.AddNewMember(0, 2, shared); t.AddNewMember(1, 2, shared)
+    t.SetMemberType(0, MemberType(9.0, 8.0, 7.0))
+    assert t.GetMemberType(1).Serialize() == [9.0, 8.0, 7.0]
+    assert MemberType(1, 2, 3) == MemberType(1 + 1e-12, 2, 3)
+
+
+@pytest.mark.parametrize("name", H.data_case_names())
+def test_sparse_views_and_serialize_match_reference_outputs(name):
+    data = H.load_json(name)
+    stored = H.load_json(name.replace("_input_", "_output_"))
+    truss, res = solved_like_reference(data)
+    out = truss.Serialize()
+    assert out["joint"] == stored["joint"] and out["member"] == stored["member"]
+    assert out["force"] == stored["force"]
+    dim, nJ, nM = truss.dim, truss.nJoint, truss.nMember
+    for key, count, width in (("displace", nJ, dim), ("external", nJ, dim), ("internal", nM, None)):
+        assert H.max_scaled_err(orc.densify(out[key], count, width),
+                                orc.densify(stored[key], count, width)) <= 1e-9
+    assert out["weight"] == pytest.approx(stored["weight"], rel=1e-13)
+    # the dicts are sparsified exactly like the oracle's restatement of truss.py:344-359
+    u, f, n = orc.sparsify(res)
+    assert sorted(truss.GetDisplacements()) == sorted(u)
+    assert sorted(truss.GetExternalForces()) == sorted(f)
+    assert sorted(truss.GetInternalForces()) == sorted(n)
+    stress = truss.GetInternalStresses()
+    m0 = next(iter(stress))
+    assert stress[m0] == truss.GetInternalForces()[m0] / truss.GetMemberType(m0).a
+
+
+def test_json_roundtrip_copy_and_getters(tmp_path):
+    data = H.load_json("bar-25_input_0")
+    truss, _ = solved_like_reference(data)
+    path = tmp_path / "out.json"
+    truss.DumpIntoJSON(str(path))
+    back = Truss(3).LoadFromJSON(str(path), isOutputFile=True)
+    assert back.isSolved and back.Serialize() == json.loads(path.read_text())
+    clone = truss.Copy()
+    assert clone.Serialize() == truss.Serialize()
+    assert truss.nJoint == 10 and truss.nMember == 25 and truss.nForce == 4 and truss.nSupport == 4
+    assert truss.nResistance == 12 and truss.isStable
+    assert truss.GetJointPosition(0) == (62.5, 100.0, 200.0)
+    assert truss.GetMemberConnect(1) == (0, 3) and truss.GetForce(2) == (500.0, 0.0, 0.0)
+    assert truss.GetJointIDs() == list(range(10)) and truss.GetMemberIDs() == list(range(25))
+    prot = truss.GetDisplacements()
+    prot[0][0] = 1e9
+    assert truss.GetDisplacements()[0][0] != 1e9          # deep copy by default
+    assert truss.GetDisplacements(False) is truss.GetDisplacements(False)
+    res = truss.GetResistances()
+    assert sorted(res) == [6, 7, 8, 9]
+    total = sum(res.values()) + sum(np.array(v) for v in truss.GetForces().values())
+    assert np.abs(total).max() < 1e-6                      # equilibrium
+    assert len(truss.GetUsedMemberTypes()) == 1
+    with pytest.raises(utils.InvaildJointError):
+        truss.AddExternalForce(99, (1, 0, 0))
+    truss.AddExternalForce(3, (0.0, 1e-12, 0.0))           # zero vectors are dropped (truss.py:181)
+    assert truss.nForce == 4
+
+
+def test_constraint_checks_and_ga_fitness_terms():
+    data = H.load_json("bar-120_input_0")
+    truss, res = solved_like_reference(data)
+    for limit in (1.0, 50.0, 1e9):
+        ok, vio = truss.IsInternalStressAllowed(limit, True)
+        ok_d, vio_d = truss.IsDisplacementAllowed(limit * 1e-3, True)
+        fit, o1, o2 = orc.fitness_terms(data, res, limit, limit * 1e-3)
+        assert (ok, ok_d) == (o1, o2)
+        mine = truss.weight + (0 if ok else vio / limit * 1e5) + (0 if ok_d else vio_d / (limit * 1e-3) * 1e5)
+        assert mine == pytest.approx(fit, rel=1e-12)
+    ok, vio_dict, non = truss.IsInternalStressAllowed(50.0, False, True)
+    assert isinstance(vio_dict, dict) and non >= 0 and ok == (len(vio_dict) == 0)
+    with pytest.raises(utils.TrussNotSolvedError):
+        Truss(3).IsDisplacementAllowed(1.0)
+
+
+def test_stability_count_and_setters():
+    t = Truss(3).LoadFromJSON(data=H.edge_cases()["3d_count_unstable"]["input"])
+    assert not t.isStable
+    with pytest.raises(TrussNotStableError):   # raised before the device is touched
+        t.Solve()
+    t2 = Truss(2).LoadFromJSON(data=H.edge_cases()["2d_pin_rollerY"]["input"])
+    t2.SetJointPosition(2, (2.0, 5.0))
+    assert t2.GetMembers()[1][2].length == pytest.approx((4 + 25) ** 0.5)
+    t2.SetMemberConnect(0, (0, 2))
+    assert t2.GetMemberConnect(0) == (0, 2) and t2.GetMemberFromConnect((0, 2)) is not None
+    t2.SetSupportType(1, SupportType.PIN)            # works here; the reference raises TypeError
+    assert t2.GetSupportType(1) == SupportType.PIN
+    with pytest.raises(utils.NotAllBeSetError):
+        t2.SetMemberTypes({0: MemberType()}, isCheckAllSet=True)
+
+
+def test_pack_layout_and_2d_embedding():
+    d3, d2 = H.load_json("bar-25_input_0"), H.load_json("bar-47_input_0")
+    p = batch.pack_json([d3, d2])
+    assert p.xyz.shape == (2, 22, 3) and p.conn.shape == (2, 47, 2)
+    assert p.nJ.tolist() == [10, 22] and p.nM.tolist() == [25, 47] and p.dim.tolist() == [3, 2]
+    assert p.n_free.tolist() == [18, 40]
+    assert p.cbits[0, :10].tolist() == [0] * 6 + [7] * 4
+    assert set(p.cbits[1, :22].tolist()) == {4, 7} and not p.xyz[1, :, 2].any()
+    assert p.A[0, 0] == 1.0 and p.E[0, 0] == 1e7 and p.rho[0, 0] == 0.1
+    assert p.loads[0, 0].tolist() == [1000.0, 20000.0, -5000.0]
+    # Truss objects and JSON dicts pack identically
+    q = batch.pack_trusses([Truss(3).LoadFromJSON(data=d3), Truss(2).LoadFromJSON(data=d2)])
+    for field in p.__dataclass_fields__:
+        np.testing.assert_array_equal(getattr(p, field), getattr(q, field))
+    r = p.replicate(3)
+    assert r.B == 6 and r.n_free.tolist() == [18, 40] * 3
+    assert p.take([1]).nM.tolist() == [47]
+    # the free-DOF count agrees with the oracle's mask
+    assert int(orc.free_mask(d3).sum()) == 18 and int(orc.free_mask(d2).sum()) == 40
+
+
+def test_solve_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    t = Truss(3).LoadFromJSON(data=H.load_json("bar-25_input_0"))
+    with pytest.raises(HipExtensionError):
+        t.Solve()
