@@ -20,11 +20,49 @@
 // segments of S rows.
 #include "trs_common.h"
 
+// Diagnostic builds only (-DTRS_POTRF_STAMPS via tools/build_variants.sh): per-phase wave-cycle
+// sums, read back through trs_debug_stamps().  The product library compiles the empty struct.
+#ifdef TRS_POTRF_STAMPS
+__device__ unsigned long long g_trs_stamps[8];
+struct Stamps {
+    unsigned long long acc[8], t;
+    __device__ __forceinline__ void start() {
+        for (int i = 0; i < 8; ++i) acc[i] = 0;
+        t = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int i) {
+        const unsigned long long n = __builtin_amdgcn_s_memtime();
+        acc[i] += n - t;
+        t = n;
+    }
+    __device__ __forceinline__ void flush() {
+        if ((threadIdx.x & 63) == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_trs_stamps[i], acc[i]);
+    }
+};
+#else
+struct Stamps {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush() {}
+};
+#endif
+
 namespace {
 
 constexpr int CT = TRS_NB / TRS_TILE;  // 4 column tiles per panel
 constexpr int NW = 4;                  // waves per work-group
-constexpr int RS = 4;                  // row-chunk slots per wave (16 rows each)
+#ifndef TRS_POTRF_RS
+#define TRS_POTRF_RS 4
+#endif
+#ifndef TRS_POTRF_WAVES_PER_SIMD
+#define TRS_POTRF_WAVES_PER_SIMD 2
+#endif
+#ifndef TRS_POTRF_DEPTH
+#define TRS_POTRF_DEPTH 4
+#endif
+constexpr int RS = TRS_POTRF_RS;       // row-chunk slots per wave (16 rows each), 1..4
+constexpr int DEPTH = TRS_POTRF_DEPTH; // k-steps of operand fragments in flight (divides 16)
 
 
 __device__ __forceinline__ double lane_bcast(double v, int src) {
@@ -152,23 +190,36 @@ __device__ __forceinline__ void tile_store(const d4& acc, const Slab& S, int c0,
 // tiles to the right.  Leaves inv(L_ss) and -L_{s2,s} in LDS for the rows below the block.
 // Returns true when a non-positive pivot was met (uniform over the work-group).
 template <int NT>
-__device__ __forceinline__ bool diag_group(const Slab& S, const int r0, PanelLds& sm) {
+__device__ __forceinline__ bool diag_group(const Slab& S, const int r0, PanelLds& sm, Stamps& st) {
     constexpr int w = NT - 1;
     const int lane = threadIdx.x & 63;
     d4 acc[NT];
 #pragma unroll
     for (int s = 0; s < NT; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
 
-    int ok = S.at(0, r0);  // rows k0 .. k0+3 of S, column r0: advanced by 4 rows per k-step
-    const int step = S.ld * 32;
-    for (int k0 = 0; k0 < r0; k0 += 4) {
-        double fb[NT];
+    // Ring of DEPTH k-steps of fragments in flight; r0 / 4 is a multiple of 16, so of DEPTH.
+    // Prefetches past k = r0 stay inside the slab (rows < n_pad) and are never used.
+    {
+        const int step = S.ld * 32;
+        int ok = S.at(0, r0);  // rows k0 .. k0+3 of S, column r0: advanced by 4 rows per k-step
+        double fb[DEPTH][NT];
 #pragma unroll
-        for (int s = 0; s < NT; ++s) fb[s] = S.load(ok + 128 * s);
+        for (int d = 0; d < DEPTH - 1; ++d)
 #pragma unroll
-        for (int s = 0; s < NT; ++s) acc[s] = mfma_f64(fb[s], fb[w], acc[s]);
-        ok += step;
+            for (int s = 0; s < NT; ++s) fb[d][s] = S.load(ok + d * step + 128 * s);
+        for (int k0 = 0; k0 < r0; k0 += 4 * DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int nd = (d + DEPTH - 1) % DEPTH;
+#pragma unroll
+                for (int s = 0; s < NT; ++s) fb[nd][s] = S.load(ok + (d + DEPTH - 1) * step + 128 * s);
+#pragma unroll
+                for (int s = 0; s < NT; ++s) acc[s] = mfma_f64(fb[d][s], fb[d][w], acc[s]);
+            }
+            ok += DEPTH * step;
+        }
     }
+    st.mark(0);
 #pragma unroll
     for (int s = 0; s < NT; ++s) tile_rsub(acc[s], S, r0 + 16 * s, r0 + 16 * w);
 
@@ -199,6 +250,7 @@ __device__ __forceinline__ bool diag_group(const Slab& S, const int r0, PanelLds
     }
 #pragma unroll
     for (int s = 0; s < NT; ++s) tile_store(acc[s], S, r0 + 16 * s, r0 + 16 * w);
+    st.mark(1);
     return false;
 }
 
@@ -208,7 +260,7 @@ __device__ __forceinline__ bool diag_group(const Slab& S, const int r0, PanelLds
 // (fragments left in LDS by diag_group), store.
 template <int NV>
 __device__ __forceinline__ void panel_group(const Slab& S, const int r0, const int rowbase,
-                                            const PanelLds& sm) {
+                                            const PanelLds& sm, Stamps& st) {
     const int lane = threadIdx.x & 63;
     d4 acc[NV][CT];
 #pragma unroll
@@ -221,34 +273,33 @@ __device__ __forceinline__ void panel_group(const Slab& S, const int r0, const i
         int ob = S.at(0, r0);       // B side: rows k0 .. k0+3 of S, columns of the panel
         int oa = S.at(0, rowbase);  // A side: same rows of S, columns = the wave's matrix rows
         const int step = S.ld * 32;
-        double fb0[CT], fa0[NV], fb1[CT], fa1[NV];
+        double fb[DEPTH][CT], fa[DEPTH][NV];
 #pragma unroll
-        for (int s = 0; s < CT; ++s) fb0[s] = S.load(ob + 128 * s);
+        for (int d = 0; d < DEPTH - 1; ++d) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) fa0[v] = S.load(oa + 512 * v);
-        for (int k0 = 0; k0 < r0; k0 += 8) {
+            for (int s = 0; s < CT; ++s) fb[d][s] = S.load(ob + d * step + 128 * s);
 #pragma unroll
-            for (int s = 0; s < CT; ++s) fb1[s] = S.load(ob + step + 128 * s);
+            for (int v = 0; v < NV; ++v) fa[d][v] = S.load(oa + d * step + 512 * v);
+        }
+        for (int k0 = 0; k0 < r0; k0 += 4 * DEPTH) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) fa1[v] = S.load(oa + step + 512 * v);
+            for (int d = 0; d < DEPTH; ++d) {
+                const int nd = (d + DEPTH - 1) % DEPTH;
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
+                for (int s = 0; s < CT; ++s) fb[nd][s] = S.load(ob + (d + DEPTH - 1) * step + 128 * s);
 #pragma unroll
-                for (int s = 0; s < CT; ++s) acc[v][s] = mfma_f64(fb0[s], fa0[v], acc[v][s]);
-            ob += 2 * step;
-            oa += 2 * step;
-            // rows r0 .. r0+3 of S exist (r0 < n_pad), so the last prefetch stays in bounds
+                for (int v = 0; v < NV; ++v) fa[nd][v] = S.load(oa + (d + DEPTH - 1) * step + 512 * v);
 #pragma unroll
-            for (int s = 0; s < CT; ++s) fb0[s] = S.load(ob + 128 * s);
+                for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int v = 0; v < NV; ++v) fa0[v] = S.load(oa + 512 * v);
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int s = 0; s < CT; ++s) acc[v][s] = mfma_f64(fb1[s], fa1[v], acc[v][s]);
+                    for (int s = 0; s < CT; ++s) acc[v][s] = mfma_f64(fb[d][s], fa[d][v], acc[v][s]);
+            }
+            ob += DEPTH * step;
+            oa += DEPTH * step;
         }
     }
 
+    st.mark(2);
     // acc = K_panel - acc, one row chunk at a time (bounds the loads in flight)
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -257,6 +308,7 @@ __device__ __forceinline__ void panel_group(const Slab& S, const int r0, const i
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    st.mark(3);
 #pragma unroll
     for (int s = 0; s < CT; ++s) {
         double wf[4];
@@ -285,9 +337,10 @@ __device__ __forceinline__ void panel_group(const Slab& S, const int r0, const i
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int s = 0; s < CT; ++s) tile_store(acc[v][s], S, r0 + 16 * s, rowbase + 64 * v);
+    st.mark(4);
 }
 
-__global__ __launch_bounds__(NW * 64, 2) void trs_potrf_kernel(double* __restrict__ S_all,
+__global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_kernel(double* __restrict__ S_all,
                                                                const int* __restrict__ n_free,
                                                                const int ld, const size_t slab_stride,
                                                                int* __restrict__ info) {
@@ -309,13 +362,15 @@ __global__ __launch_bounds__(NW * 64, 2) void trs_potrf_kernel(double* __restric
     S.loff = ((unsigned)(lane >> 4) * (unsigned)ld + (unsigned)(lane & 15)) * 8u;
     const int nchunks = npad / 16 + 1;  // + the right-hand-side chunk at rows n_pad .. n_pad+15
 
+    Stamps st;
+    st.start();
     for (int r0 = 0; r0 < npad; r0 += TRS_NB) {
         bool bad;
         switch (wave) {
-            case 0: bad = diag_group<1>(S, r0, sm); break;
-            case 1: bad = diag_group<2>(S, r0, sm); break;
-            case 2: bad = diag_group<3>(S, r0, sm); break;
-            default: bad = diag_group<4>(S, r0, sm); break;
+            case 0: bad = diag_group<1>(S, r0, sm, st); break;
+            case 1: bad = diag_group<2>(S, r0, sm, st); break;
+            case 2: bad = diag_group<3>(S, r0, sm, st); break;
+            default: bad = diag_group<4>(S, r0, sm, st); break;
         }
         if (bad) {
             if (threadIdx.x == 0) info[b] = sm.info;
@@ -328,18 +383,38 @@ __global__ __launch_bounds__(NW * 64, 2) void trs_potrf_kernel(double* __restric
             const int rowbase = r0 + (CT + g0 + wave) * 16;
             switch (nv) {
                 case 0: break;
-                case 1: panel_group<1>(S, r0, rowbase, sm); break;
-                case 2: panel_group<2>(S, r0, rowbase, sm); break;
-                case 3: panel_group<3>(S, r0, rowbase, sm); break;
-                default: panel_group<4>(S, r0, rowbase, sm); break;
+                case 1: panel_group<1>(S, r0, rowbase, sm, st); break;
+#if TRS_POTRF_RS >= 2
+                case 2: panel_group<2>(S, r0, rowbase, sm, st); break;
+#endif
+#if TRS_POTRF_RS >= 3
+                case 3: panel_group<3>(S, r0, rowbase, sm, st); break;
+#endif
+#if TRS_POTRF_RS >= 4
+                case 4: panel_group<4>(S, r0, rowbase, sm, st); break;
+#endif
+                default: break;
             }
         }
         __syncthreads();  // this panel's stores are visible to the next panel's loads
+        st.mark(5);
     }
+    st.flush();
     if (threadIdx.x == 0) info[b] = 0;
 }
 
 }  // namespace
+
+#ifdef TRS_POTRF_STAMPS
+extern "C" int trs_debug_stamps(unsigned long long* host_out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_trs_stamps), sizeof(g_trs_stamps));
+    if (reset) {
+        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trs_stamps), zero, sizeof(zero));
+    }
+    return rc;
+}
+#endif
 
 extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, double* S,
                                 int* info, hipStream_t stream) {

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build experiment variants of the solver library with different potrf tuning macros:
+#   tools/build_variants.sh "tag1:-DTRS_POTRF_RS=2 -DTRS_POTRF_WAVES_PER_SIMD=4" "tag2:..."
+# -> python_stable_3d_truss_analysis_amd/variants/libtrs_<tag>.so   (git-ignored; travels with gpurun)
+set -e
+cd "$(dirname "$0")/../python_stable_3d_truss_analysis_amd/csrc"
+mkdir -p ../variants
+for spec in "$@"; do
+  tag=${spec%%:*}; flags=${spec#*:}
+  objs=""
+  for f in dofmap assemble potrf potrs recover capi; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-value $flags -c $f.hip -o /tmp/var_${tag}_$f.o &
+    objs="$objs /tmp/var_${tag}_$f.o"
+  done
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../variants/libtrs_$tag.so
+  echo "built variants/libtrs_$tag.so ($flags)"
+done

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""A/B timing of solver-library variants (tools/build_variants.sh) in ONE process, interleaved rounds
+(cdna_hip_programming.md rule 24).  Times each pipeline stage with events on the launch stream and
+checks every variant's solution against the first one.
+
+    python tools/potrf_variants.py [--batch 4096] [--rounds 5] tagA tagB ...   ('default' = the product lib)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from python_stable_3d_truss_analysis_amd import _capi, batch
+
+
+def load_variant(tag):
+    path = _capi.LIB_PATH if tag == "default" else os.path.join(
+        ROOT, "python_stable_3d_truss_analysis_amd", "variants", f"libtrs_{tag}.so")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in _capi.SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tags", nargs="+")
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--case", default="bar-942_input_0")
+    args = ap.parse_args()
+    with open(os.path.join(ROOT, "tests", "golden", "data", args.case + ".json")) as fh:
+        data = json.load(fh)
+    dev = batch.DeviceBatch(batch.pack_json([data]).replicate(args.batch))
+    libs = {t: load_variant(t) for t in args.tags}
+    stages = ("dofmap", "assemble", "potrf", "potrs", "recover")
+    times = {t: {s: [] for s in stages} for t in args.tags}
+    ref_u = None
+    for rnd in range(args.rounds + 1):
+        for tag in args.tags:
+            dev.lib = libs[tag]
+            evs = []
+            for s in stages:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); getattr(dev, s)(); e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            if rnd == 0:   # warm-up round + correctness
+                u = dev.u[0].cpu().numpy()
+                info = int(dev.info.abs().sum().item())
+                if ref_u is None:
+                    ref_u = u
+                err = float(np.abs(u - ref_u).max() / np.abs(ref_u).max())
+                print(f"{tag}: info_nonzero={info} max_rel_diff_vs_first={err:.2e}")
+                continue
+            for s, (e0, e1) in zip(stages, evs):
+                times[tag][s].append(e0.elapsed_time(e1))
+    for tag in args.tags:
+        if hasattr(libs[tag], "trs_debug_stamps"):   # diagnostic build: per-phase wave-cycle shares of potrf
+            buf = (ctypes.c_ulonglong * 8)()
+            libs[tag].trs_debug_stamps(buf, 1)
+            tot = float(sum(buf)) or 1.0
+            names = ("diag_gemm", "diag_factor", "panel_gemm", "panel_ksub", "panel_trsm_store", "panel_end_barrier")
+            print(f"{tag} stamp shares: " + ", ".join(f"{n} {buf[i] / tot:.3f}" for i, n in enumerate(names)))
+        med = {s: float(np.median(v)) for s, v in times[tag].items()}
+        mn = {s: float(np.min(v)) for s, v in times[tag].items()}
+        total = sum(med.values())
+        print(f"{tag:>12}: potrf med {med['potrf']:.3f} min {mn['potrf']:.3f} ms | assemble {med['assemble']:.3f} "
+              f"| potrs {med['potrs']:.3f} | recover {med['recover']:.3f} | total {total:.3f} ms "
+              f"-> {args.batch / total * 1e3:.0f} solves/s")
+
+
+if __name__ == "__main__":
+    main()
