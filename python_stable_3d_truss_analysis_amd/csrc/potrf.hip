@@ -4,8 +4,15 @@
 // Replaces the factorisation inside np.linalg.solve of the reference
 // (slientruss3d/truss.py:343; LAPACK dgesv there, Cholesky here: K_ff is SPD).
 //
-// One work-group (4 waves) per truss; two work-groups per CU so that one group's serial
-// 16x16 diagonal factorisations hide under the other's MFMA stream.
+// One work-group (4 waves) per truss, two or three work-groups per CU.  Per 64-column panel:
+//   D  every wave updates one 16-row chunk of the 64 x 64 diagonal block and hands its tiles to
+//      wave 0 through LDS;
+//   F  wave 0 alone factors the block (four 16 x 16 scalar factorisations + 64 MFMAs) and leaves
+//      inv(L_ss) and L_{s2,s} as MFMA operand fragments in LDS;
+//   I  meanwhile the other waves (and wave 0 once F is done) pull 64-row work items from an LDS
+//      queue: stream the update  K - L[rows, :r0] L[panel, :r0]^T  through the MFMA pipe, wait for
+//      F, solve against the diagonal block with MFMAs, store.
+// The serial part F is off the other waves' critical path; the queue balances the waves.
 //
 // Storage (see include/trs_solver.h): S[c][i] row-major, only i >= tile start of c is used.
 // With U = L^T stored in place, "row k of S" holds column k of L, so the MFMA operand
@@ -141,13 +148,23 @@ __device__ __forceinline__ int chol16_invert(d4& t, ChScratch& sc, double* wfrag
     return bad;
 }
 
+// pair index of a strictly-lower tile (u, s), s < u < 4, and of a lower tile incl. diagonal
+__device__ __forceinline__ constexpr int lf_idx(int u, int s) { return u * (u - 1) / 2 + s; }
+__device__ __forceinline__ constexpr int t_idx(int u, int s) { return u * (u + 1) / 2 + s; }
+
 struct PanelLds {
     // inv(L_ss) as MFMA A-fragments: W[s][r*64 + lane] = inv(L_ss)[lane & 15][4 r + (lane >> 4)]
     double W[CT][256];
-    // -L_{s2,s} (s2 > s), same fragment layout: rows of tile s2 against columns of tile s
-    double Lneg[CT][CT][256];
+    // L_{u,s} (u > s) as A-fragments = the D-form registers of the tile (rows of tile u, columns
+    // of tile s): Lf[lf_idx(u,s)][r*64 + lane]
+    double Lf[6][256];
+    // diagonal-block tiles (D-form) handed from the D waves to the factor wave: T[t_idx(u,s)]
+    double T[10][256];
     ChScratch ch;  // scratch of the scalar 16x16 factorisation
-    int info;
+    int info;      // 1-based column of the first non-positive pivot, 0 = none
+    int d_done;    // diagonal chunks updated so far (4 per panel, monotone over panels)
+    int f_done;    // panels whose diagonal block is factored (monotone)
+    int queue;     // next work item (monotone over panels)
 };
 
 // Address helper: every global access of the factorisation is "wave-uniform offset + the same
@@ -170,12 +187,18 @@ struct Slab {
     }
 };
 
+// acc -= A * B : the BLGP field of the f64 MFMA is NEG[2:0] (bit 0 negates A; probed on gfx950
+// with tools/mfma_neg_test.hip).
+__device__ __forceinline__ d4 mfma_f64_negA(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+}
+
 // D-form tile (rows c0 .. c0+15 of S = panel columns, columns i0 .. i0+15 of S = matrix rows):
 // comp r of lane (lq, li) <-> S[c0 + lq + 4 r][i0 + li].
-__device__ __forceinline__ void tile_rsub(d4& acc, const Slab& S, int c0, int i0) {
+__device__ __forceinline__ void tile_load(d4& acc, const Slab& S, int c0, int i0) {
     const int o = S.at(c0, i0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = S.load(o + r * (S.ld * 32)) - acc[r];
+    for (int r = 0; r < 4; ++r) acc[r] = S.load(o + r * (S.ld * 32));
 }
 __device__ __forceinline__ void tile_store(const d4& acc, const Slab& S, int c0, int i0) {
     const int o = S.at(c0, i0);
@@ -183,23 +206,30 @@ __device__ __forceinline__ void tile_store(const d4& acc, const Slab& S, int c0,
     for (int r = 0; r < 4; ++r) S.store(o + r * (S.ld * 32), acc[r]);
 }
 
-// ---- the panel's 64 x 64 diagonal block -------------------------------------------------------
-// Wave w (= NT - 1) owns row chunk w of the block and its tiles s = 0 .. w (lower block
-// triangle).  Update with the columns left of the panel, then factor tile by tile:
-// chol16 of the diagonal tile by its owner, X = W T for the tiles below it, rank-16 update of the
-// tiles to the right.  Leaves inv(L_ss) and -L_{s2,s} in LDS for the rows below the block.
-// Returns true when a non-positive pivot was met (uniform over the work-group).
+// LDS hand-off flags (work-group scope; LDS is coherent inside a work-group).
+__device__ __forceinline__ void lds_signal_add(int* flag) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_wait_ge(int* flag, int target) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+        __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- D: one 16-row chunk of the panel's 64 x 64 diagonal block ---------------------------------
+// Wave w (= NT - 1) owns row chunk w of the block and its tiles s = 0 .. w:
+//   T_{w,s} = K_{w,s} - sum_{k < r0} L[chunk w][k] L[tile s][k]^T      -> LDS, for the factor wave.
 template <int NT>
-__device__ __forceinline__ bool diag_group(const Slab& S, const int r0, PanelLds& sm, Stamps& st) {
+__device__ __forceinline__ void diag_update(const Slab& S, const int r0, PanelLds& sm, Stamps& st) {
     constexpr int w = NT - 1;
     const int lane = threadIdx.x & 63;
     d4 acc[NT];
 #pragma unroll
-    for (int s = 0; s < NT; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
-
-    // Ring of DEPTH k-steps of fragments in flight; r0 / 4 is a multiple of 16, so of DEPTH.
-    // Prefetches past k = r0 stay inside the slab (rows < n_pad) and are never used.
-    {
+    for (int s = 0; s < NT; ++s) tile_load(acc[s], S, r0 + 16 * s, r0 + 16 * w);
+    if (r0 > 0) {
+        // Ring of DEPTH k-steps of fragments in flight; r0 / 4 is a multiple of 16, so of DEPTH.
+        // Prefetches past k = r0 stay inside the slab (rows < n_pad) and are never used.
         const int step = S.ld * 32;
         int ok = S.at(0, r0);  // rows k0 .. k0+3 of S, column r0: advanced by 4 rows per k-step
         double fb[DEPTH][NT];
@@ -214,64 +244,89 @@ __device__ __forceinline__ bool diag_group(const Slab& S, const int r0, PanelLds
 #pragma unroll
                 for (int s = 0; s < NT; ++s) fb[nd][s] = S.load(ok + (d + DEPTH - 1) * step + 128 * s);
 #pragma unroll
-                for (int s = 0; s < NT; ++s) acc[s] = mfma_f64(fb[d][s], fb[d][w], acc[s]);
+                for (int s = 0; s < NT; ++s) acc[s] = mfma_f64_negA(fb[d][s], fb[d][w], acc[s]);
             }
             ok += DEPTH * step;
         }
     }
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm.T[t_idx(w, s)][r * 64 + lane] = acc[s][r];
+    lds_signal_add(&sm.d_done);
     st.mark(0);
-#pragma unroll
-    for (int s = 0; s < NT; ++s) tile_rsub(acc[s], S, r0 + 16 * s, r0 + 16 * w);
-
-#pragma unroll
-    for (int s = 0; s < CT; ++s) {
-        if (s == w) {
-            const int bad = chol16_invert(acc[w], sm.ch, sm.W[s]);
-            if (bad >= 0 && lane == 0) sm.info = r0 + 16 * s + bad + 1;
-        }
-        __syncthreads();
-        if (sm.info != 0) return true;
-        if (s < w) {  // X_s^T = inv(L_ss) T_s^T ; publish -L_{w,s}
-            d4 x = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x = mfma_f64(sm.W[s][r * 64 + lane], acc[s < NT ? s : 0][r], x);
-            acc[s < NT ? s : 0] = x;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sm.Lneg[w][s][r * 64 + lane] = -x[r];
-        }
-        __syncthreads();
-        if (s < w) {
-#pragma unroll
-            for (int s2 = s + 1; s2 < NT; ++s2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[s2] = mfma_f64(sm.Lneg[s2][s][r * 64 + lane], acc[s < NT ? s : 0][r], acc[s2]);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < NT; ++s) tile_store(acc[s], S, r0 + 16 * s, r0 + 16 * w);
-    st.mark(1);
-    return false;
 }
 
-// ---- rows below the diagonal block -------------------------------------------------------------
-// The wave owns NV row chunks (16 rows each, 64 rows apart, first at row `rowbase`) and all four
-// column tiles of the panel: update, subtract from K, solve against the factored diagonal block
-// (fragments left in LDS by diag_group), store.
+// ---- F: factor the 64 x 64 diagonal block (one wave, everything in registers) -------------------
+// t[u][s] (s <= u) are the lower tiles in D-form.  For s = 0..3: scalar Cholesky of T_ss, then
+// X_{u,s}^T = inv(L_ss) T_{u,s}^T for the tiles below it and the rank-16 update of the tiles to the
+// right; a D-form register r of X_{u,s} is at the same time the A-fragment (k-step r) of L_{u,s}.
+__device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelLds& sm) {
+    const int lane = threadIdx.x & 63;
+    d4 t[CT][CT];
+#pragma unroll
+    for (int u = 0; u < CT; ++u)
+#pragma unroll
+        for (int s = 0; s <= u; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[u][s][r] = sm.T[t_idx(u, s)][r * 64 + lane];
+    bool ok = true;
+#pragma unroll
+    for (int s = 0; s < CT; ++s) {
+        if (ok) {
+            const int bad = chol16_invert(t[s][s], sm.ch, sm.W[s]);
+            if (bad >= 0) {
+                if (lane == 0) sm.info = r0 + 16 * s + bad + 1;
+                ok = false;
+            }
+        }
+        if (ok) {
+            double wf[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wf[r] = sm.W[s][r * 64 + lane];
+#pragma unroll
+            for (int u = s + 1; u < CT; ++u) {
+                d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x = mfma_f64(wf[r], t[u][s][r], x);
+                t[u][s] = x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm.Lf[lf_idx(u, s)][r * 64 + lane] = x[r];
+            }
+#pragma unroll
+            for (int u = s + 1; u < CT; ++u)
+#pragma unroll
+                for (int s2 = s + 1; s2 <= u; ++s2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[u][s2] = mfma_f64_negA(t[s2][s][r], t[u][s][r], t[u][s2]);
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int s = 0; s <= u; ++s) tile_store(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+    }
+    lds_signal_add(&sm.f_done);
+}
+
+// ---- I: one work item = NV consecutive 16-row chunks below the diagonal block ---------------------
+// Update (streams L from HBM, B-side fragments shared through L1/L2), wait for the factor wave,
+// solve against the diagonal block with the fragments it left in LDS, store.
 template <int NV>
-__device__ __forceinline__ void panel_group(const Slab& S, const int r0, const int rowbase,
-                                            const PanelLds& sm, Stamps& st) {
+__device__ __forceinline__ void panel_item(const Slab& S, const int r0, const int rowbase,
+                                           PanelLds& sm, const int f_target, Stamps& st) {
     const int lane = threadIdx.x & 63;
     d4 acc[NV][CT];
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int s = 0; s < CT; ++s) acc[v][s] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < CT; ++s) tile_load(acc[v][s], S, r0 + 16 * s, rowbase + 16 * v);
 
-    // acc[v][s](c, i) = sum_{k < r0} L[c][k] L[i][k]
+    // acc[v][s](c, i) = K - sum_{k < r0} L[c][k] L[i][k]
     if (r0 > 0) {
         int ob = S.at(0, r0);       // B side: rows k0 .. k0+3 of S, columns of the panel
-        int oa = S.at(0, rowbase);  // A side: same rows of S, columns = the wave's matrix rows
+        int oa = S.at(0, rowbase);  // A side: same rows of S, columns = the item's matrix rows
         const int step = S.ld * 32;
         double fb[DEPTH][CT], fa[DEPTH][NV];
 #pragma unroll
@@ -279,7 +334,7 @@ __device__ __forceinline__ void panel_group(const Slab& S, const int r0, const i
 #pragma unroll
             for (int s = 0; s < CT; ++s) fb[d][s] = S.load(ob + d * step + 128 * s);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) fa[d][v] = S.load(oa + d * step + 512 * v);
+            for (int v = 0; v < NV; ++v) fa[d][v] = S.load(oa + d * step + 128 * v);
         }
         for (int k0 = 0; k0 < r0; k0 += 4 * DEPTH) {
 #pragma unroll
@@ -288,27 +343,21 @@ __device__ __forceinline__ void panel_group(const Slab& S, const int r0, const i
 #pragma unroll
                 for (int s = 0; s < CT; ++s) fb[nd][s] = S.load(ob + (d + DEPTH - 1) * step + 128 * s);
 #pragma unroll
-                for (int v = 0; v < NV; ++v) fa[nd][v] = S.load(oa + (d + DEPTH - 1) * step + 512 * v);
+                for (int v = 0; v < NV; ++v) fa[nd][v] = S.load(oa + (d + DEPTH - 1) * step + 128 * v);
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int s = 0; s < CT; ++s) acc[v][s] = mfma_f64(fb[d][s], fa[d][v], acc[v][s]);
+                    for (int s = 0; s < CT; ++s) acc[v][s] = mfma_f64_negA(fb[d][s], fa[d][v], acc[v][s]);
             }
             ob += DEPTH * step;
             oa += DEPTH * step;
         }
     }
-
     st.mark(2);
-    // acc = K_panel - acc, one row chunk at a time (bounds the loads in flight)
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-#pragma unroll
-        for (int s = 0; s < CT; ++s) tile_rsub(acc[v][s], S, r0 + 16 * s, rowbase + 64 * v);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
+    lds_wait_ge(&sm.f_done, f_target);
     st.mark(3);
+    if (sm.info != 0) return;
+
 #pragma unroll
     for (int s = 0; s < CT; ++s) {
         double wf[4];
@@ -325,31 +374,34 @@ __device__ __forceinline__ void panel_group(const Slab& S, const int r0, const i
         for (int s2 = s + 1; s2 < CT; ++s2) {  // T_{s2}^T -= L_{s2,s} X_s^T
             double lf[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lf[r] = sm.Lneg[s2][s][r * 64 + lane];
+            for (int r = 0; r < 4; ++r) lf[r] = sm.Lf[lf_idx(s2, s)][r * 64 + lane];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[v][s2] = mfma_f64(lf[r], acc[v][s][r], acc[v][s2]);
+                for (int r = 0; r < 4; ++r) acc[v][s2] = mfma_f64_negA(lf[r], acc[v][s][r], acc[v][s2]);
         }
     }
-
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int s = 0; s < CT; ++s) tile_store(acc[v][s], S, r0 + 16 * s, rowbase + 64 * v);
+        for (int s = 0; s < CT; ++s) tile_store(acc[v][s], S, r0 + 16 * s, rowbase + 16 * v);
     st.mark(4);
 }
 
-__global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_kernel(double* __restrict__ S_all,
-                                                               const int* __restrict__ n_free,
-                                                               const int ld, const size_t slab_stride,
-                                                               int* __restrict__ info) {
+__global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_kernel(
+    double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
+    int* __restrict__ info) {
     __shared__ PanelLds sm;
     const int b = blockIdx.x;
     const int npad = trs_round_up(n_free[b], TRS_NB);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) sm.info = 0;
+    if (threadIdx.x == 0) {
+        sm.info = 0;
+        sm.d_done = 0;
+        sm.f_done = 0;
+        sm.queue = 0;
+    }
     __syncthreads();
     if (npad == 0) {
         if (threadIdx.x == 0) info[b] = 0;
@@ -364,43 +416,50 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
 
     Stamps st;
     st.start();
-    for (int r0 = 0; r0 < npad; r0 += TRS_NB) {
-        bool bad;
+    int qbase = 0;
+    for (int r0 = 0, panel = 0; r0 < npad; r0 += TRS_NB, ++panel) {
         switch (wave) {
-            case 0: bad = diag_group<1>(S, r0, sm, st); break;
-            case 1: bad = diag_group<2>(S, r0, sm, st); break;
-            case 2: bad = diag_group<3>(S, r0, sm, st); break;
-            default: bad = diag_group<4>(S, r0, sm, st); break;
+            case 0: diag_update<1>(S, r0, sm, st); break;
+            case 1: diag_update<2>(S, r0, sm, st); break;
+            case 2: diag_update<3>(S, r0, sm, st); break;
+            default: diag_update<4>(S, r0, sm, st); break;
         }
-        if (bad) {
-            if (threadIdx.x == 0) info[b] = sm.info;
-            return;
+        if (wave == 0) {
+            lds_wait_ge(&sm.d_done, 4 * (panel + 1));
+            factor_block(S, r0, sm);
+            st.mark(1);
         }
         const int below = nchunks - r0 / 16 - CT;  // row chunks under the diagonal block (>= 1)
-        for (int g0 = 0; g0 < below; g0 += NW * RS) {
-            const int rem = below - g0 - wave;
-            const int nv = rem <= 0 ? 0 : min(RS, (rem + NW - 1) / NW);
-            const int rowbase = r0 + (CT + g0 + wave) * 16;
+        const int nitems = (below + RS - 1) / RS;
+        for (;;) {
+            int item = 0;
+            if (lane == 0) item = __hip_atomic_fetch_add(&sm.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            item = __builtin_amdgcn_readfirstlane(item) - qbase;
+            if (item >= nitems) break;
+            const int nv = min(RS, below - item * RS);
+            const int rowbase = r0 + (CT + item * RS) * 16;
             switch (nv) {
-                case 0: break;
-                case 1: panel_group<1>(S, r0, rowbase, sm, st); break;
+                case 1: panel_item<1>(S, r0, rowbase, sm, panel + 1, st); break;
 #if TRS_POTRF_RS >= 2
-                case 2: panel_group<2>(S, r0, rowbase, sm, st); break;
+                case 2: panel_item<2>(S, r0, rowbase, sm, panel + 1, st); break;
 #endif
 #if TRS_POTRF_RS >= 3
-                case 3: panel_group<3>(S, r0, rowbase, sm, st); break;
+                case 3: panel_item<3>(S, r0, rowbase, sm, panel + 1, st); break;
 #endif
 #if TRS_POTRF_RS >= 4
-                case 4: panel_group<4>(S, r0, rowbase, sm, st); break;
+                case 4: panel_item<4>(S, r0, rowbase, sm, panel + 1, st); break;
 #endif
                 default: break;
             }
         }
-        __syncthreads();  // this panel's stores are visible to the next panel's loads
+        // every wave overshoots the queue by exactly one failed pull per panel
+        qbase += nitems + NW;
+        __syncthreads();  // this panel's stores are visible to the next panel's loads; LDS reusable
         st.mark(5);
+        if (sm.info != 0) break;
     }
     st.flush();
-    if (threadIdx.x == 0) info[b] = 0;
+    if (threadIdx.x == 0) info[b] = sm.info;
 }
 
 }  // namespace
