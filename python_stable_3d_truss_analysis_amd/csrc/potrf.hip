@@ -5,8 +5,8 @@
 // (slientruss3d/truss.py:343; LAPACK dgesv there, Cholesky here: K_ff is SPD).
 //
 // One work-group (4 waves) per truss, two or three work-groups per CU.  Per 64-column panel:
-//   D  every wave updates one 16-row chunk of the 64 x 64 diagonal block and hands its tiles to
-//      wave 0 through LDS;
+//   D  the four waves update the 64 x 64 diagonal block (5 of its 10 lower tiles x half of the
+//      k range each) and hand the partial tiles to wave 0 through LDS;
 //   F  wave 0 alone factors the block (four 16 x 16 scalar factorisations + 64 MFMAs) and leaves
 //      inv(L_ss) and L_{s2,s} as MFMA operand fragments in LDS;
 //   I  meanwhile the other waves (and wave 0 once F is done) pull 64-row work items from an LDS
@@ -79,73 +79,77 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 }
 
 // Cholesky of one symmetric 16x16 tile by the calling wave, plus the inverse of its factor.
-// The tile stays in D-form in four registers per lane (t[r] = T[c = lq + 4 r][i = li]); LDS is
-// used only to broadcast the pivot row of each step, so the routine adds almost nothing to the
-// register pressure of the accumulators around it.
-//   t       : in  the symmetric tile; out U = L^T in D-form with exact zeros below the diagonal
-//   sc      : scratch, ChScratch layout below
+// Runs in the factor wave, which holds no streaming accumulators, so it can afford a row-owner
+// copy of the tile in registers: lane li (every quarter-wave holds the same copy) owns row li,
+// a[k] = T[li][k].  Pivots, the column of the running step and the entries of L needed by the
+// inverse are broadcast with v_readlane (compile-time lanes, SGPR results): no LDS traffic and
+// no cross-lane waits inside the 16 sequential steps.
+//   t       : in  the symmetric tile in D-form (t[r] = T[c = lq + 4 r][i = li]);
+//             out U = L^T in D-form with exact zeros below the diagonal
+//   sc      : LDS scratch (layout conversion D-form <-> row owner, inverse hand-over)
 //   wfrag   : receives inv(L) as A-fragments (layout of PanelLds::W[s])
-// Returns the 0-based index of the first non-positive pivot, or -1.
+// Leaves the 0-based index of the first non-positive pivot, or -1, in sc.bad.
 struct ChScratch {
-    double U[16][17];   // U[k][i] = L[i][k]
+    double U[16][17];   // the tile on entry (row-major, symmetric)
     double Wt[16][17];  // Wt[t][c] = inv(L)[t][c]
-    double row[16];     // pivot row of the running step
     double rdiag[16];   // 1 / L[j][j]
+    int bad;            // 0-based index of the first non-positive pivot, or -1
 };
 
-__device__ __forceinline__ int chol16_invert(d4& t, ChScratch& sc, double* wfrag) {
+// Not inlined: ONE copy of this long straight-line routine keeps the kernel's code inside the
+// instruction cache (four inlined copies pushed it to 73 KB and every call ran from cold lines).
+// The tile travels by value in registers; the pivot status goes through sc.bad.
+__device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc.U[lq + 4 * r][li] = t[r];
+    __builtin_amdgcn_wave_barrier();
+    double a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = sc.U[li][k];
     int bad = -1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        // row j of the running tile sits in comp (j >> 2) of the 16 lanes with lq == (j & 3)
-        if (lq == (j & 3)) sc.row[li] = t[j >> 2];
-        __builtin_amdgcn_wave_barrier();
-        double d = sc.row[j];
+        double d = lane_bcast(a[j], j);
         if (!(d > 0.0)) {
             if (bad < 0) bad = j;
             d = 1.0;
         }
-        const double sq = sqrt(d);
-        const double rinv = 1.0 / sq;
-        const double lij = sc.row[li] * rinv;  // L[li][j], meaningful for li > j
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = lq + 4 * r;             // D-form row of this component
-            const double lcj = sc.row[c] * rinv;  // L[c][j]
-            if (c > j) t[r] -= lcj * lij;
-            else if (c == j) t[r] = (li == j) ? sq : lij;
-        }
-        if (lq == (j & 3)) sc.U[j][li] = (li >= j) ? t[j >> 2] : 0.0;
+        const double rinv = rsqrt(d);
         if (lane == 0) sc.rdiag[j] = rinv;
-        __builtin_amdgcn_wave_barrier();
+        const double ltj = a[j] * rinv;  // L[li][j] for li >= j (li == j: d / sqrt(d))
+        a[j] = ltj;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] -= ltj * lane_bcast(ltj, c);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // U = L^T in D-form: comp r of lane (lq, li) is U[lq + 4 r][li] = L[li][lq + 4 r]
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (lq + 4 * r > li) t[r] = 0.0;
-    // W = inv(L) row by row: W[t][c] = (delta(t,c) - sum_{k<t} L[t][k] W[k][c]) / L[t][t].
-    // Lane (lq, li) works on column c = li and sums the terms k = lq (mod 4); the four
-    // quarter-waves are then added with two cross-lane exchanges.
+    for (int r = 0; r < 4; ++r) {
+        const double v = lq == 0 ? a[4 * r] : lq == 1 ? a[4 * r + 1] : lq == 2 ? a[4 * r + 2] : a[4 * r + 3];
+        t[r] = (lq + 4 * r <= li) ? v : 0.0;
+    }
+    // W = inv(L): lane li computes column li by forward substitution,
+    // W[t][c] = (delta(t,c) - sum_{k<t} L[t][k] W[k][c]) / L[t][t], L[t][k] broadcast from lane t.
+    __builtin_amdgcn_wave_barrier();
+    double w[16];
 #pragma unroll
     for (int tt = 0; tt < 16; ++tt) {
-        double part = 0.0;
+        double s = (tt == li) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k4 = 0; k4 < tt; k4 += 4) {
-            const int k = k4 + lq;
-            if (k < tt) part += sc.U[k][tt] * sc.Wt[k][li];
-        }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        const double wt = ((tt == li ? 1.0 : 0.0) - part) * sc.rdiag[tt];
-        if (lq == 0) sc.Wt[tt][li] = wt;
-        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < tt; ++k) s -= lane_bcast(a[k], tt) * w[k];
+        w[tt] = s * sc.rdiag[tt];
         __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt)
+        if ((tt >> 2) == lq) sc.Wt[tt][li] = w[tt];  // quarter lq hands over rows 4 lq .. 4 lq + 3
+    __builtin_amdgcn_wave_barrier();
     // A-fragment layout: wfrag[r*64 + lane] = W[t = li][c = 4 r + lq]
 #pragma unroll
     for (int r = 0; r < 4; ++r) wfrag[r * 64 + lane] = sc.Wt[li][4 * r + lq];
-    return bad;
+    if (lane == 0) sc.bad = bad;
+    return t;
 }
 
 // pair index of a strictly-lower tile (u, s), s < u < 4, and of a lower tile incl. diagonal
@@ -158,8 +162,9 @@ struct PanelLds {
     // L_{u,s} (u > s) as A-fragments = the D-form registers of the tile (rows of tile u, columns
     // of tile s): Lf[lf_idx(u,s)][r*64 + lane]
     double Lf[6][256];
-    // diagonal-block tiles (D-form) handed from the D waves to the factor wave: T[t_idx(u,s)]
-    double T[10][256];
+    // diagonal-block tiles (D-form), two k-half partials, handed from the D waves to the factor
+    // wave: T[half][t_idx(u,s)]
+    double T[2][10][256];
     ChScratch ch;  // scratch of the scalar 16x16 factorisation
     int info;      // 1-based column of the first non-positive pivot, 0 = none
     int d_done;    // diagonal chunks updated so far (4 per panel, monotone over panels)
@@ -217,42 +222,52 @@ __device__ __forceinline__ void lds_wait_ge(int* flag, int target) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// ---- D: one 16-row chunk of the panel's 64 x 64 diagonal block ---------------------------------
-// Wave w (= NT - 1) owns row chunk w of the block and its tiles s = 0 .. w:
-//   T_{w,s} = K_{w,s} - sum_{k < r0} L[chunk w][k] L[tile s][k]^T      -> LDS, for the factor wave.
-template <int NT>
+// ---- D: update of the panel's 64 x 64 diagonal block, split 2 x 2 over the four waves ------------
+// The ten lower 16 x 16 tiles (u, s), s <= u, are cut into two sets of five and the k range
+// [0, r0) into two halves; wave (2*SET + HALF) accumulates its five tiles over its half.  HALF 0
+// starts from the K tiles, HALF 1 from zero; the factor wave adds the two partials (fixed order,
+// so the result is reproducible).  2.5 tile-streams per wave instead of 4 on the busiest one.
+//   T_{u,s} = K_{u,s} - sum_{k < r0} L[chunk u][k] L[tile s][k]^T
+template <int SET, int HALF>
 __device__ __forceinline__ void diag_update(const Slab& S, const int r0, PanelLds& sm, Stamps& st) {
-    constexpr int w = NT - 1;
+    constexpr int NT = 5;
+    constexpr int NFB = SET == 0 ? 3 : 4;  // chunks of the block whose fragments this set needs
+    constexpr int TU[2][NT] = {{0, 1, 1, 2, 2}, {2, 3, 3, 3, 3}};
+    constexpr int TS[2][NT] = {{0, 0, 1, 0, 1}, {2, 0, 1, 2, 3}};
     const int lane = threadIdx.x & 63;
     d4 acc[NT];
 #pragma unroll
-    for (int s = 0; s < NT; ++s) tile_load(acc[s], S, r0 + 16 * s, r0 + 16 * w);
+    for (int q = 0; q < NT; ++q) {
+        if (HALF == 0) tile_load(acc[q], S, r0 + 16 * TS[SET][q], r0 + 16 * TU[SET][q]);
+        else acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    }
     if (r0 > 0) {
-        // Ring of DEPTH k-steps of fragments in flight; r0 / 4 is a multiple of 16, so of DEPTH.
-        // Prefetches past k = r0 stay inside the slab (rows < n_pad) and are never used.
+        // Ring of DEPTH k-steps of fragments in flight; r0 / 8 is a multiple of 8, so of DEPTH.
+        // Prefetches past the half's end stay inside the slab (rows < n_pad) and are never used.
         const int step = S.ld * 32;
-        int ok = S.at(0, r0);  // rows k0 .. k0+3 of S, column r0: advanced by 4 rows per k-step
-        double fb[DEPTH][NT];
+        int ok = S.at(HALF * (r0 / 2), r0);  // rows k0 .. k0+3 of S, column r0
+        double fb[DEPTH][NFB];
 #pragma unroll
         for (int d = 0; d < DEPTH - 1; ++d)
 #pragma unroll
-            for (int s = 0; s < NT; ++s) fb[d][s] = S.load(ok + d * step + 128 * s);
-        for (int k0 = 0; k0 < r0; k0 += 4 * DEPTH) {
+            for (int c = 0; c < NFB; ++c) fb[d][c] = S.load(ok + d * step + 128 * c);
+        for (int k0 = 0; k0 < r0 / 2; k0 += 4 * DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const int nd = (d + DEPTH - 1) % DEPTH;
 #pragma unroll
-                for (int s = 0; s < NT; ++s) fb[nd][s] = S.load(ok + (d + DEPTH - 1) * step + 128 * s);
+                for (int c = 0; c < NFB; ++c) fb[nd][c] = S.load(ok + (d + DEPTH - 1) * step + 128 * c);
 #pragma unroll
-                for (int s = 0; s < NT; ++s) acc[s] = mfma_f64_negA(fb[d][s], fb[d][w], acc[s]);
+                for (int q = 0; q < NT; ++q)
+                    acc[q] = mfma_f64_negA(fb[d][TS[SET][q]], fb[d][TU[SET][q]], acc[q]);
             }
             ok += DEPTH * step;
         }
     }
 #pragma unroll
-    for (int s = 0; s < NT; ++s)
+    for (int q = 0; q < NT; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sm.T[t_idx(w, s)][r * 64 + lane] = acc[s][r];
+        for (int r = 0; r < 4; ++r) sm.T[HALF][t_idx(TU[SET][q], TS[SET][q])][r * 64 + lane] = acc[q][r];
     lds_signal_add(&sm.d_done);
     st.mark(0);
 }
@@ -261,7 +276,7 @@ __device__ __forceinline__ void diag_update(const Slab& S, const int r0, PanelLd
 // t[u][s] (s <= u) are the lower tiles in D-form.  For s = 0..3: scalar Cholesky of T_ss, then
 // X_{u,s}^T = inv(L_ss) T_{u,s}^T for the tiles below it and the rank-16 update of the tiles to the
 // right; a D-form register r of X_{u,s} is at the same time the A-fragment (k-step r) of L_{u,s}.
-__device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelLds& sm) {
+__device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelLds& sm, Stamps& st) {
     const int lane = threadIdx.x & 63;
     d4 t[CT][CT];
 #pragma unroll
@@ -269,12 +284,17 @@ __device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelL
 #pragma unroll
         for (int s = 0; s <= u; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[u][s][r] = sm.T[t_idx(u, s)][r * 64 + lane];
+            for (int r = 0; r < 4; ++r)
+                t[u][s][r] = sm.T[0][t_idx(u, s)][r * 64 + lane] + sm.T[1][t_idx(u, s)][r * 64 + lane];
     bool ok = true;
 #pragma unroll
     for (int s = 0; s < CT; ++s) {
         if (ok) {
-            const int bad = chol16_invert(t[s][s], sm.ch, sm.W[s]);
+            st.mark(1);
+            t[s][s] = chol16_invert(t[s][s], sm.ch, sm.W[s]);
+            __builtin_amdgcn_wave_barrier();
+            const int bad = sm.ch.bad;
+            st.mark(7);
             if (bad >= 0) {
                 if (lane == 0) sm.info = r0 + 16 * s + bad + 1;
                 ok = false;
@@ -419,14 +439,19 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
     int qbase = 0;
     for (int r0 = 0, panel = 0; r0 < npad; r0 += TRS_NB, ++panel) {
         switch (wave) {
-            case 0: diag_update<1>(S, r0, sm, st); break;
-            case 1: diag_update<2>(S, r0, sm, st); break;
-            case 2: diag_update<3>(S, r0, sm, st); break;
-            default: diag_update<4>(S, r0, sm, st); break;
+            case 0: diag_update<0, 0>(S, r0, sm, st); break;
+            case 1: diag_update<0, 1>(S, r0, sm, st); break;
+            case 2: diag_update<1, 0>(S, r0, sm, st); break;
+            default: diag_update<1, 1>(S, r0, sm, st); break;
         }
         if (wave == 0) {
             lds_wait_ge(&sm.d_done, 4 * (panel + 1));
-            factor_block(S, r0, sm);
+            st.mark(6);
+            // the serial factorisation is the panel's critical path: let its VALU stream win
+            // issue arbitration against the co-resident work-group's MFMA stream on this SIMD
+            __builtin_amdgcn_s_setprio(3);
+            factor_block(S, r0, sm, st);
+            __builtin_amdgcn_s_setprio(0);
             st.mark(1);
         }
         const int below = nchunks - r0 / 16 - CT;  // row chunks under the diagonal block (>= 1)

@@ -67,7 +67,7 @@ def main():
             buf = (ctypes.c_ulonglong * 8)()
             libs[tag].trs_debug_stamps(buf, 1)
             tot = float(sum(buf)) or 1.0
-            names = ("diag_gemm", "diag_factor", "panel_gemm", "panel_ksub", "panel_trsm_store", "panel_end_barrier")
+            names = ("diag_gemm", "factor_rest", "item_gemm", "item_wait_f", "item_trsm_store", "end_barrier", "wait_d", "chol16")
             print(f"{tag} stamp shares: " + ", ".join(f"{n} {buf[i] / tot:.3f}" for i, n in enumerate(names)))
         med = {s: float(np.median(v)) for s, v in times[tag].items()}
         mn = {s: float(np.min(v)) for s, v in times[tag].items()}
