@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TRS_ABI_VERSION 1
+#define TRS_ABI_VERSION 2
 
 /* trs_assemble flags */
 #define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests) */
@@ -60,17 +60,22 @@ int trs_slab_rows(int n_max);
 int trs_dofmap(int B, int nJ_max, const uint8_t *cbits, const int32_t *nJ,
                int32_t *free_index /* [B][nJ_max*3] */, int32_t *n_free /* [B] */, void *stream);
 
+/* Bytes of assembly workspace PER TRUSS (joint stiffness blocks + row directory) for a batch
+ * with these maxima; the caller passes B times this many bytes as `work`. */
+size_t trs_assemble_work_bytes(int nJ_max, int nM_max, int n_max);
+
 /* Assembly of the reduced stiffness matrix and load vector.  Replaces Member.k/cosines/matK
  * (truss.py:56-86), Truss.GetKMatrix (truss.py:307-316), GetExternalForceVector
  * (truss.py:303-304) and the row/column elimination matK[mask,:][:,mask], vecF[mask]
- * (truss.py:343). */
+ * (truss.py:343).  Deterministic: the sums follow a fixed order (sorted joint adjacency), so the
+ * slab is bit-identical from run to run and between identical trusses of a batch. */
 int trs_assemble(int B, int nJ_max, int nM_max,
                  const double *xyz /* [B][nJ_max][3] */, const int32_t *conn /* [B][nM_max][2] */,
                  const double *E /* [B][nM_max] */, const double *A /* [B][nM_max] */,
                  const double *loads /* [B][nJ_max][3] */, const int32_t *free_index,
                  const int32_t *n_free, const int32_t *nJ, const int32_t *nM,
                  int ld, int slab_rows, double *S /* [B][slab_rows][ld] */, int flags,
-                 void *stream);
+                 void *work /* B * trs_assemble_work_bytes(...) */, void *stream);
 
 /* Batched Cholesky factorisation with fused forward substitution of the right-hand-side
  * column.  Replaces the factorisation half of np.linalg.solve (truss.py:343; LAPACK dgesv in
@@ -113,7 +118,7 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound,
               const uint8_t *cbits, const double *loads, const int32_t *nJ, const int32_t *nM,
               int32_t *free_index, int32_t *n_free, int ld, int slab_rows, double *S,
               double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info,
-              void *stream);
+              void *work, void *stream);
 
 #ifdef __cplusplus
 }

@@ -186,6 +186,8 @@ class DeviceBatch:
         self.f_ext = torch.empty([B, self.nJ_max, 3], dtype=torch.float64, device=dev)
         self.N = torch.empty([B, self.nM_max], dtype=torch.float64, device=dev)
         self.info = torch.empty([B], dtype=torch.int32, device=dev)
+        work_bytes = self.lib.trs_assemble_work_bytes(self.nJ_max, self.nM_max, self.n_max)
+        self.work = torch.empty([B, work_bytes], dtype=torch.uint8, device=dev)
 
     # -- individual stages (used by the parity tests and the benchmark) ------------------
     def _stream(self):
@@ -201,7 +203,7 @@ class DeviceBatch:
             self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
             self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
             self.n_free.data_ptr(), self.nJ.data_ptr(), self.nM.data_ptr(), self.ld, self.rows,
-            self.S.data_ptr(), flags, self._stream()), "trs_assemble")
+            self.S.data_ptr(), flags, self.work.data_ptr(), self._stream()), "trs_assemble")
 
     def potrf(self):
         _capi.check(self.lib.trs_potrf_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
@@ -229,7 +231,7 @@ class DeviceBatch:
                 self.nJ.data_ptr(), self.nM.data_ptr(), self.free_index.data_ptr(),
                 self.n_free.data_ptr(), self.ld, self.rows, self.S.data_ptr(), self.uf.data_ptr(),
                 self.rows, self.u.data_ptr(), self.f_ext.data_ptr(), self.N.data_ptr(),
-                self.info.data_ptr(), self._stream()), "trs_solve")
+                self.info.data_ptr(), self.work.data_ptr(), self._stream()), "trs_solve")
 
     def fitness(self, allow_stress, allow_displace):
         """(weight, stress_violation, displacement_violation) per truss, on device."""

@@ -7,7 +7,8 @@ extern "C" {
 int trs_dofmap_launch(int, int, const uint8_t*, const int*, int*, int*, hipStream_t);
 int trs_assemble_launch(int, int, int, const double*, const int*, const double*, const double*,
                         const double*, const int*, const int*, const int*, const int*, int, size_t,
-                        int, double*, int, hipStream_t);
+                        int, double*, int, void*, hipStream_t);
+size_t trs_assemble_work_bytes(int, int, int);
 int trs_potrf_launch(int, const int*, int, size_t, double*, int*, hipStream_t);
 int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, hipStream_t);
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
@@ -42,10 +43,12 @@ int trs_dofmap(int B, int nJ_max, const uint8_t* cbits, const int32_t* nJ, int32
 int trs_assemble(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn,
                  const double* E, const double* A, const double* loads, const int32_t* free_index,
                  const int32_t* n_free, const int32_t* nJ, const int32_t* nM, int ld, int slab_rows,
-                 double* S, int flags, void* stream) {
-    if (B < 0 || nJ_max <= 0 || nM_max < 0 || bad_slab(ld, slab_rows)) return (int)hipErrorInvalidValue;
+                 double* S, int flags, void* work, void* stream) {
+    if (B < 0 || nJ_max <= 0 || nM_max < 0 || bad_slab(ld, slab_rows) || (B > 0 && !work))
+        return (int)hipErrorInvalidValue;
     return trs_assemble_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM,
-                               ld, (size_t)slab_rows * ld, slab_rows, S, flags, (hipStream_t)stream);
+                               ld, (size_t)slab_rows * ld, slab_rows, S, flags, work,
+                               (hipStream_t)stream);
 }
 
 int trs_potrf_batched(int B, const int32_t* n_free, int ld, int slab_rows, double* S, int32_t* info,
@@ -83,12 +86,12 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
               const double* E, const double* A, const uint8_t* cbits, const double* loads,
               const int32_t* nJ, const int32_t* nM, int32_t* free_index, int32_t* n_free, int ld,
               int slab_rows, double* S, double* uf, int ld_uf, double* u, double* f_ext, double* N,
-              int32_t* info, void* stream) {
+              int32_t* info, void* work, void* stream) {
     if (n_max_bound > slab_rows) return (int)hipErrorInvalidValue;
     int rc = trs_dofmap(B, nJ_max, cbits, nJ, free_index, n_free, stream);
     if (rc) return rc;
     rc = trs_assemble(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM, ld,
-                      slab_rows, S, 0, stream);
+                      slab_rows, S, 0, work, stream);
     if (rc) return rc;
     rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, stream);
     if (rc) return rc;

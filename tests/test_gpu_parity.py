@@ -213,9 +213,11 @@ def test_replicated_batch_is_identical_and_deterministic(gpu):
     assert not first.info.any()
     z = H.dense_golden()
     assert H.max_scaled_err(first.displace[0], z["bar-942_input_0/u"]) <= TOL_FP64
+    # assembly (sorted adjacency), factorisation and substitution all sum in a fixed order:
+    # every copy is bit-identical to copy 0
     for b in range(1, 64):
-        assert H.max_scaled_err(first.displace[b], first.displace[0]) <= TOL_FP64
-        assert H.max_scaled_err(first.internal[b], first.internal[0]) <= TOL_FP64
+        assert np.array_equal(first.displace[b], first.displace[0])
+        assert np.array_equal(first.internal[b], first.internal[0])
     # potrf on identical input is bitwise reproducible (fixed summation order)
     dev.dofmap(); dev.assemble()
     S0 = dev.S.clone()
