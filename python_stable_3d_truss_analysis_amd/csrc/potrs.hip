@@ -3,8 +3,9 @@
 // (slientruss3d/truss.py:343).  HBM-bound: U is streamed once, row by row (contiguous rows).
 //
 // One work-group per truss.  Blocks of 64 rows from the bottom up: all four waves form
-// t = y - U[rows, solved columns] . u for the block (coalesced row reads, wave reductions) and
-// stage the 64 x 64 diagonal block in LDS; wave 0 then solves the triangle.
+// t = y - U[rows, solved columns] . u for the block (16 independent coalesced loads in flight per
+// lane and 64-column chunk, 16-lane reductions) and stage the 64 x 64 diagonal block in LDS;
+// wave 0 then solves the triangle.
 #include "trs_common.h"
 
 namespace {
@@ -19,23 +20,39 @@ __global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npad = trs_round_up(n_free[b], TRS_NB);
     if (npad == 0) return;
-    double* us = sh;                // [npad] solution
-    double* Ub = sh + npad;         // [64][65] diagonal block
+    double* us = sh;                  // [npad] solution
+    double* Ub = sh + npad;           // [64][65] diagonal block
     double* tb = Ub + BS * (BS + 1);  // [64] right-hand side of the block
     const double* S = S_all + (size_t)b * slab_stride;
+    // lane (g, l): rows 4 g .. 4 g + 3 of the wave's 16 rows, columns l + 16 k of a 64-column chunk.
+    // Every load instruction covers four rows x 128 contiguous bytes; 16 independent loads per chunk.
+    const int g = lane >> 4, l = lane & 15;
+    const int wrow = 16 * wave + 4 * g;  // first of this lane's four rows inside the block
 
     for (int cb = npad - BS; cb >= 0; cb -= BS) {
-        // t[c] = y[c] - sum_{i >= cb+64} U[c][i] u[i]; 16 rows per wave
-        for (int rr = 0; rr < 16; ++rr) {
-            const int c = cb + 16 * wave + rr;
-            const double* row = S + (size_t)c * ld;
-            double sum = 0.0;
-            for (int i = cb + BS + lane; i < npad; i += 64) sum += row[i] * us[i];
+        const double* rows = S + (size_t)(cb + wrow) * ld;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i0 = cb + BS; i0 < npad; i0 += BS) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
-            if (lane == 0) tb[16 * wave + rr] = row[npad] - sum;
-            // diagonal block row (columns cb .. cb+63)
-            Ub[(16 * wave + rr) * (BS + 1) + lane] = row[cb + lane];
+            for (int k = 0; k < 4; ++k) {
+                const int col = i0 + 16 * k + l;
+                const double ui = us[col];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += rows[(size_t)q * ld + col] * ui;
+            }
+        }
+        // the diagonal block rows (columns cb .. cb+63) go to LDS for the triangle solve
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                Ub[(wrow + q) * (BS + 1) + 16 * k + l] = rows[(size_t)q * ld + cb + 16 * k + l];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v = acc[q];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+            if (l == 0) tb[wrow + q] = rows[(size_t)q * ld + npad] - v;  // y - U[c, solved] u
         }
         __syncthreads();
         if (wave == 0) {
