@@ -1,0 +1,236 @@
+"""Member-type selection by a genetic algorithm, with every generation's fitness evaluated in ONE
+batched GPU solve (BASELINE config 4).
+
+Same constructor, method names, fitness formula and - for a given `random.seed` - the same sequence
+of `random` calls as the reference's `slientruss3d/ga.py:12-237`, so a seeded run walks the same
+trajectory.  What differs: the reference's `Select` (`ga.py:155-160`) and `GetBestFeasibleGene`
+(`ga.py:110-123`) call `Truss.Solve()` once per individual; here the population shares geometry,
+supports and loads and differs only in (a, e, density) per member, so the whole population is one
+`DeviceBatch` whose sections are gathered on the device from the member-type table and whose
+weight / stress / displacement reductions run in `trs_fitness`.
+
+`GetFitness(gene)` keeps working for one gene (and may be overridden, as the reference's docs allow,
+`detail/truss_optimization.md:183-239`); an overridden `GetFitness` switches the population
+evaluation back to one call per gene.
+"""
+import random
+
+import numpy as np
+
+from .truss import Truss
+from .type import MemberType
+from .utils import (INF, ZERO_EPS, EliteNumberTooMuchError, MinDisplaceTooLargeError,
+                    MinStressTooLargeError, OnlyOneMemberTypeError, ProbabilityGreaterThanOneError)
+
+PENALTY = 1e5  # weight of the normalised violations in the fitness (ga.py:146-148)
+
+
+class GA:
+    def __init__(self, truss: Truss, memberTypeList, allowStress=30000., allowDisplace=10.,
+                 nIteration=None, nPatience=50, nPop=200, nElite=50, pCrossover=0.7, pMutate=0.1,
+                 pOrigin=0.1, isCheckWorst=False):
+        self.nPop, self.nElite = nPop, nElite
+        self.pCrossover, self.pMutate, self.pOrigin = pCrossover, pMutate, pOrigin
+        self.pRandomGene = 1. - pCrossover - pMutate - pOrigin
+        self.nIteration, self.nPatience = nIteration, nPatience
+        self.truss = truss
+        self.allowStress, self.allowDisplace = allowStress, allowDisplace
+        self.typeList = memberTypeList
+        self.nMember = truss.nMember
+        self.nType = len(memberTypeList)
+        self.memberIDList = truss.GetMemberIDs()
+        self.memberIDMap = dict(enumerate(self.memberIDList))
+        self._feasibleGene = [None] * self.nMember
+        self._feasibleFitness = None
+        self._device = None  # DeviceBatch of nPop copies, built on first use
+        self.CheckRatioality(isCheckWorst)
+
+    # ------------------------------------------------------------------ configuration checks
+    @property
+    def memberTypeWeightedInitProb(self):
+        return [1.] * len(self.typeList)
+
+    def CheckRatioality(self, isCheckWorst):
+        """Parameter sanity (ga.py:70-108)."""
+        if self.nElite > self.nPop:
+            raise EliteNumberTooMuchError(
+                f"Number of elites must <= number of population. Got [nElite] = {self.nElite}, [nPop] = {self.nPop}.")
+        if self.pCrossover + self.pMutate + self.pOrigin > 1.:
+            raise ProbabilityGreaterThanOneError(
+                f"[pCrossover] + [pMutate] + [pOrigin] must <= 1.0, but got "
+                f"[{self.pCrossover + self.pMutate + self.pOrigin :.4f}].")
+        if self.nType <= 1:
+            raise OnlyOneMemberTypeError(f"Number of member types must >= 2, but got {self.nType}.")
+        if not isCheckWorst:
+            return
+        # the stiffest choices must satisfy the limits, otherwise no gene can (ga.py:86-108)
+        byArea = max(self.typeList, key=lambda t: t.a)
+        byStiffness = max(self.typeList, key=lambda t: t.e * t.a)
+        self._setAll(byArea)
+        self.truss.Solve()
+        if not self.truss.IsInternalStressAllowed(self.allowStress)[0]:
+            raise MinStressTooLargeError(
+                "Minimum stress is too large. Need other member types which have more [A] value.")
+        self._setAll(byStiffness)
+        self.truss.Solve()
+        if not self.truss.IsDisplacementAllowed(self.allowDisplace)[0]:
+            raise MinDisplaceTooLargeError(
+                "Minimum displacement is too large. Need other member types which have more [E*A] value.")
+
+    def _setAll(self, memberType):
+        for memberID in self.memberIDList:
+            self.truss.SetMemberType(memberID, memberType)
+
+    # ------------------------------------------------------------------------- gene helpers
+    def TranslateGene(self, gene):
+        return {self.memberIDMap[i]: self.typeList[locus] for i, locus in enumerate(gene)}
+
+    def GetRandomGene(self):
+        return random.choices(range(self.nType), k=self.nMember)
+
+    def SetMemberTypesByGene(self, gene, truss):
+        for i, locus in enumerate(gene):
+            truss.SetMemberType(self.memberIDMap[i], self.typeList[locus])
+        return truss
+
+    def Initialize(self):
+        weights = self.memberTypeWeightedInitProb
+        return [random.choices(range(self.nType), k=self.nMember, weights=weights)
+                for _ in range(self.nPop)]
+
+    # ------------------------------------------------------------------------------ fitness
+    def _compose(self, weight, stressViolation, displaceViolation):
+        """Fitness triple from the three reductions (ga.py:143-149)."""
+        okStress = abs(stressViolation) < ZERO_EPS
+        okDisplace = abs(displaceViolation) < ZERO_EPS
+        fitness = weight
+        if not okStress:
+            fitness += stressViolation / self.allowStress * PENALTY
+        if not okDisplace:
+            fitness += displaceViolation / self.allowDisplace * PENALTY
+        return fitness, okStress, okDisplace
+
+    def GetFitness(self, gene):
+        """One gene (ga.py:139-149).  The population path does not call this unless overridden."""
+        return self.GetFitnessBatch([gene])[0]
+
+    def _population_device(self, count):
+        from .batch import DeviceBatch, pack_trusses
+        if self._device is None or self._device.B < count:
+            import torch
+            base = pack_trusses([self.truss])
+            self._device = DeviceBatch(base.replicate(max(count, self.nPop)))
+            table = np.array([[t.a, t.e, t.density] for t in self.typeList], dtype=np.float64)
+            self._typeTable = torch.from_numpy(table).to(self._device.device)
+        return self._device
+
+    def GetFitnessBatch(self, genes):
+        """[(fitness, isInternalAllowed, isDisplaceAllowed)] for a list of genes: one batched solve.
+        Member sections are gathered on the device from the type table by the gene matrix."""
+        import torch
+        dev = self._population_device(len(genes))
+        count = len(genes)
+        loci = torch.zeros([dev.B, dev.nM_max], dtype=torch.int64, device=dev.device)
+        loci[:count, :self.nMember] = torch.tensor(genes, dtype=torch.int64, device=dev.device)
+        sections = self._typeTable[loci]                    # [B, nM, 3] = (a, e, density)
+        dev.A.copy_(sections[..., 0]); dev.E.copy_(sections[..., 1]); dev.rho.copy_(sections[..., 2])
+        dev.solve()
+        weight, stressVio, dispVio = dev.fitness(self.allowStress, self.allowDisplace)
+        info = dev.info[:count].cpu().numpy()
+        if info.any():
+            raise np.linalg.LinAlgError("Singular matrix")
+        w, s, d = (t[:count].cpu().numpy() for t in (weight, stressVio, dispVio))
+        return [self._compose(float(w[i]), float(s[i]), float(d[i])) for i in range(count)]
+
+    def _evaluate(self, pop):
+        """Population -> list of fitness triples; batched unless GetFitness was overridden."""
+        if type(self).GetFitness is not GA.GetFitness:
+            return [self.GetFitness(gene) for gene in pop]
+        return self.GetFitnessBatch(pop)
+
+    # ---------------------------------------------------------------------------- operators
+    def _RecordFeasible(self, evaluatedPop, isSorted=False):
+        for gene, (fitness, okStress, okDisplace) in evaluatedPop:
+            if okStress and okDisplace and (self._feasibleFitness is None or fitness < self._feasibleFitness):
+                self._feasibleGene[:], self._feasibleFitness = gene, fitness
+                if isSorted:
+                    break
+
+    def Select(self, pop, isRecordFeasible=False):
+        """Rank the population (stable sort by fitness, ga.py:155-160) and return the elites."""
+        ranked = sorted(([gene, info] for gene, info in zip(pop, self._evaluate(pop))),
+                        key=lambda pair: pair[1][0])
+        if isRecordFeasible:
+            self._RecordFeasible(ranked, isSorted=True)
+        return [gene for gene, _ in ranked[:self.nElite]], ranked[0][1]
+
+    def Crossover(self, gene0, gene1):
+        cut0, cut1 = sorted(random.sample(range(self.nMember), k=2))
+        return [gene0[i] if i < cut0 or i >= cut1 else gene1[i] for i in range(self.nMember)]
+
+    def Mutate(self, gene):
+        child = gene.copy()
+        at = random.randint(0, self.nMember - 1)
+        child[at] = random.choice([t for t in range(self.nType) if t != child[at]])
+        return child
+
+    def UpdatePop(self, pop, elitePop):
+        """Next generation (ga.py:173-190): elites, then one random draw per remaining slot."""
+        toCross = self.pCrossover
+        toMutate = toCross + self.pMutate
+        toKeep = toMutate + self.pOrigin
+        newPop = list(elitePop) + [None] * (self.nPop - self.nElite)
+        for j in range(self.nElite, self.nPop):
+            p = random.random()
+            if p <= toCross:
+                newPop[j] = self.Crossover(*random.sample(elitePop, k=2))
+            elif p <= toMutate:
+                newPop[j] = self.Mutate(random.choice(elitePop))
+            elif p <= toKeep:
+                newPop[j] = pop[j]
+            else:
+                newPop[j] = self.GetRandomGene()
+        return newPop
+
+    def GetBestFeasibleGene(self, pop, isDirectlyReturnRecord=False):
+        if isDirectlyReturnRecord and self._feasibleFitness is not None:
+            return self._feasibleGene, (self._feasibleFitness, True, True)
+        best, bestInfo = None, (INF, False, False)
+        for gene, info in zip(pop, self._evaluate(pop)):
+            if info[1] and info[2] and info[0] < bestInfo[0]:
+                best, bestInfo = gene, info
+        if best is None and self._feasibleFitness is not None:
+            return self._feasibleGene, (self._feasibleFitness, True, True)
+        return best, bestInfo
+
+    # -------------------------------------------------------------------------------- driver
+    def Evolve(self, isPrintMessage=True):
+        """Run the GA (ga.py:192-237).  Returns (minGene, minGeneInfo, finalPop, bestFitnessHistory)."""
+        pop = self.Initialize()
+        bestFitness, history, nWait, earlyStop = INF, [], 0, False
+        iteration = 0
+        while self.nIteration is None or iteration < self.nIteration:
+            elitePop, (minFitness, okStress, okDisplace) = self.Select(pop, True)
+            if minFitness < bestFitness:
+                bestFitness, nWait = minFitness, 0
+            else:
+                nWait += 1
+                if nWait >= self.nPatience:
+                    earlyStop = True
+                    break
+            history.append(bestFitness)
+            if isPrintMessage:
+                print(f"\rIteration: {iteration :6d}, nWaitBestIter: {nWait :3d}, minFitness: {minFitness :12.4f}, "
+                      f"isInternalAllowed: {str(okStress) :5s}, isDisplaceAllowed: {str(okDisplace) :5s}", end='')
+            pop = self.UpdatePop(pop, elitePop)
+            iteration += 1
+        if isPrintMessage:
+            print('...Early stoping !' if earlyStop else "")
+        minGene, minGeneInfo = self.GetBestFeasibleGene(pop, earlyStop)
+        if minGene is None:
+            minGene = pop[0]
+            minGeneInfo = self._evaluate([minGene])[0]
+            if isPrintMessage:
+                print('-' * 50 + '\n' + "Warning: Cannot find any feasible result, so only return the gene "
+                      "which has lowest fitness." + '\n' + '-' * 50)
+        return minGene, minGeneInfo, pop, history

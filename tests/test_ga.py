@@ -1,0 +1,125 @@
+"""GA: host logic on CPU against the seeded trace captured from the reference
+(tests/golden/ga_trace.json), with the oracle standing in for the batched GPU evaluation; and the
+real GPU path (-m gpu) against the same trace."""
+import copy
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import truss_oracle as orc
+from python_stable_3d_truss_analysis_amd import MemberType, Truss, utils
+from python_stable_3d_truss_analysis_amd.ga import GA
+from tests import helpers as H
+
+
+def _trace():
+    with open(os.path.join(H.GOLDEN, "ga_trace.json")) as fh:
+        return json.load(fh)
+
+
+def _seeded_setup(trace):
+    random.seed(trace["seed"])
+    types = [MemberType(inch, random.uniform(1e7, 3e7), random.uniform(0.1, 1.0)) for inch in range(1, 21)]
+    assert [t.Serialize() for t in types] == trace["memberTypes"]
+    truss = Truss(3).LoadFromJSON(data=H.load_json("bar-120_input_0"))
+    return truss, types
+
+
+class OracleGA(GA):
+    """Population evaluation through the CPU oracle (test stand-in for the device)."""
+    def GetFitnessBatch(self, genes):
+        base = H.load_json("bar-120_input_0")
+        out = []
+        for gene in genes:
+            data = copy.deepcopy(base)
+            for m, locus in enumerate(gene):
+                data["member"][m][1] = self.typeList[locus].Serialize()
+            out.append(orc.fitness_terms(data, orc.solve(data), self.allowStress, self.allowDisplace))
+        return out
+
+
+def _check_against_trace(ga, trace):
+    state = random.getstate()
+    pop0 = ga.Initialize()
+    assert pop0 == trace["pop0"]
+    gen0 = ga.GetFitnessBatch(pop0)
+    for (fit, ok_s, ok_d), (rfit, rs, rd) in zip(gen0, trace["gen0"]):
+        assert fit == pytest.approx(rfit, rel=1e-9) and (ok_s, ok_d) == (rs, rd)
+    random.setstate(state)
+    minGene, minInfo, pop, history = ga.Evolve(isPrintMessage=False)
+    assert history == pytest.approx(trace["bestFitnessHistory"], rel=1e-9)
+    assert minGene == trace["minGene"]
+    assert minInfo[0] == pytest.approx(trace["minInfo"][0], rel=1e-9) and list(minInfo[1:]) == trace["minInfo"][1:]
+    assert pop == trace["finalPop"]
+
+
+def test_ga_host_logic_reproduces_reference_trace_with_oracle_fitness():
+    trace = _trace()
+    truss, types = _seeded_setup(trace)
+    ga = OracleGA(truss, types, trace["allowStress"], trace["allowDisplace"], nIteration=trace["nIteration"],
+                  nPatience=50, nPop=trace["nPop"], nElite=trace["nElite"])
+    _check_against_trace(ga, trace)
+    assert ga.TranslateGene(trace["minGene"])[0] == types[trace["minGene"][0]]
+
+
+def test_ga_parameter_checks():
+    truss = Truss(3).LoadFromJSON(data=H.load_json("bar-25_input_0"))
+    two = [MemberType(1, 1e7, .1), MemberType(2, 1e7, .1)]
+    with pytest.raises(utils.EliteNumberTooMuchError):
+        GA(truss, two, nPop=10, nElite=11)
+    with pytest.raises(utils.ProbabilityGreaterThanOneError):
+        GA(truss, two, pCrossover=.8, pMutate=.2, pOrigin=.1)
+    with pytest.raises(utils.OnlyOneMemberTypeError):
+        GA(truss, two[:1])
+    ga = GA(truss, two, nPop=8, nElite=2)
+    random.seed(3)
+    child = ga.Crossover([0] * 25, [1] * 25)
+    assert len(child) == 25 and 0 < sum(child) < 25
+    mutant = ga.Mutate([0] * 25)
+    assert sum(mutant) == 1
+    assert len(ga.Initialize()) == 8 and len(ga.GetRandomGene()) == 25
+
+
+class _CustomFitness(OracleGA):
+    def GetFitness(self, gene):           # overriding switches back to one call per gene
+        fit, a, b = OracleGA.GetFitnessBatch(self, [gene])[0]
+        return fit * 2.0, a, b
+
+
+def test_overridden_getfitness_is_honoured():
+    truss = Truss(3).LoadFromJSON(data=H.load_json("bar-120_input_0"))
+    random.seed(1)
+    types = [MemberType(i, 2e7, 0.5) for i in range(1, 5)]
+    ga = _CustomFitness(truss, types, nIteration=1, nPop=4, nElite=2)
+    pop = ga.Initialize()
+    plain = OracleGA.GetFitnessBatch(ga, pop)
+    assert [f for f, _, _ in ga._evaluate(pop)] == pytest.approx([2.0 * f for f, _, _ in plain])
+
+
+@pytest.mark.gpu
+def test_ga_on_gpu_reproduces_reference_trace():
+    """BASELINE config 4 at the captured size: every generation is one batched GPU solve."""
+    trace = _trace()
+    truss, types = _seeded_setup(trace)
+    ga = GA(truss, types, trace["allowStress"], trace["allowDisplace"], nIteration=trace["nIteration"],
+            nPatience=50, nPop=trace["nPop"], nElite=trace["nElite"])
+    _check_against_trace(ga, trace)
+
+
+@pytest.mark.gpu
+def test_ga_population_1024_fitness_matches_oracle_sample():
+    """Config 4 proper: nPop = 1024 on bar-120; spot-check the batched fitness against the oracle."""
+    truss = Truss(3).LoadFromJSON(data=H.load_json("bar-120_input_0"))
+    random.seed(5)
+    types = [MemberType(inch, random.uniform(1e7, 3e7), random.uniform(0.1, 1.0)) for inch in range(1, 21)]
+    ga = GA(truss, types, nIteration=2, nPop=1024, nElite=256)
+    pop = ga.Initialize()
+    got = ga.GetFitnessBatch(pop)
+    ref = OracleGA.GetFitnessBatch(ga, pop[::128])
+    for (f, a, b), (rf, ra, rb) in zip(got[::128], ref):
+        assert f == pytest.approx(rf, rel=1e-9) and (a, b) == (ra, rb)
+    _, info, finalPop, history = ga.Evolve(isPrintMessage=False)
+    assert len(history) == 2 and history[1] <= history[0] and len(finalPop) == 1024
