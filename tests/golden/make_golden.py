@@ -20,6 +20,7 @@ Written files:
   cube_ragged.npz        12 seeded GenerateRandomCubeTrusses cases (inputs + dense outputs)
   edge_cases.json        synthetic edge cases (inputs + dense outputs or expected exception)
   ga_trace.json          seeded GA run on bar-120 (generation-0 fitness triples, history)
+  hetero_bar25.npz       HeteroData tensors of bar-25 for the four (task, metapath) combinations
 """
 import glob
 import json
@@ -208,12 +209,59 @@ def capture_ga_trace(rt, rty, rga):
     print("  ga history:", history)
 
 
+def capture_hetero(rt, rty):
+    """HeteroData tensors of bar-25 under the four (task, metapath) combinations (data.py:11-282).
+    torch_geometric is not installed: a dict-of-stores stand-in for HeteroData lets data.py import."""
+    import torch
+
+    class _Store(dict):
+        __getattr__ = dict.get
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    class HeteroData(dict):
+        def __getitem__(self, key):
+            if key not in self:
+                dict.__setitem__(self, key, _Store())
+            return dict.__getitem__(self, key)
+
+    tg, tgd = types.ModuleType("torch_geometric"), types.ModuleType("torch_geometric.data")
+    tgd.HeteroData = HeteroData
+    tg.data = tgd
+    sys.modules["torch_geometric"], sys.modules["torch_geometric.data"] = tg, tgd
+    import slientruss3d.data as rd
+    out = {}
+    path = os.path.join(REF, "data", "bar-25_input_0.json")
+    for task_name, task in (("opt", rty.TaskType.OPTIMIZATION), ("reg", rty.TaskType.REGRESSION)):
+        for meta_name, meta in (("noimp", rty.MetapathType.NO_IMPLICIT), ("imp", rty.MetapathType.USE_IMPLICIT)):
+            creator = rd.TrussHeteroDataCreator(meta, task)
+            g = creator.FromJSON(path, 3, forceScale=1000., displaceScale=0.1, positionScale=100.)
+            key = f"{task_name}_{meta_name}"
+            for store_key, store in g.items():
+                if not isinstance(store, dict):
+                    continue
+                name = store_key if isinstance(store_key, str) else "__".join(store_key)
+                for field, value in store.items():
+                    if torch.is_tensor(value):
+                        out[f"{key}/{name}/{field}"] = value.numpy()
+            out[f"{key}/originWeight"] = np.array(g["originWeight"])
+    np.savez_compressed(os.path.join(HERE, "hetero_bar25.npz"), **out)
+    print("  hetero:", len(out), "arrays;", {k: v.shape for k, v in out.items() if k.startswith("reg_imp")})
+
+
 def main():
     rt, rty, rg, rga = import_reference()
-    capture_data_cases(rt)
-    capture_cube_ragged(rt, rty, rg)
-    capture_edge_cases(rt)
-    capture_ga_trace(rt, rty, rga)
+    which = sys.argv[1:] or ["data", "cube", "edge", "ga", "hetero"]
+    if "data" in which:
+        capture_data_cases(rt)
+    if "cube" in which:
+        capture_cube_ragged(rt, rty, rg)
+    if "edge" in which:
+        capture_edge_cases(rt)
+    if "ga" in which:
+        capture_ga_trace(rt, rty, rga)
+    if "hetero" in which:
+        capture_hetero(rt, rty)
 
 
 if __name__ == "__main__":

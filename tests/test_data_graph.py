@@ -1,0 +1,103 @@
+"""Graph-tensor builder against the HeteroData tensors captured from the
+reference for bar-25 under the four (task, metapath) combinations (tests/golden/hetero_bar25.npz).
+CPU: results injected from the oracle; GPU (-m gpu): the two batched solves."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from oracle import truss_oracle as orc
+from python_stable_3d_truss_analysis_amd import MemberType, Truss, batch
+from python_stable_3d_truss_analysis_amd.data import (TrussHeteroDataCreator, hetero_tensors_batch,
+                                                      solve_actual_and_prior)
+from python_stable_3d_truss_analysis_amd.type import MetapathType, TaskType
+from tests import helpers as H
+
+SCALES = dict(forceScale=1000., displaceScale=0.1, positionScale=100.)
+COMBOS = [("opt", TaskType.OPTIMIZATION), ("reg", TaskType.REGRESSION)]
+METAS = [("noimp", MetapathType.NO_IMPLICIT), ("imp", MetapathType.USE_IMPLICIT)]
+FIXED = MemberType(1., 1e7, 0.1)
+
+
+def _oracle_results(data):
+    def dense(d):
+        r = orc.solve(d)
+        nJ, nM = len(d["joint"]), len(d["member"])
+        u = np.zeros([1, nJ, 3]); f = np.zeros([1, nJ, 3])
+        u[0], f[0] = r["u"], r["f_ext"]
+        return batch.BatchResult(u, f, r["N"][None], np.zeros([1], dtype=np.int32))
+    fixed = copy.deepcopy(data)
+    for m in fixed["member"]:
+        m[1] = FIXED.Serialize()
+    return dense(data), dense(fixed)
+
+
+def _edges(t):
+    return {tuple(e) for e in np.asarray(t).T.tolist()}
+
+
+def _compare(graph, z, key):
+    np.testing.assert_allclose(graph["joint"].x.numpy(), z[f"{key}/joint/x"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(graph["member"].x.numpy(), z[f"{key}/member/x"], rtol=2e-6, atol=1e-7)
+    if f"{key}/joint/y" in z.files:
+        np.testing.assert_allclose(graph["joint"].y.numpy(), z[f"{key}/joint/y"], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(graph["member"].y.numpy(), z[f"{key}/member/y"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(graph["joint", "j2m", "member"].edge_index.numpy(),
+                                  z[f"{key}/joint__j2m__member/edge_index"])
+    np.testing.assert_array_equal(graph["member", "m2j", "joint"].edge_index.numpy(),
+                                  z[f"{key}/member__m2j__joint/edge_index"])
+    if f"{key}/joint__j2j__joint/edge_index" in z.files:
+        assert _edges(graph["joint", "j2j", "joint"].edge_index) == _edges(z[f"{key}/joint__j2j__joint/edge_index"])
+        assert _edges(graph["member", "m2m", "member"].edge_index) == _edges(z[f"{key}/member__m2m__member/edge_index"])
+    assert float(graph["originWeight"]) == pytest.approx(float(z[f"{key}/originWeight"]), rel=1e-13)
+
+
+@pytest.mark.parametrize("task", COMBOS, ids=[c[0] for c in COMBOS])
+@pytest.mark.parametrize("meta", METAS, ids=[m[0] for m in METAS])
+def test_graph_tensors_match_reference_capture(task, meta):
+    z = np.load(os.path.join(H.GOLDEN, "hetero_bar25.npz"))
+    data = H.load_json("bar-25_input_0")
+    truss = Truss(3).LoadFromJSON(data=data)
+    creator = TrussHeteroDataCreator(meta[1], task[1])
+    graph = creator.FromTruss(truss, fixedMemberType=FIXED, _results=_oracle_results(data), **SCALES)
+    _compare(graph, z, f"{task[0]}_{meta[0]}")
+    assert creator.jointIndexToID == list(range(10)) and creator.memberIndexToID == list(range(25))
+
+
+def test_dense_edges_master_node_and_member_type_targets():
+    data = H.load_json("bar-25_input_0")
+    truss = Truss(3).LoadFromJSON(data=data)
+    creator = TrussHeteroDataCreator(MetapathType.USE_IMPLICIT, TaskType.OPTIMIZATION)
+    used = [MemberType(2, 1e7, 0.1), MemberType(1, 1e7, 0.1)]
+    g = creator.FromTruss(truss, usedMemberTypes=used, isUseFixed=False, _results=(_oracle_results(data)[0], None))
+    assert g["joint"].x.shape == (10, 7) and g["member"].x.shape == (25, 8)
+    assert g["member"].y.numpy().ravel().tolist() == [1.0] * 25
+    g = creator.AddDenseEdges(g)
+    assert g["joint", "jFCm", "member"].edge_index.shape == (2, 250)
+    assert g["member", "mFCm", "member"].edge_index.shape == (2, 625)
+    g = creator.AddMasterNode(g, embeddingDim=3, fillValue=0.5)
+    assert g["master"].x.shape == (3, 1) and g["member", "m2M", "master"].edge_index.shape == (2, 25)
+
+
+@pytest.mark.gpu
+def test_batched_dataset_path_on_gpu():
+    """Config 5 in miniature: a generated batch -> two batched solves -> one graph per truss; plus the
+    single-truss front end against the reference capture."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    z = np.load(os.path.join(H.GOLDEN, "hetero_bar25.npz"))
+    creator = TrussHeteroDataCreator(MetapathType.USE_IMPLICIT, TaskType.REGRESSION)
+    graph = creator.FromJSON(os.path.join(H.GOLDEN, "data", "bar-25_input_0.json"), 3,
+                             fixedMemberType=FIXED, **SCALES)
+    _compare(graph, z, "reg_imp")
+    packed = gen.generate_cube_batch([7] * 32, gridRange=(5, 5, 5), lengthRange=(100, 200),
+                                     forceRange=[(-1000, 1000)] * 3, seed=42)
+    actual, prior = solve_actual_and_prior(packed, FIXED)
+    assert not actual.info.any() and not prior.info.any()
+    graphs = hetero_tensors_batch(packed, actual, prior, FIXED.a, TaskType.REGRESSION, MetapathType.NO_IMPLICIT)
+    assert len(graphs) == 32
+    for b in (0, 31):
+        nJ, nM = int(packed.nJ[b]), int(packed.nM[b])
+        assert graphs[b]["joint"].x.shape == (nJ, 10) and graphs[b]["member"].x.shape == (nM, 10)
+        ref = orc.solve(gen.packed_to_json(packed, b))
+        np.testing.assert_allclose(graphs[b]["joint"].y.numpy(), ref["u"], rtol=1e-5, atol=1e-9)
