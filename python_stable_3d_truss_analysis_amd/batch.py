@@ -63,6 +63,14 @@ class PackedBatch:
         return PackedBatch(*(np.ascontiguousarray(getattr(self, f)[index])
                              for f in self.__dataclass_fields__))
 
+    def trimmed(self):
+        """The same batch with the joint / member padding cut to this batch's own maxima."""
+        jm = max(1, int(self.nJ.max(initial=1)))
+        mm = max(1, int(self.nM.max(initial=1)))
+        cut = {"xyz": jm, "loads": jm, "cbits": jm, "conn": mm, "E": mm, "A": mm, "rho": mm}
+        return PackedBatch(*(np.ascontiguousarray(getattr(self, f)[:, :cut[f]]) if f in cut
+                             else getattr(self, f) for f in self.__dataclass_fields__))
+
 
 def count_free(cbits, nJ):
     """n_free[b] from the constraint bits (host copy of what trs_dofmap computes)."""
@@ -256,10 +264,42 @@ class DeviceBatch:
                            self.info.cpu().numpy())
 
 
-def solve_batch(trusses_or_packed, device=None):
-    """Solve many trusses in one device pipeline.  Accepts `list[Truss]` or a `PackedBatch`."""
+def size_buckets(packed: PackedBatch, max_slab_bytes=32 << 30):
+    """Group the trusses of a ragged batch for launching: same padded system size n_pad per group
+    (the slab and every work-group of a launch are then uniform) and at most `max_slab_bytes` of
+    stiffness slab per launch.  Returns a list of index arrays (their union is range(B))."""
+    n_pad = (packed.n_free.astype(np.int64) + 63) // 64 * 64
+    groups = []
+    for size in np.unique(n_pad):
+        idx = np.flatnonzero(n_pad == size)
+        per_truss = max(1, int(size) * (int(size) + 16) * 8)
+        step = max(1, max_slab_bytes // per_truss)
+        groups.extend(idx[i: i + step] for i in range(0, len(idx), step))
+    return groups
+
+
+def solve_batch(trusses_or_packed, device=None, max_slab_bytes=32 << 30):
+    """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
+
+    A ragged batch is bucketed by padded system size (`size_buckets`): one launch pipeline per
+    bucket, inputs trimmed to the bucket's own maxima, results scattered back to batch order."""
     packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
         else pack_trusses(list(trusses_or_packed))
-    dev = DeviceBatch(packed, device)
-    dev.solve()
-    return dev.result()
+    groups = size_buckets(packed, max_slab_bytes)
+    if len(groups) <= 1:
+        dev = DeviceBatch(packed, device)
+        dev.solve()
+        return dev.result()
+    out = BatchResult(np.zeros([packed.B, packed.nJ_max, 3]), np.zeros([packed.B, packed.nJ_max, 3]),
+                      np.zeros([packed.B, packed.nM_max]), np.zeros([packed.B], dtype=np.int32))
+    for idx in groups:
+        sub = packed.take(idx).trimmed()
+        dev = DeviceBatch(sub, device)
+        dev.solve()
+        res = dev.result()
+        out.displace[idx, :sub.nJ_max] = res.displace
+        out.external[idx, :sub.nJ_max] = res.external
+        out.internal[idx, :sub.nM_max] = res.internal
+        out.info[idx] = res.info
+        del dev
+    return out

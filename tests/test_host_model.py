@@ -177,3 +177,18 @@ def test_solve_without_gpu_fails_loudly():
     t = Truss(3).LoadFromJSON(data=H.load_json("bar-25_input_0"))
     with pytest.raises(HipExtensionError):
         t.Solve()
+
+
+def test_size_buckets_and_trimmed_cover_a_ragged_batch():
+    datas = [H.load_json(n) for n in H.data_case_names()]
+    p = batch.pack_json(datas).replicate(3)
+    groups = batch.size_buckets(p)
+    assert sorted(np.concatenate(groups).tolist()) == list(range(p.B))
+    for idx in groups:
+        pads = (p.n_free[idx] + 63) // 64 * 64
+        assert len(set(pads.tolist())) == 1                  # one padded size per launch
+    small = batch.size_buckets(p, max_slab_bytes=1 << 20)     # memory bound splits a bucket
+    assert len(small) > len(groups) and sum(len(i) for i in small) == p.B
+    sub = p.take(groups[0]).trimmed()
+    assert sub.nJ_max == int(sub.nJ.max()) and sub.nM_max == int(sub.nM.max())
+    assert sub.n_free.tolist() == p.n_free[groups[0]].tolist()

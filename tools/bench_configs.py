@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configs on one GPU (informational; bench.py is the contract).
+
+  config 3  GenerateRandomCubeTrusses-like mixed sizes (native generator), bucketed ragged batching
+  config 4  one GA generation on bar-120: population 1024 in one batched solve + fitness reduction
+  config 5  dataset sample = two solves (actual + fixed section) of cube trusses, graph tensors on host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from python_stable_3d_truss_analysis_amd import MemberType, Truss, batch
+from python_stable_3d_truss_analysis_amd import generate as gen
+from python_stable_3d_truss_analysis_amd.ga import GA
+
+
+def config3(B, out):
+    rng = np.random.default_rng(0)
+    t0 = time.perf_counter()
+    packed = gen.generate_cube_batch(rng.integers(8, 191, size=B), gridRange=(6, 6, 6), seed=7)
+    t_gen = time.perf_counter() - t0
+    groups = batch.size_buckets(packed, 48 << 30)
+    subs = [packed.take(i).trimmed() for i in groups]
+    torch.cuda.synchronize()
+    total_gpu = 0.0
+    bad = 0
+    for sub in subs:
+        dev = batch.DeviceBatch(sub)
+        dev.solve(); torch.cuda.synchronize()            # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); dev.solve(); e1.record(); torch.cuda.synchronize()
+        total_gpu += e0.elapsed_time(e1) * 1e-3
+        bad += int((dev.info != 0).sum().item())
+        del dev
+    out["config3"] = {"B": B, "buckets": len(groups), "n_free_mean": float(packed.n_free.mean()),
+                      "n_free_max": int(packed.n_free.max()), "generate_s": t_gen,
+                      "solve_s_resident": total_gpu, "solves_per_s": B / total_gpu, "info_nonzero": bad}
+
+
+def config4(out):
+    import random
+    with open(os.path.join(ROOT, "tests", "golden", "data", "bar-120_input_0.json")) as fh:
+        truss = Truss(3).LoadFromJSON(data=json.load(fh))
+    random.seed(0)
+    types = [MemberType(i, random.uniform(1e7, 3e7), random.uniform(0.1, 1.0)) for i in range(1, 21)]
+    ga = GA(truss, types, nIteration=3, nPop=1024, nElite=256)
+    pop = ga.Initialize()
+    ga.GetFitnessBatch(pop)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ga.GetFitnessBatch(pop)
+    dt = (time.perf_counter() - t0) / 5
+    out["config4"] = {"nPop": 1024, "generation_eval_s": dt, "fitness_evals_per_s": 1024 / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cubes", type=int, default=65536)
+    args = ap.parse_args()
+    out = {}
+    config4(out)
+    config3(args.cubes, out)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
