@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TRS_ABI_VERSION 2
+#define TRS_ABI_VERSION 3
 
 /* trs_assemble flags */
 #define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests) */
@@ -60,6 +60,14 @@ int trs_slab_rows(int n_max);
 int trs_dofmap(int B, int nJ_max, const uint8_t *cbits, const int32_t *nJ,
                int32_t *free_index /* [B][nJ_max*3] */, int32_t *n_free /* [B] */, void *stream);
 
+/* Envelope metadata (optional; pass NULL everywhere to treat every matrix as dense).
+ * trs_assemble derives, per truss, the row envelope of the reduced stiffness matrix at 16-row
+ * granularity (first tile per row chunk, last row chunk per 64-column panel; layout in
+ * csrc/trs_common.h) and writes only the slab tiles inside it; trs_potrf_batched and
+ * trs_potrs_batched skip the tiles outside it, which are exact zeros of the Cholesky factor.
+ * `env` is an int32 array of B * trs_env_ints(n_max) entries. */
+int trs_env_ints(int n_max);
+
 /* Bytes of assembly workspace PER TRUSS (joint stiffness blocks + row directory) for a batch
  * with these maxima; the caller passes B times this many bytes as `work`. */
 size_t trs_assemble_work_bytes(int nJ_max, int nM_max, int n_max);
@@ -75,7 +83,8 @@ int trs_assemble(int B, int nJ_max, int nM_max,
                  const double *loads /* [B][nJ_max][3] */, const int32_t *free_index,
                  const int32_t *n_free, const int32_t *nJ, const int32_t *nM,
                  int ld, int slab_rows, double *S /* [B][slab_rows][ld] */, int flags,
-                 void *work /* B * trs_assemble_work_bytes(...) */, void *stream);
+                 void *work /* B * trs_assemble_work_bytes(...) */,
+                 int32_t *env /* out, B * trs_env_ints(...), or NULL */, void *stream);
 
 /* Batched Cholesky factorisation with fused forward substitution of the right-hand-side
  * column.  Replaces the factorisation half of np.linalg.solve (truss.py:343; LAPACK dgesv in
@@ -83,12 +92,13 @@ int trs_assemble(int B, int nJ_max, int nM_max,
  * info[b] = 0 on success, k > 0 when the pivot of column k (1-based) is not positive
  * (the reference raises numpy.linalg.LinAlgError for an exactly singular matrix). */
 int trs_potrf_batched(int B, const int32_t *n_free, int ld, int slab_rows, double *S,
-                      int32_t *info /* [B] */, void *stream);
+                      int32_t *info /* [B] */, const int32_t *env /* or NULL */, void *stream);
 
 /* Back substitution U u_f = y.  Replaces the solve half of np.linalg.solve (truss.py:343).
  * uf[b][c] = reduced displacement c (c < n_free[b]); entries up to n_pad are written. */
 int trs_potrs_batched(int B, const int32_t *n_free, int ld, int slab_rows, const double *S,
-                      double *uf /* [B][ld_uf] */, int ld_uf, void *stream);
+                      double *uf /* [B][ld_uf] */, int ld_uf, const int32_t *env /* or NULL */,
+                      void *stream);
 
 /* Result recovery.  Replaces the displacement scatter (truss.py:342), the reactions
  * vecF[~mask] = K[~mask,:] @ u (truss.py:348-349) and the member-force loop
@@ -118,7 +128,8 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound,
               const uint8_t *cbits, const double *loads, const int32_t *nJ, const int32_t *nM,
               int32_t *free_index, int32_t *n_free, int ld, int slab_rows, double *S,
               double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info,
-              void *work, void *stream);
+              void *work, int32_t *env /* workspace for the envelope metadata, or NULL = dense */,
+              void *stream);
 
 #ifdef __cplusplus
 }

@@ -21,18 +21,19 @@ SIGNATURES = {
     "trs_slab_ld": (_I, [_I]),
     "trs_slab_rows": (_I, [_I]),
     "trs_dofmap": (_I, [_I, _I, _P, _P, _P, _P, _P]),
+    "trs_env_ints": (_I, [_I]),
     "trs_assemble_work_bytes": (ctypes.c_size_t, [_I, _I, _I]),
-    "trs_assemble": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
-    "trs_potrf_batched": (_I, [_I, _P, _I, _I, _P, _P, _P]),
-    "trs_potrs_batched": (_I, [_I, _P, _I, _I, _P, _P, _I, _P]),
+    "trs_assemble": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P]),
+    "trs_potrf_batched": (_I, [_I, _P, _I, _I, _P, _P, _P, _P]),
+    "trs_potrs_batched": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
     "trs_recover": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "trs_fitness": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _P, _P, _P, _P]),
     "trs_solve": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
-                       _P, _P, _P, _P, _P, _P]),
+                       _P, _P, _P, _P, _P, _P, _P]),
 }
 
 #: must equal TRS_ABI_VERSION of include/trs_solver.h
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

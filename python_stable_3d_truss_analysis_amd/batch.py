@@ -8,6 +8,7 @@ All device work is enqueued on the current PyTorch-ROCm stream; tensors are only
 the kernels run on (plumbing).  No CPU fallback: without a GPU or the built library the calls
 raise `HipExtensionError`.
 """
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -172,7 +173,8 @@ class DeviceBatch:
     lives on one device; kernels run on the current stream of that device.
     """
 
-    def __init__(self, packed: PackedBatch, device=None):
+    def __init__(self, packed: PackedBatch, device=None, use_envelope=True):
+        """`use_envelope=False` treats every reduced stiffness matrix as dense (no tile skipping)."""
         torch, dev = _require_gpu(device)
         self.torch, self.device, self.packed = torch, dev, packed
         self.lib = _capi.load()
@@ -189,6 +191,8 @@ class DeviceBatch:
         self.free_index = torch.empty([B, self.nJ_max * 3], dtype=torch.int32, device=dev)
         self.n_free = torch.empty([B], dtype=torch.int32, device=dev)
         self.S = torch.empty([B, self.rows, self.ld], dtype=torch.float64, device=dev)
+        if os.environ.get("TRS_DEBUG_POISON"):   # tests: any read of a never-written slab entry shows
+            self.S.fill_(float("nan"))
         self.uf = torch.empty([B, self.rows], dtype=torch.float64, device=dev)
         self.u = torch.empty([B, self.nJ_max, 3], dtype=torch.float64, device=dev)
         self.f_ext = torch.empty([B, self.nJ_max, 3], dtype=torch.float64, device=dev)
@@ -196,10 +200,15 @@ class DeviceBatch:
         self.info = torch.empty([B], dtype=torch.int32, device=dev)
         work_bytes = self.lib.trs_assemble_work_bytes(self.nJ_max, self.nM_max, self.n_max)
         self.work = torch.empty([B, work_bytes], dtype=torch.uint8, device=dev)
+        self.env = torch.zeros([B, self.lib.trs_env_ints(self.n_max)], dtype=torch.int32, device=dev) \
+            if use_envelope else None
 
     # -- individual stages (used by the parity tests and the benchmark) ------------------
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _env_ptr(self):
+        return self.env.data_ptr() if self.env is not None else None
 
     def dofmap(self):
         _capi.check(self.lib.trs_dofmap(self.B, self.nJ_max, self.cbits.data_ptr(), self.nJ.data_ptr(),
@@ -211,17 +220,18 @@ class DeviceBatch:
             self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
             self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
             self.n_free.data_ptr(), self.nJ.data_ptr(), self.nM.data_ptr(), self.ld, self.rows,
-            self.S.data_ptr(), flags, self.work.data_ptr(), self._stream()), "trs_assemble")
+            self.S.data_ptr(), flags, self.work.data_ptr(), self._env_ptr(), self._stream()),
+            "trs_assemble")
 
     def potrf(self):
         _capi.check(self.lib.trs_potrf_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
-                                               self.S.data_ptr(), self.info.data_ptr(),
+                                               self.S.data_ptr(), self.info.data_ptr(), self._env_ptr(),
                                                self._stream()), "trs_potrf_batched")
 
     def potrs(self):
         _capi.check(self.lib.trs_potrs_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
                                                self.S.data_ptr(), self.uf.data_ptr(), self.rows,
-                                               self._stream()), "trs_potrs_batched")
+                                               self._env_ptr(), self._stream()), "trs_potrs_batched")
 
     def recover(self):
         _capi.check(self.lib.trs_recover(
@@ -239,7 +249,8 @@ class DeviceBatch:
                 self.nJ.data_ptr(), self.nM.data_ptr(), self.free_index.data_ptr(),
                 self.n_free.data_ptr(), self.ld, self.rows, self.S.data_ptr(), self.uf.data_ptr(),
                 self.rows, self.u.data_ptr(), self.f_ext.data_ptr(), self.N.data_ptr(),
-                self.info.data_ptr(), self.work.data_ptr(), self._stream()), "trs_solve")
+                self.info.data_ptr(), self.work.data_ptr(), self._env_ptr(), self._stream()),
+                "trs_solve")
 
     def fitness(self, allow_stress, allow_displace):
         """(weight, stress_violation, displacement_violation) per truss, on device."""

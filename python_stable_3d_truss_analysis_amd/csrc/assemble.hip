@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
     const double* __restrict__ A, const double* __restrict__ loads,
     const int* __restrict__ free_index, const int* __restrict__ n_free, const int* __restrict__ nJ_arr,
     const int* __restrict__ nM_arr, const int nJ_max, const int nM_max, const int n_pad_max,
-    unsigned char* __restrict__ work_all) {
+    unsigned char* __restrict__ work_all, int* __restrict__ env_all) {
     extern __shared__ unsigned char lds_raw[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nJ = nJ_arr[b], nM = nM_arr[b];
@@ -65,10 +65,12 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
     int* start = cnt + nJ_max;                                // [nJ_max+1] exclusive scan of cnt
     int* fill = start + nJ_max + 1;                           // [nJ_max]   fill cursor / entry count
     int* adj = fill + nJ_max;                                 // [2 nM_max] (other joint << 16) | member
+    int* chunkmin = adj + 2 * nM_max;                         // [n_pad_max/16] first tile per row chunk
 
     const double* X = xyz + (size_t)b * 3 * nJ_max;
     const int* fi = free_index + (size_t)b * 3 * nJ_max;
     for (int j = tid; j < nJ; j += 256) cnt[j] = 0;
+    for (int q = tid; q < n_pad_max / 16; q += 256) chunkmin[q] = q;  // padding rows: diagonal only
     __syncthreads();
     for (int m = tid; m < nM; m += 256) {
         const size_t mm = (size_t)b * nM_max + m;
@@ -128,8 +130,15 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
         const int e0 = a + start[a];  // first entry of this joint: the diagonal block
         double diag[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int nent = 1, i = 0;
+        int mincol = 0x7fffffff;  // smallest reduced column coupled to this joint's rows (envelope)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (fi[3 * a + s] >= 0) mincol = min(mincol, fi[3 * a + s]);
         while (i < deg) {
             const int other = list[i] >> 16;
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                if (fi[3 * other + s] >= 0) mincol = min(mincol, fi[3 * other + s]);
             double blk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             do {  // run of parallel members between the same two joints, in member order
                 const int m = list[i] & 0xffff;
@@ -155,6 +164,9 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
 #pragma unroll
         for (int s = 0; s < 3; ++s) ent_cols[4 * (size_t)e0 + s] = fi[3 * a + s];
         fill[a] = nent;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (fi[3 * a + s] >= 0) atomicMin(&chunkmin[fi[3 * a + s] / 16], mincol / 16);
     }
     __syncthreads();
     const double* F = loads + (size_t)b * 3 * nJ_max;
@@ -165,6 +177,23 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
             rowinfo[2 * c] = a + start[a];
             rowinfo[2 * c + 1] = fill[a] | (r << 16);
             rowrhs[c] = F[dof];  // truss.py:303-304, vecF[mask]
+        }
+    }
+    // envelope metadata (trs_common.h): monotone first-tile per chunk, last chunk per panel
+    if (env_all != nullptr && tid == 0) {
+        int* env = env_all + (size_t)b * trs_env_stride(n_pad_max);
+        const int nch = trs_round_up(n_free[b], TRS_NB) / 16;
+        int* ft = env;
+        int* last = env + n_pad_max / 16;
+        int running = nch;
+        for (int q = nch - 1; q >= 0; --q) {
+            running = min(running, chunkmin[q]);
+            ft[q] = running;
+        }
+        int q = 0;
+        for (int j = 0; j < nch / 4; ++j) {
+            while (q + 1 < nch && ft[q + 1] <= 4 * j + 3) ++q;
+            last[j] = q;
         }
     }
 }
@@ -181,7 +210,8 @@ __global__ __launch_bounds__(256) void trs_expand_kernel(const unsigned char* __
                                                          const int nJ_max, const int nM_max,
                                                          const int n_pad_max, const int ld,
                                                          const size_t slab_stride,
-                                                         double* __restrict__ S_all, const int flags) {
+                                                         double* __restrict__ S_all, const int flags,
+                                                         const int* __restrict__ env_all) {
     extern __shared__ double lds[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = n_free[b];
@@ -225,15 +255,22 @@ __global__ __launch_bounds__(256) void trs_expand_kernel(const unsigned char* __
         }
         if (tid < TR && c0 + tid < n) prhs = rowrhs[c0 + tid];
     };
+    const bool full = (flags & TRS_ASM_FULL_SYMMETRIC) != 0;
+    const bool has_env = env_all != nullptr && !full;
+    const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr};
     fetch(0);
     for (int c0 = 0; c0 < npad; c0 += TR) {
-        const int i_lo = (flags & TRS_ASM_FULL_SYMMETRIC) ? 0 : (c0 & ~15);  // first stored column
-        const int W = npad + 16 - i_lo;                                     // multiple of 16
+        // stored part of these rows: columns [i_lo, i_hi) (diagonal tile .. end of the envelope of
+        // the panel the rows belong to) followed in the tile by the 16-wide load-column chunk
+        const int i_lo = full ? 0 : (c0 & ~15);
+        const int i_hi = has_env ? 16 * trs_env_row_end(env, c0 / TRS_NB, npad / 16) : npad;
+        const int Wm = i_hi - i_lo;  // multiple of 16
+        const int W = Wm + 16;
         {   // scatter: every (row, column) of the tile is written by exactly one thread
             double* row = T + (size_t)rr * W - i_lo;
-            if (pcols.x >= i_lo) row[pcols.x] = pv0;
-            if (pcols.y >= i_lo) row[pcols.y] = pv1;
-            if (pcols.z >= i_lo) row[pcols.z] = pv2;
+            if (pcols.x >= i_lo && pcols.x < i_hi) row[pcols.x] = pv0;
+            if (pcols.y >= i_lo && pcols.y < i_hi) row[pcols.y] = pv1;
+            if (pcols.z >= i_lo && pcols.z < i_hi) row[pcols.z] = pv2;
             const int c = c0 + rr;
             if (c < n) {  // joints with more than TPR - 1 neighbours: rare, not prefetched
                 const int2 info = dir[c];
@@ -242,24 +279,25 @@ __global__ __launch_bounds__(256) void trs_expand_kernel(const unsigned char* __
                     const size_t ent = (size_t)info.x + e;
                     const int4 cols = ent_cols[ent];
                     const double* v = ent_vals + 6 * ent;
-                    if (cols.x >= i_lo) row[cols.x] = v[r];
-                    if (cols.y >= i_lo) row[cols.y] = v[r == 0 ? 1 : (r == 1 ? 3 : 4)];
-                    if (cols.z >= i_lo) row[cols.z] = v[r == 0 ? 2 : (r == 1 ? 4 : 5)];
+                    if (cols.x >= i_lo && cols.x < i_hi) row[cols.x] = v[r];
+                    if (cols.y >= i_lo && cols.y < i_hi) row[cols.y] = v[r == 0 ? 1 : (r == 1 ? 3 : 4)];
+                    if (cols.z >= i_lo && cols.z < i_hi) row[cols.z] = v[r == 0 ? 2 : (r == 1 ? 4 : 5)];
                 }
             }
             if (tid < TR) {
                 const int cc = c0 + tid;
-                T[(size_t)tid * W + npad - i_lo] = cc < n ? prhs : 0.0;  // load column
+                T[(size_t)tid * W + Wm] = cc < n ? prhs : 0.0;            // load column
                 if (cc >= n) T[(size_t)tid * W + cc - i_lo] = 1.0;        // identity padding
             }
         }
         if (c0 + TR < npad) fetch(c0 + TR);  // next block's loads fly during the store phase
         __syncthreads();
         for (int q = 0; q < TR; ++q) {
-            double* dst = S + (size_t)(c0 + q) * ld + i_lo;
+            double* dst = S + (size_t)(c0 + q) * ld;
             double* src = T + (size_t)q * W;
             for (int x = tid * 2; x < W; x += 512) {
-                *reinterpret_cast<d2*>(dst + x) = *reinterpret_cast<const d2*>(src + x);
+                const int col = x < Wm ? i_lo + x : npad + (x - Wm);  // envelope part | load column
+                *reinterpret_cast<d2*>(dst + col) = *reinterpret_cast<const d2*>(src + x);
                 *reinterpret_cast<d2*>(src + x) = d2{0.0, 0.0};
             }
         }
@@ -277,17 +315,17 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
                                    const double* E, const double* A, const double* loads,
                                    const int* free_index, const int* n_free, const int* nJ,
                                    const int* nM, int ld, size_t slab_stride, int n_pad_max,
-                                   double* S, int flags, void* work, hipStream_t stream) {
+                                   double* S, int flags, void* work, int* env, hipStream_t stream) {
     if (B <= 0 || n_pad_max <= 0) return 0;
     if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;  // packed adjacency keys
-    const size_t lds1 = (size_t)nM_max * 32 + (size_t)(3 * nJ_max + 1 + 2 * nM_max) * 4;
+    const size_t lds1 = (size_t)nM_max * 32 + (size_t)(3 * nJ_max + 1 + 2 * nM_max + n_pad_max / 16) * 4;
     if (lds1 > 160 * 1024) return (int)hipErrorInvalidValue;
     if (lds1 > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_joint_blocks_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     hipLaunchKernelGGL(trs_joint_blocks_kernel, dim3(B), dim3(256), lds1, stream, xyz, conn, E, A,
                        loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max,
-                       static_cast<unsigned char*>(work));
+                       static_cast<unsigned char*>(work), env);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     // Rows per block: the largest TR <= TRS_EXPAND_TR_MAX whose LDS (tile + row directory) stays
@@ -305,7 +343,7 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_expand_kernel<TRV>),            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);           \
         hipLaunchKernelGGL(trs_expand_kernel<TRV>, dim3(B), dim3(256), lds2, stream, w, n_free, nJ_max, \
-                           nM_max, n_pad_max, ld, slab_stride, S, flags);                               \
+                           nM_max, n_pad_max, ld, slab_stride, S, flags, env);                          \
     } while (0)
     if (TRS_EXPAND_TR_MAX >= 8 && 8 * row_bytes + dir_bytes <= 65536) {
         TRS_LAUNCH_EXPAND(8);

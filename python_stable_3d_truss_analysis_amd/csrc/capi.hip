@@ -7,10 +7,10 @@ extern "C" {
 int trs_dofmap_launch(int, int, const uint8_t*, const int*, int*, int*, hipStream_t);
 int trs_assemble_launch(int, int, int, const double*, const int*, const double*, const double*,
                         const double*, const int*, const int*, const int*, const int*, int, size_t,
-                        int, double*, int, void*, hipStream_t);
+                        int, double*, int, void*, int*, hipStream_t);
 size_t trs_assemble_work_bytes(int, int, int);
-int trs_potrf_launch(int, const int*, int, size_t, double*, int*, hipStream_t);
-int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, hipStream_t);
+int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int*, hipStream_t);
+int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, const int*, hipStream_t);
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, const int*, const double*, int, double*,
                        double*, double*, hipStream_t);
@@ -34,6 +34,8 @@ int trs_slab_rows(int n_max) { return trs_round_up(n_max < 1 ? 1 : n_max, TRS_NB
 
 int trs_slab_ld(int n_max) { return trs_slab_rows(n_max) + 16; }
 
+int trs_env_ints(int n_max) { return trs_env_stride(trs_slab_rows(n_max)); }
+
 int trs_dofmap(int B, int nJ_max, const uint8_t* cbits, const int32_t* nJ, int32_t* free_index,
                int32_t* n_free, void* stream) {
     if (B < 0 || nJ_max <= 0) return (int)hipErrorInvalidValue;
@@ -43,24 +45,25 @@ int trs_dofmap(int B, int nJ_max, const uint8_t* cbits, const int32_t* nJ, int32
 int trs_assemble(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn,
                  const double* E, const double* A, const double* loads, const int32_t* free_index,
                  const int32_t* n_free, const int32_t* nJ, const int32_t* nM, int ld, int slab_rows,
-                 double* S, int flags, void* work, void* stream) {
+                 double* S, int flags, void* work, int32_t* env, void* stream) {
     if (B < 0 || nJ_max <= 0 || nM_max < 0 || bad_slab(ld, slab_rows) || (B > 0 && !work))
         return (int)hipErrorInvalidValue;
     return trs_assemble_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM,
-                               ld, (size_t)slab_rows * ld, slab_rows, S, flags, work,
+                               ld, (size_t)slab_rows * ld, slab_rows, S, flags, work, env,
                                (hipStream_t)stream);
 }
 
 int trs_potrf_batched(int B, const int32_t* n_free, int ld, int slab_rows, double* S, int32_t* info,
-                      void* stream) {
+                      const int32_t* env, void* stream) {
     if (B < 0 || bad_slab(ld, slab_rows)) return (int)hipErrorInvalidValue;
-    return trs_potrf_launch(B, n_free, ld, (size_t)slab_rows * ld, S, info, (hipStream_t)stream);
+    return trs_potrf_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, info, env,
+                            (hipStream_t)stream);
 }
 
 int trs_potrs_batched(int B, const int32_t* n_free, int ld, int slab_rows, const double* S, double* uf,
-                      int ld_uf, void* stream) {
+                      int ld_uf, const int32_t* env, void* stream) {
     if (B < 0 || bad_slab(ld, slab_rows) || ld_uf < slab_rows) return (int)hipErrorInvalidValue;
-    return trs_potrs_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, uf, ld_uf,
+    return trs_potrs_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, uf, ld_uf, env,
                             (hipStream_t)stream);
 }
 
@@ -86,16 +89,16 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
               const double* E, const double* A, const uint8_t* cbits, const double* loads,
               const int32_t* nJ, const int32_t* nM, int32_t* free_index, int32_t* n_free, int ld,
               int slab_rows, double* S, double* uf, int ld_uf, double* u, double* f_ext, double* N,
-              int32_t* info, void* work, void* stream) {
+              int32_t* info, void* work, int32_t* env, void* stream) {
     if (n_max_bound > slab_rows) return (int)hipErrorInvalidValue;
     int rc = trs_dofmap(B, nJ_max, cbits, nJ, free_index, n_free, stream);
     if (rc) return rc;
     rc = trs_assemble(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM, ld,
-                      slab_rows, S, 0, work, stream);
+                      slab_rows, S, 0, work, env, stream);
     if (rc) return rc;
-    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, stream);
+    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, env, stream);
     if (rc) return rc;
-    rc = trs_potrs_batched(B, n_free, ld, slab_rows, S, uf, ld_uf, stream);
+    rc = trs_potrs_batched(B, n_free, ld, slab_rows, S, uf, ld_uf, env, stream);
     if (rc) return rc;
     return trs_recover(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf, u,
                        f_ext, N, stream);

@@ -224,12 +224,15 @@ __device__ __forceinline__ void lds_wait_ge(int* flag, int target) {
 
 // ---- D: update of the panel's 64 x 64 diagonal block, split 2 x 2 over the four waves ------------
 // The ten lower 16 x 16 tiles (u, s), s <= u, are cut into two sets of five and the k range
-// [0, r0) into two halves; wave (2*SET + HALF) accumulates its five tiles over its half.  HALF 0
-// starts from the K tiles, HALF 1 from zero; the factor wave adds the two partials (fixed order,
-// so the result is reproducible).  2.5 tile-streams per wave instead of 4 on the busiest one.
+// [kstart, r0) into two halves (multiples of 16 columns); wave (2*SET + HALF) accumulates its five
+// tiles over its half [kbeg, kend).  HALF 0 starts from the K tiles, HALF 1 from zero; the factor
+// wave adds the two partials (fixed order, so the result is reproducible).  2.5 tile-streams per
+// wave instead of 4 on the busiest one.  kstart > 0 when the envelope says that the block's rows
+// have no non-zero left of it.
 //   T_{u,s} = K_{u,s} - sum_{k < r0} L[chunk u][k] L[tile s][k]^T
 template <int SET, int HALF>
-__device__ __forceinline__ void diag_update(const Slab& S, const int r0, PanelLds& sm, Stamps& st) {
+__device__ __forceinline__ void diag_update(const Slab& S, const int r0, const int kbeg, const int kend,
+                                            PanelLds& sm, Stamps& st) {
     constexpr int NT = 5;
     constexpr int NFB = SET == 0 ? 3 : 4;  // chunks of the block whose fragments this set needs
     constexpr int TU[2][NT] = {{0, 1, 1, 2, 2}, {2, 3, 3, 3, 3}};
@@ -241,17 +244,17 @@ __device__ __forceinline__ void diag_update(const Slab& S, const int r0, PanelLd
         if (HALF == 0) tile_load(acc[q], S, r0 + 16 * TS[SET][q], r0 + 16 * TU[SET][q]);
         else acc[q] = d4{0.0, 0.0, 0.0, 0.0};
     }
-    if (r0 > 0) {
-        // Ring of DEPTH k-steps of fragments in flight; r0 / 8 is a multiple of 8, so of DEPTH.
-        // Prefetches past the half's end stay inside the slab (rows < n_pad) and are never used.
+    if (kend > kbeg) {
+        // Ring of DEPTH k-steps of fragments in flight; kend - kbeg is a multiple of 16 columns =
+        // DEPTH k-steps.  Prefetches past kend stay inside the slab and are never used.
         const int step = S.ld * 32;
-        int ok = S.at(HALF * (r0 / 2), r0);  // rows k0 .. k0+3 of S, column r0
+        int ok = S.at(kbeg, r0);  // rows k0 .. k0+3 of S, column r0
         double fb[DEPTH][NFB];
 #pragma unroll
         for (int d = 0; d < DEPTH - 1; ++d)
 #pragma unroll
             for (int c = 0; c < NFB; ++c) fb[d][c] = S.load(ok + d * step + 128 * c);
-        for (int k0 = 0; k0 < r0 / 2; k0 += 4 * DEPTH) {
+        for (int k0 = kbeg; k0 < kend; k0 += 4 * DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const int nd = (d + DEPTH - 1) % DEPTH;
@@ -335,7 +338,8 @@ __device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelL
 // solve against the diagonal block with the fragments it left in LDS, store.
 template <int NV>
 __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const int rowbase,
-                                           PanelLds& sm, const int f_target, Stamps& st) {
+                                           const int kstart, PanelLds& sm, const int f_target,
+                                           Stamps& st) {
     const int lane = threadIdx.x & 63;
     d4 acc[NV][CT];
 #pragma unroll
@@ -343,10 +347,11 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
 #pragma unroll
         for (int s = 0; s < CT; ++s) tile_load(acc[v][s], S, r0 + 16 * s, rowbase + 16 * v);
 
-    // acc[v][s](c, i) = K - sum_{k < r0} L[c][k] L[i][k]
-    if (r0 > 0) {
-        int ob = S.at(0, r0);       // B side: rows k0 .. k0+3 of S, columns of the panel
-        int oa = S.at(0, rowbase);  // A side: same rows of S, columns = the item's matrix rows
+    // acc[v][s](c, i) = K - sum_{kstart <= k < r0} L[c][k] L[i][k]; the item's rows are zero left of
+    // kstart (envelope), kstart is a multiple of 16
+    if (r0 > kstart) {
+        int ob = S.at(kstart, r0);       // B side: rows k0 .. k0+3 of S, columns of the panel
+        int oa = S.at(kstart, rowbase);  // A side: same rows of S, columns = the item's matrix rows
         const int step = S.ld * 32;
         double fb[DEPTH][CT], fa[DEPTH][NV];
 #pragma unroll
@@ -356,7 +361,7 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
 #pragma unroll
             for (int v = 0; v < NV; ++v) fa[d][v] = S.load(oa + d * step + 128 * v);
         }
-        for (int k0 = 0; k0 < r0; k0 += 4 * DEPTH) {
+        for (int k0 = kstart; k0 < r0; k0 += 4 * DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const int nd = (d + DEPTH - 1) % DEPTH;
@@ -410,7 +415,7 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
 
 __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_kernel(
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
-    int* __restrict__ info) {
+    int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max) {
     __shared__ PanelLds sm;
     const int b = blockIdx.x;
     const int npad = trs_round_up(n_free[b], TRS_NB);
@@ -432,17 +437,23 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
                                              (int)(slab_stride * sizeof(double)), 0x00020000);
     S.ld = ld;
     S.loff = ((unsigned)(lane >> 4) * (unsigned)ld + (unsigned)(lane & 15)) * 8u;
-    const int nchunks = npad / 16 + 1;  // + the right-hand-side chunk at rows n_pad .. n_pad+15
+    const int nch = npad / 16;  // row chunks of the matrix; the right-hand side is one more, at row n_pad
+    const bool has_env = env_all != nullptr;
+    const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr};
 
     Stamps st;
     st.start();
     int qbase = 0;
     for (int r0 = 0, panel = 0; r0 < npad; r0 += TRS_NB, ++panel) {
-        switch (wave) {
-            case 0: diag_update<0, 0>(S, r0, sm, st); break;
-            case 1: diag_update<0, 1>(S, r0, sm, st); break;
-            case 2: diag_update<1, 0>(S, r0, sm, st); break;
-            default: diag_update<1, 1>(S, r0, sm, st); break;
+        {   // D: k range [kstart, r0) in two halves of whole 16-column tiles
+            const int kstart = has_env ? 16 * env.ft[4 * panel] : 0;
+            const int kmid = kstart + 16 * (((r0 - kstart) / 16 + 1) / 2);
+            switch (wave) {
+                case 0: diag_update<0, 0>(S, r0, kstart, kmid, sm, st); break;
+                case 1: diag_update<0, 1>(S, r0, kmid, r0, sm, st); break;
+                case 2: diag_update<1, 0>(S, r0, kstart, kmid, sm, st); break;
+                default: diag_update<1, 1>(S, r0, kmid, r0, sm, st); break;
+            }
         }
         if (wave == 0) {
             lds_wait_ge(&sm.d_done, 4 * (panel + 1));
@@ -454,25 +465,38 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
             __builtin_amdgcn_s_setprio(0);
             st.mark(1);
         }
-        const int below = nchunks - r0 / 16 - CT;  // row chunks under the diagonal block (>= 1)
-        const int nitems = (below + RS - 1) / RS;
+        // Items: the row chunks under the diagonal block that reach into this panel (all of them
+        // for a dense matrix, up to last[panel] with an envelope) in groups of RS, then the
+        // right-hand-side chunk as an item of its own.
+        const int lastq = has_env ? env.last[panel] : nch - 1;
+        const int below = lastq - (4 * panel + CT - 1);  // >= 0
+        const int nmain = (below + RS - 1) / RS;
+        const int nitems = nmain + 1;
         for (;;) {
             int item = 0;
             if (lane == 0) item = __hip_atomic_fetch_add(&sm.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             item = __builtin_amdgcn_readfirstlane(item) - qbase;
             if (item >= nitems) break;
+            if (item == nmain) {
+                // L y = f rides along as the row n_pad.  Its own envelope is dense, but the panel's
+                // rows are zero (and unwritten) left of their envelope: start there.
+                panel_item<1>(S, r0, npad, has_env ? 16 * env.ft[4 * panel] : 0, sm, panel + 1, st);
+                continue;
+            }
+            const int c0 = 4 * panel + CT + item * RS;  // first chunk of the item
             const int nv = min(RS, below - item * RS);
-            const int rowbase = r0 + (CT + item * RS) * 16;
+            const int rowbase = c0 * 16;
+            const int kstart = has_env ? 16 * env.ft[c0] : 0;
             switch (nv) {
-                case 1: panel_item<1>(S, r0, rowbase, sm, panel + 1, st); break;
+                case 1: panel_item<1>(S, r0, rowbase, kstart, sm, panel + 1, st); break;
 #if TRS_POTRF_RS >= 2
-                case 2: panel_item<2>(S, r0, rowbase, sm, panel + 1, st); break;
+                case 2: panel_item<2>(S, r0, rowbase, kstart, sm, panel + 1, st); break;
 #endif
 #if TRS_POTRF_RS >= 3
-                case 3: panel_item<3>(S, r0, rowbase, sm, panel + 1, st); break;
+                case 3: panel_item<3>(S, r0, rowbase, kstart, sm, panel + 1, st); break;
 #endif
 #if TRS_POTRF_RS >= 4
-                case 4: panel_item<4>(S, r0, rowbase, sm, panel + 1, st); break;
+                case 4: panel_item<4>(S, r0, rowbase, kstart, sm, panel + 1, st); break;
 #endif
                 default: break;
             }
@@ -500,10 +524,10 @@ extern "C" int trs_debug_stamps(unsigned long long* host_out, int reset) {
 }
 #endif
 
-extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, double* S,
-                                int* info, hipStream_t stream) {
+extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
+                                double* S, int* info, const int* env, hipStream_t stream) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(trs_potrf_kernel, dim3(B), dim3(NW * 64), 0, stream, S, n_free, ld,
-                       slab_stride, info);
+                       slab_stride, info, env, n_pad_max);
     return (int)hipGetLastError();
 }

@@ -15,7 +15,9 @@ constexpr int BS = 64;  // rows per block
 __global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict__ S_all,
                                                         const int* __restrict__ n_free, const int ld,
                                                         const size_t slab_stride,
-                                                        double* __restrict__ uf, const int ld_uf) {
+                                                        double* __restrict__ uf, const int ld_uf,
+                                                        const int* __restrict__ env_all,
+                                                        const int n_pad_max) {
     extern __shared__ double sh[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npad = trs_round_up(n_free[b], TRS_NB);
@@ -29,16 +31,23 @@ __global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict
     const int g = lane >> 4, l = lane & 15;
     const int wrow = 16 * wave + 4 * g;  // first of this lane's four rows inside the block
 
+    const int nch = npad / 16;
     for (int cb = npad - BS; cb >= 0; cb -= BS) {
         const double* rows = S + (size_t)(cb + wrow) * ld;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i0 = cb + BS; i0 < npad; i0 += BS) {
+        // columns beyond the envelope of these rows are exact zeros of U (and were never written)
+        int col_end = npad;
+        if (env_all != nullptr)
+            col_end = 16 * trs_env_row_end(trs_env_of(env_all, b, n_pad_max), cb / BS, nch);
+        for (int i0 = cb + BS; i0 < col_end; i0 += BS) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int col = i0 + 16 * k + l;
-                const double ui = us[col];
+                if (i0 + 16 * k < col_end) {  // uniform: the envelope ends on a 16-column boundary
+                    const int col = i0 + 16 * k + l;
+                    const double ui = us[col];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] += rows[(size_t)q * ld + col] * ui;
+                    for (int q = 0; q < 4; ++q) acc[q] += rows[(size_t)q * ld + col] * ui;
+                }
             }
         }
         // the diagonal block rows (columns cb .. cb+63) go to LDS for the triangle solve
@@ -73,7 +82,8 @@ __global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict
 }  // namespace
 
 extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
-                                const double* S, double* uf, int ld_uf, hipStream_t stream) {
+                                const double* S, double* uf, int ld_uf, const int* env,
+                                hipStream_t stream) {
     if (B <= 0 || n_pad_max <= 0) return 0;
     const size_t lds = (size_t)(n_pad_max + BS * (BS + 1) + BS) * sizeof(double);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
@@ -81,6 +91,6 @@ extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_st
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(trs_potrs_kernel, dim3(B), dim3(256), lds, stream, S, n_free, ld, slab_stride,
-                       uf, ld_uf);
+                       uf, ld_uf, env, n_pad_max);
     return (int)hipGetLastError();
 }

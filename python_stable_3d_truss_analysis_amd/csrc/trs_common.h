@@ -26,3 +26,30 @@ __device__ static inline double readlane_f64(double v) {
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
     return __hiloint2double(hi, lo);
 }
+
+// ---- envelope (profile) metadata of the reduced stiffness matrix, per truss ----------------------
+// Written by trs_assemble, read by trs_potrf_batched / trs_potrs_batched (optional: a null pointer
+// means "treat the matrix as dense").  All quantities are in units of 16-row chunks / 16-column
+// tiles of the padded system (nch = n_pad / 16):
+//   ft[q]   q < nch : first tile of row chunk q that can hold a non-zero of L (row envelope of the
+//                     lower triangle), made non-decreasing in q (running minimum from the end), so
+//                     that the set of chunks reaching into a panel is a contiguous range;
+//   last[j] j < nch/4: last row chunk q with ft[q] <= 4 j + 3, i.e. the last chunk with any non-zero
+//                     in the 64 columns of panel j (>= 4 j + 3).
+// Cholesky fill stays inside the row envelope, so tiles outside it are exact zeros and are skipped:
+// trs_assemble writes row tiles of panel j only up to chunk last[j] + 3 (the slack covers the
+// 4-chunk work items of the factorisation), plus the load column.
+struct TrsEnv {
+    const int* ft;
+    const int* last;
+};
+__host__ __device__ static inline int trs_env_stride(int n_pad_max) { return n_pad_max / 16 + n_pad_max / 64 + 8; }
+__host__ __device__ static inline TrsEnv trs_env_of(const int* env, int b, int n_pad_max) {
+    const int* base = env + (size_t)b * trs_env_stride(n_pad_max);
+    return TrsEnv{base, base + n_pad_max / 16};
+}
+// chunks written / read for the rows of panel j: exclusive upper bound, in chunks
+__host__ __device__ static inline int trs_env_row_end(const TrsEnv& e, int j, int nch) {
+    const int end = e.last[j] + 4;
+    return end < nch ? end : nch;
+}

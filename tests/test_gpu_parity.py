@@ -68,13 +68,31 @@ def test_stages_against_oracle(gpu, name):
     np.testing.assert_array_equal(S[n:npad, n:npad], np.eye(npad - n))
     assert not S[:npad, npad + 1: npad + 16].any()
 
+    # --- envelope metadata against the non-zero pattern of the oracle's K_ff ----------------------
+    nch = npad // 16
+    first = np.arange(nch)
+    for c in range(n):
+        first[c // 16] = min(first[c // 16], int(np.flatnonzero(ref["K_ff"][c])[0]) // 16)
+    ft = np.minimum.accumulate(first[::-1])[::-1]
+    last = [max(q for q in range(nch) if ft[q] <= 4 * j + 3) for j in range(nch // 4)]
+    env = dev.env.cpu().numpy()[0]
+    env_ft, env_last = env[:nch], env[dev.rows // 16: dev.rows // 16 + nch // 4]
+    # the device envelope is STRUCTURAL (joint coupling), so it may only be wider than the numerical
+    # pattern (a member along an axis gives exact zeros inside its 3x3 blocks)
+    assert (env_ft <= ft).all() and (env_ft <= np.arange(nch)).all() and (np.diff(env_ft) >= 0).all()
+    assert (env_last >= np.array(last)).all()
+    assert env_last.tolist() == [max(q for q in range(nch) if env_ft[q] <= 4 * j + 3) for j in range(nch // 4)]
+
     # --- assemble (production layout: upper part by 16-tiles) -----------------------------------
     dev.S.fill_(float("nan"))
     dev.assemble(flags=0)
     S = dev.S.cpu().numpy()[0]
     for c in (0, n // 2, n - 1):
         lo = c // 16 * 16
-        assert H.max_scaled_err(S[c, lo:n], ref["K_ff"][c, lo:]) <= 1e-14
+        hi = min(npad, 16 * (int(env_last[c // 64]) + 4))      # end of the written part of the row
+        assert H.max_scaled_err(S[c, lo:min(hi, n)], ref["K_ff"][c, lo:min(hi, n)]) <= 1e-14
+        assert not ref["K_ff"][c, min(hi, n):].any()            # beyond it K is structurally zero
+        assert np.isnan(S[c, hi:npad]).all() or hi >= npad      # ... and nothing was written there
 
     # --- potrf: U^T U = K_ff, y = L^-1 f ------------------------------------------------------
     dev.potrf()
@@ -82,6 +100,11 @@ def test_stages_against_oracle(gpu, name):
     S = dev.S.cpu().numpy()[0]
     U, y = _upper_from_slab(S, npad)
     Lref = np.linalg.cholesky(ref["K_ff"])
+    # tiles outside the envelope are never written (NaN poison of the test slab): there the factor
+    # must be structurally zero
+    outside = np.isnan(U[:n, :n])
+    assert np.abs(Lref.T[outside]).max(initial=0.0) <= 1e-12 * np.abs(Lref).max()
+    U = np.where(np.isnan(U), 0.0, U)
     assert H.max_scaled_err(U[:n, :n], Lref.T) <= 1e-9, "Cholesky factor differs from numpy"
     np.testing.assert_array_equal(np.diag(U)[n:], np.ones(npad - n))
     yref = np.linalg.solve(Lref, f_free)
@@ -225,7 +248,8 @@ def test_replicated_batch_is_identical_and_deterministic(gpu):
     U1 = dev.S.clone()
     dev.S.copy_(S0)
     dev.potrf()
-    assert bool((U1[:, :704, :720].triu() == dev.S[:, :704, :720].triu()).all())
+    same = U1[:, :704, :720].triu().view(dev.torch.int64) == dev.S[:, :704, :720].triu().view(dev.torch.int64)
+    assert bool(same.all())   # bitwise (NaN poison outside the envelope compares equal as bits)
 
 
 def test_property_checks_at_full_batch(gpu):

@@ -1,0 +1,22 @@
+import sys, json, os
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from python_stable_3d_truss_analysis_amd import batch
+data = json.load(open('tests/golden/data/bar-942_input_0.json'))
+packed = batch.pack_json([data]).replicate(4096)
+for use_env in (True, False):
+    dev = batch.DeviceBatch(packed, use_envelope=use_env)
+    dev.solve(); torch.cuda.synchronize()
+    ts = {}
+    for name in ("dofmap", "assemble", "potrf", "potrs", "recover"):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); getattr(dev, name)(); e1.record(); torch.cuda.synchronize()
+        ts[name] = round(e0.elapsed_time(e1), 3)
+    res = dev.result()
+    if use_env:
+        ref_u = res.displace[0].copy()
+        env = dev.env[0].cpu().numpy()
+        print("ft", env[:44].tolist()); print("last", env[44:55].tolist())
+    print("env" if use_env else "dense", ts, "total", round(sum(ts.values()), 3), "info", int((res.info != 0).sum()),
+          "diff_vs_env", float(np.abs(res.displace[0] - ref_u).max() / np.abs(ref_u).max()))
+    del dev
