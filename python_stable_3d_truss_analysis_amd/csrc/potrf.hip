@@ -157,14 +157,18 @@ __device__ __forceinline__ constexpr int lf_idx(int u, int s) { return u * (u - 
 __device__ __forceinline__ constexpr int t_idx(int u, int s) { return u * (u + 1) / 2 + s; }
 
 struct PanelLds {
-    // inv(L_ss) as MFMA A-fragments: W[s][r*64 + lane] = inv(L_ss)[lane & 15][4 r + (lane >> 4)]
-    double W[CT][256];
-    // L_{u,s} (u > s) as A-fragments = the D-form registers of the tile (rows of tile u, columns
-    // of tile s): Lf[lf_idx(u,s)][r*64 + lane]
-    double Lf[6][256];
     // diagonal-block tiles (D-form), two k-half partials, handed from the D waves to the factor
-    // wave: T[half][t_idx(u,s)]
+    // wave: T[half][t_idx(u,s)].  Once the factor wave holds them in registers the same memory is
+    // reused for the operand fragments it produces (the D waves write T again only after the
+    // panel's closing barrier):
+    //   W(s)   = T[0][s]      inv(L_ss) as MFMA A-fragments: [r*64 + lane] = inv(L_ss)[lane & 15][4 r + (lane >> 4)]
+    //   Lf(i)  = T[0][4 + i]  L_{u,s} (u > s), i = lf_idx(u,s): the D-form registers of the tile
+    //                          (rows of tile u, columns of tile s) = its A-fragments
     double T[2][10][256];
+    __device__ __forceinline__ double* W(int s) { return T[0][s]; }
+    __device__ __forceinline__ const double* W(int s) const { return T[0][s]; }
+    __device__ __forceinline__ double* Lf(int i) { return T[0][4 + i]; }
+    __device__ __forceinline__ const double* Lf(int i) const { return T[0][4 + i]; }
     ChScratch ch;  // scratch of the scalar 16x16 factorisation
     int info;      // 1-based column of the first non-positive pivot, 0 = none
     int d_done;    // diagonal chunks updated so far (4 per panel, monotone over panels)
@@ -294,7 +298,7 @@ __device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelL
     for (int s = 0; s < CT; ++s) {
         if (ok) {
             st.mark(1);
-            t[s][s] = chol16_invert(t[s][s], sm.ch, sm.W[s]);
+            t[s][s] = chol16_invert(t[s][s], sm.ch, sm.W(s));
             __builtin_amdgcn_wave_barrier();
             const int bad = sm.ch.bad;
             st.mark(7);
@@ -306,7 +310,7 @@ __device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelL
         if (ok) {
             double wf[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) wf[r] = sm.W[s][r * 64 + lane];
+            for (int r = 0; r < 4; ++r) wf[r] = sm.W(s)[r * 64 + lane];
 #pragma unroll
             for (int u = s + 1; u < CT; ++u) {
                 d4 x = d4{0.0, 0.0, 0.0, 0.0};
@@ -314,7 +318,7 @@ __device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelL
                 for (int r = 0; r < 4; ++r) x = mfma_f64(wf[r], t[u][s][r], x);
                 t[u][s] = x;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sm.Lf[lf_idx(u, s)][r * 64 + lane] = x[r];
+                for (int r = 0; r < 4; ++r) sm.Lf(lf_idx(u, s))[r * 64 + lane] = x[r];
             }
 #pragma unroll
             for (int u = s + 1; u < CT; ++u)
@@ -387,7 +391,7 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
     for (int s = 0; s < CT; ++s) {
         double wf[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wf[r] = sm.W[s][r * 64 + lane];
+        for (int r = 0; r < 4; ++r) wf[r] = sm.W(s)[r * 64 + lane];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {  // X_s^T = inv(L_ss) T_s^T
             d4 x = d4{0.0, 0.0, 0.0, 0.0};
@@ -399,7 +403,7 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
         for (int s2 = s + 1; s2 < CT; ++s2) {  // T_{s2}^T -= L_{s2,s} X_s^T
             double lf[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lf[r] = sm.Lf[lf_idx(s2, s)][r * 64 + lane];
+            for (int r = 0; r < 4; ++r) lf[r] = sm.Lf(lf_idx(s2, s))[r * 64 + lane];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -411,6 +415,21 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
 #pragma unroll
         for (int s = 0; s < CT; ++s) tile_store(acc[v][s], S, r0 + 16 * s, rowbase + 16 * v);
     st.mark(4);
+}
+
+// ---- which kernel factors a matrix --------------------------------------------------------------------
+// A matrix whose envelope reaches at most TRS_NARROW_MAX_BELOW row chunks below every diagonal block
+// has so little MFMA work per panel that one wave can carry it alone (trs_potrf_narrow_kernel: one
+// WAVE per matrix, no barriers, the serial 16x16 factorisations of up to 8 matrices per CU overlap);
+// all others go to trs_potrf_kernel (one WORK-GROUP per matrix).  Both kernels are launched and
+// evaluate this same rule, so every matrix is factored exactly once.
+#ifndef TRS_NARROW_MAX_BELOW
+#define TRS_NARROW_MAX_BELOW 12
+#endif
+__device__ __forceinline__ bool is_narrow(const TrsEnv& env, int npanels) {
+    int widest = 0;
+    for (int j = 0; j < npanels; ++j) widest = max(widest, env.last[j] - (4 * j + CT - 1));
+    return widest <= TRS_NARROW_MAX_BELOW;
 }
 
 __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_kernel(
@@ -440,6 +459,7 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
     const int nch = npad / 16;  // row chunks of the matrix; the right-hand side is one more, at row n_pad
     const bool has_env = env_all != nullptr;
     const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr};
+    if (has_env && is_narrow(env, npad / TRS_NB)) return;  // trs_potrf_narrow_kernel's matrix
 
     Stamps st;
     st.start();
@@ -511,6 +531,189 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
     if (threadIdx.x == 0) info[b] = sm.info;
 }
 
+// ======================================================================================================
+// Narrow-envelope variant: one WAVE per matrix, four matrices per work-group, no barriers, no LDS
+// hand-offs.  The wave keeps the panel's ten diagonal-block tiles, the four inv(L_ss) and the six
+// L_{u,s} operand tiles in registers (they are MFMA fragments as they stand), so the only LDS use is
+// the scratch of the scalar 16x16 factorisation.  Same arithmetic, same order of operations per
+// tile as the work-group kernel except that the diagonal-block update is not split in two halves.
+// ======================================================================================================
+#ifndef TRS_NARROW_RS
+#define TRS_NARROW_RS 2
+#endif
+#ifndef TRS_NARROW_DEPTH
+#define TRS_NARROW_DEPTH 4
+#endif
+#ifndef TRS_NARROW_WAVES_PER_SIMD
+#define TRS_NARROW_WAVES_PER_SIMD 2
+#endif
+constexpr int RSN = TRS_NARROW_RS;      // row chunks per item in the narrow kernel (1 or 2)
+constexpr int DEPTHN = TRS_NARROW_DEPTH;  // k-steps of fragments in flight (divides 4 k-steps = 16 columns)
+
+template <int NV>
+__device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const int rowbase, const int kstart,
+                                            const d4 (&W)[CT], const d4 (&t)[CT][CT]) {
+    d4 acc[NV][CT];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int s = 0; s < CT; ++s) tile_load(acc[v][s], S, r0 + 16 * s, rowbase + 16 * v);
+    if (r0 > kstart) {
+        int ob = S.at(kstart, r0);
+        int oa = S.at(kstart, rowbase);
+        const int step = S.ld * 32;
+        double fb[DEPTHN][CT], fa[DEPTHN][NV];
+#pragma unroll
+        for (int d = 0; d < DEPTHN - 1; ++d) {
+#pragma unroll
+            for (int s = 0; s < CT; ++s) fb[d][s] = S.load(ob + d * step + 128 * s);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) fa[d][v] = S.load(oa + d * step + 128 * v);
+        }
+        for (int k0 = kstart; k0 < r0; k0 += 4 * DEPTHN) {
+#pragma unroll
+            for (int d = 0; d < DEPTHN; ++d) {
+                const int nd = (d + DEPTHN - 1) % DEPTHN;
+#pragma unroll
+                for (int s = 0; s < CT; ++s) fb[nd][s] = S.load(ob + (d + DEPTHN - 1) * step + 128 * s);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) fa[nd][v] = S.load(oa + (d + DEPTHN - 1) * step + 128 * v);
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int s = 0; s < CT; ++s) acc[v][s] = mfma_f64_negA(fb[d][s], fa[d][v], acc[v][s]);
+            }
+            ob += DEPTHN * step;
+            oa += DEPTHN * step;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < CT; ++s) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {  // X_s^T = inv(L_ss) T_s^T
+            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x = mfma_f64(W[s][r], acc[v][s][r], x);
+            acc[v][s] = x;
+        }
+#pragma unroll
+        for (int s2 = s + 1; s2 < CT; ++s2)  // T_{s2}^T -= L_{s2,s} X_s^T
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[v][s2] = mfma_f64_negA(t[s2][s][r], acc[v][s][r], acc[v][s2]);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int s = 0; s < CT; ++s) tile_store(acc[v][s], S, r0 + 16 * s, rowbase + 16 * v);
+}
+
+__global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narrow_kernel(
+    double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
+    int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max, const int B) {
+    __shared__ ChScratch scratch[4];
+    __shared__ double wtmp[4][256];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;  // no work-group barrier anywhere in this kernel: waves are independent
+    const int npad = trs_round_up(n_free[b], TRS_NB);
+    if (npad == 0) {
+        if (lane == 0) info[b] = 0;
+        return;
+    }
+    const TrsEnv env = trs_env_of(env_all, b, n_pad_max);
+    if (!is_narrow(env, npad / TRS_NB)) return;  // trs_potrf_kernel's matrix
+    Slab S;
+    S.rs = __builtin_amdgcn_make_buffer_rsrc(S_all + (size_t)b * slab_stride, 0,
+                                             (int)(slab_stride * sizeof(double)), 0x00020000);
+    S.ld = ld;
+    S.loff = ((unsigned)(lane >> 4) * (unsigned)ld + (unsigned)(lane & 15)) * 8u;
+    ChScratch& sc = scratch[wave];
+    double* wfrag = wtmp[wave];
+    int bad_col = 0;
+
+    for (int r0 = 0, panel = 0; r0 < npad && bad_col == 0; r0 += TRS_NB, ++panel) {
+        const int kd = 16 * env.ft[4 * panel];
+        // D: the ten lower tiles of the diagonal block
+        d4 t[CT][CT];
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int s = 0; s <= u; ++s) tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+        if (r0 > kd) {
+            const int step = S.ld * 32;
+            int ok = S.at(kd, r0);
+            double fb[DEPTHN][CT];
+#pragma unroll
+            for (int d = 0; d < DEPTHN - 1; ++d)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) fb[d][c] = S.load(ok + d * step + 128 * c);
+            for (int k0 = kd; k0 < r0; k0 += 4 * DEPTHN) {
+#pragma unroll
+                for (int d = 0; d < DEPTHN; ++d) {
+                    const int nd = (d + DEPTHN - 1) % DEPTHN;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) fb[nd][c] = S.load(ok + (d + DEPTHN - 1) * step + 128 * c);
+#pragma unroll
+                    for (int u = 0; u < CT; ++u)
+#pragma unroll
+                        for (int s = 0; s <= u; ++s) t[u][s] = mfma_f64_negA(fb[d][s], fb[d][u], t[u][s]);
+                }
+                ok += DEPTHN * step;
+            }
+        }
+        // F: factor the block in registers
+        d4 W[CT];
+#pragma unroll
+        for (int s = 0; s < CT; ++s) {
+            if (bad_col == 0) {
+                t[s][s] = chol16_invert(t[s][s], sc, wfrag);
+                __builtin_amdgcn_wave_barrier();
+                const int bad = sc.bad;
+                if (bad >= 0) bad_col = r0 + 16 * s + bad + 1;
+            }
+            if (bad_col == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) W[s][r] = wfrag[r * 64 + lane];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = s + 1; u < CT; ++u) {
+                    d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x = mfma_f64(W[s][r], t[u][s][r], x);
+                    t[u][s] = x;
+                }
+#pragma unroll
+                for (int u = s + 1; u < CT; ++u)
+#pragma unroll
+                    for (int s2 = s + 1; s2 <= u; ++s2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) t[u][s2] = mfma_f64_negA(t[s2][s][r], t[u][s][r], t[u][s2]);
+            } else {
+                W[s] = d4{0.0, 0.0, 0.0, 0.0};
+            }
+        }
+        if (bad_col != 0) break;
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int s = 0; s <= u; ++s) tile_store(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+        // items: the chunks below the block that reach into this panel, then the load column
+        const int lastq = env.last[panel];
+        for (int c0 = 4 * panel + CT; c0 <= lastq; c0 += RSN) {
+            const int ks = 16 * env.ft[c0];
+            if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1)>(S, r0, c0 * 16, ks, W, t);
+            else narrow_item<1>(S, r0, c0 * 16, ks, W, t);
+        }
+        narrow_item<1>(S, r0, npad, kd, W, t);
+        // this wave's stores must have landed before its own loads of the next panel
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    if (lane == 0) info[b] = bad_col;
+}
+
 }  // namespace
 
 #ifdef TRS_POTRF_STAMPS
@@ -527,6 +730,12 @@ extern "C" int trs_debug_stamps(unsigned long long* host_out, int reset) {
 extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
                                 double* S, int* info, const int* env, hipStream_t stream) {
     if (B <= 0) return 0;
+    if (env != nullptr) {
+        hipLaunchKernelGGL(trs_potrf_narrow_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, S, n_free, ld,
+                           slab_stride, info, env, n_pad_max, B);
+        const int rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(trs_potrf_kernel, dim3(B), dim3(NW * 64), 0, stream, S, n_free, ld,
                        slab_stride, info, env, n_pad_max);
     return (int)hipGetLastError();

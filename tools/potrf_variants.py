@@ -35,10 +35,11 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--case", default="bar-942_input_0")
+    ap.add_argument("--dense", action="store_true", help="no envelope tile skipping")
     args = ap.parse_args()
     with open(os.path.join(ROOT, "tests", "golden", "data", args.case + ".json")) as fh:
         data = json.load(fh)
-    dev = batch.DeviceBatch(batch.pack_json([data]).replicate(args.batch))
+    dev = batch.DeviceBatch(batch.pack_json([data]).replicate(args.batch), use_envelope=not args.dense)
     libs = {t: load_variant(t) for t in args.tags}
     stages = ("dofmap", "assemble", "potrf", "potrs", "recover")
     times = {t: {s: [] for s in stages} for t in args.tags}
