@@ -37,17 +37,20 @@ def load_case(name):
         return json.load(fh)
 
 
-def algorithmic_counts(n, nJ, nM):
-    """Per-truss algorithmic work (DESIGN.md section 'Kernels')."""
+def algorithmic_counts(n, nJ, nM, env_last=None, slack=3):
+    """Per-truss algorithmic work (DESIGN.md section 'Kernels').  With an envelope only the row
+    tiles up to chunk last[panel] + 3 are written / read (csrc/trs_common.h)."""
     npad = (n + 63) // 64 * 64
+    nch = npad // 16
     inputs = 8 * nM + 16 * nM + 24 * nJ + nJ + 24 * nJ
     # upper part by 16-row tiles incl. diagonal tiles, + rhs column chunk (16 wide)
-    upper = sum((npad + 16 - (c // 16) * 16) for c in range(npad)) * 8
+    row_end = (lambda c: npad) if env_last is None else (lambda c: 16 * min(nch, int(env_last[c // 64]) + 1 + slack))
+    upper = sum((row_end(c) + 16 - (c // 16) * 16) for c in range(npad)) * 8
     return {
         "potrf_flops": n ** 3 / 3.0 + n ** 2,           # factor + fused forward substitution
         "assemble_bytes": inputs + upper,               # K written once (upper part) + inputs
         "assemble_bytes_full_contract": inputs + 8 * n * n + 8 * n,  # SURVEY section 8d figure
-        "potrs_bytes": 8 * n * (n + 1) / 2 + 16 * n,    # U read once + y in, u out
+        "potrs_bytes": upper + 8 * n,                   # stored part of U read once (incl. y), u out
         "recover_bytes": 8 * nM + 16 * nM + 24 * nJ + 8 * n + 24 * nJ + 24 * nJ + 8 * nM,
     }
 
@@ -107,6 +110,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense", action="store_true",
                     help="treat every stiffness matrix as dense (no envelope tile skipping)")
+    ap.add_argument("--no-dense-ref", action="store_true",
+                    help="skip the dense-mode reference measurement of the factorisation (profiling runs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -172,7 +177,7 @@ def main():
     # reference point outside the timed region (rank 0): the same kernels with the envelope switched
     # off, i.e. the dense factorisation that SURVEY section 8d's FLOP figure describes
     dense_ms = None
-    if rank == 0 and not args.dense:
+    if rank == 0 and not args.dense and not args.no_dense_ref:
         dense = batch.DeviceBatch(packed, device, use_envelope=False)
         dense.solve(); torch.cuda.synchronize(device)
         dense.dofmap(); dense.assemble()
@@ -183,14 +188,21 @@ def main():
 
     if rank == 0:
         total_trusses = world * args.batch * args.steps
-        counts = algorithmic_counts(n, nJ, nM)
         potrf_s = stage_ms["potrf"] * 1e-3
+        potrf_kernel = "trs_potrf_kernel"
         if dev.env is not None:
             env = dev.env[0].cpu().numpy()
             nchm = dev.rows // 16
-            tile_flops = potrf_tile_flops(n, env[:nchm], env[nchm:])
+            env_ft, env_last = env[:nchm], env[nchm:nchm + dev.rows // 64]
+            slack = int(env[nchm + dev.rows // 64])
+            narrow = slack == 1   # the kernel choice recorded by trs_assemble (csrc/trs_common.h)
+            potrf_kernel = "trs_potrf_narrow_kernel" if narrow else "trs_potrf_kernel"
+            tile_flops = potrf_tile_flops(n, env_ft, env_last, rs=2 if narrow else 4)
+            counts = algorithmic_counts(n, nJ, nM, env_last, slack)
         else:
             tile_flops = potrf_tile_flops(n)
+            counts = algorithmic_counts(n, nJ, nM)
+        dense_flops = algorithmic_counts(n, nJ, nM)["potrf_flops"]
         achieved_tflops = tile_flops * args.batch / potrf_s / 1e12
         asm_gbs = counts["assemble_bytes"] * args.batch / (stage_ms["assemble"] * 1e-3) / 1e9
         traffic = None
@@ -219,29 +231,29 @@ def main():
             "config": {"workload": f"{args.case} x {args.batch} independent copies per GPU "
                                    f"(nJ {nJ}, nM {nM}, n_free {n})",
                        "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, no collective"},
-            "roofline": {"kernel": "trs_potrf_kernel", "bound": "mfma", "achieved": achieved_tflops,
+            "roofline": {"kernel": potrf_kernel, "bound": "mfma", "achieved": achieved_tflops,
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
                          "flop_per_truss": tile_flops, "avg_launch_ms": stage_ms["potrf"],
                          "flop_model": "MFMA work inside the 16x16-tile envelope of K_ff (what the kernel "
                                        "executes; equals the dense tile count with --dense)",
-                         "dense_equivalent_tflops": counts["potrf_flops"] * args.batch / potrf_s / 1e12,
-                         "dense_flop_per_truss": counts["potrf_flops"]},
+                         "dense_equivalent_tflops": dense_flops * args.batch / potrf_s / 1e12,
+                         "dense_flop_per_truss": dense_flops},
             "stages_ms": stage_ms,
             "assemble_roofline": {"bound": "hbm", "achieved": asm_gbs, "peak": PEAK_HBM_GBS,
                                   "unit": "GB/s", "frac": asm_gbs / PEAK_HBM_GBS,
                                   "bytes_per_truss": counts["assemble_bytes"],
-                                  "note": "upper part by 16-row tiles + rhs column; the full symmetric "
-                                          "figure of SURVEY 8d would be "
-                                          f"{counts['assemble_bytes_full_contract']} B"},
+                                  "note": "bytes of the slab part that is stored (upper 16-row tiles inside the "
+                                          "envelope + load column) + inputs; the full symmetric dense "
+                                          f"figure of SURVEY 8d would be {counts['assemble_bytes_full_contract']} B"},
             "max_rel_err_vs_oracle": {"u": err_u, "N": err_n, "info_nonzero": int((res.info != 0).sum())},
             "envelope": not args.dense,
         }
         if dense_ms is not None:
             line["dense_mode_potrf"] = {
                 "avg_launch_ms": dense_ms,
-                "achieved_tflops": counts["potrf_flops"] * args.batch / (dense_ms * 1e-3) / 1e12,
-                "frac_of_peak": counts["potrf_flops"] * args.batch / (dense_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                "achieved_tflops": dense_flops * args.batch / (dense_ms * 1e-3) / 1e12,
+                "frac_of_peak": dense_flops * args.batch / (dense_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                 "note": "same kernel with the envelope off: n^3/3 + n^2 FLOP per truss (SURVEY 8d)"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(data, args.cpu_seconds)

@@ -66,9 +66,11 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
     int* fill = start + nJ_max + 1;                           // [nJ_max]   fill cursor / entry count
     int* adj = fill + nJ_max;                                 // [2 nM_max] (other joint << 16) | member
     int* chunkmin = adj + 2 * nM_max;                         // [n_pad_max/16] first tile per row chunk
+    int* fi = chunkmin + n_pad_max / 16;                      // [3 nJ_max] free index of every DOF
 
     const double* X = xyz + (size_t)b * 3 * nJ_max;
-    const int* fi = free_index + (size_t)b * 3 * nJ_max;
+    const int* fi_global = free_index + (size_t)b * 3 * nJ_max;
+    for (int d = tid; d < 3 * nJ; d += 256) fi[d] = fi_global[d];
     for (int j = tid; j < nJ; j += 256) cnt[j] = 0;
     for (int q = tid; q < n_pad_max / 16; q += 256) chunkmin[q] = q;  // padding rows: diagonal only
     __syncthreads();
@@ -190,11 +192,15 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
             running = min(running, chunkmin[q]);
             ft[q] = running;
         }
-        int q = 0;
+        int q = 0, widest = 0;
         for (int j = 0; j < nch / 4; ++j) {
             while (q + 1 < nch && ft[q + 1] <= 4 * j + 3) ++q;
             last[j] = q;
+            widest = max(widest, q - (4 * j + 3));
         }
+        // which factorisation kernel will take this matrix decides the item size, hence the slack
+        env[n_pad_max / 16 + n_pad_max / 64] =
+            (widest <= TRS_NARROW_MAX_BELOW ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1;
     }
 }
 
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void trs_expand_kernel(const unsigned char* __
     };
     const bool full = (flags & TRS_ASM_FULL_SYMMETRIC) != 0;
     const bool has_env = env_all != nullptr && !full;
-    const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr};
+    const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr, 0};
     fetch(0);
     for (int c0 = 0; c0 < npad; c0 += TR) {
         // stored part of these rows: columns [i_lo, i_hi) (diagonal tile .. end of the envelope of
@@ -292,10 +298,10 @@ __global__ __launch_bounds__(256) void trs_expand_kernel(const unsigned char* __
         }
         if (c0 + TR < npad) fetch(c0 + TR);  // next block's loads fly during the store phase
         __syncthreads();
-        for (int q = 0; q < TR; ++q) {
-            double* dst = S + (size_t)(c0 + q) * ld;
-            double* src = T + (size_t)q * W;
-            for (int x = tid * 2; x < W; x += 512) {
+        {   // all TR rows in parallel: TPR threads per row, 16 bytes per thread and pass
+            double* dst = S + (size_t)(c0 + rr) * ld;
+            double* src = T + (size_t)rr * W;
+            for (int x = e_first * 2; x < W; x += 2 * TPR) {
                 const int col = x < Wm ? i_lo + x : npad + (x - Wm);  // envelope part | load column
                 *reinterpret_cast<d2*>(dst + col) = *reinterpret_cast<const d2*>(src + x);
                 *reinterpret_cast<d2*>(src + x) = d2{0.0, 0.0};
@@ -318,7 +324,7 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
                                    double* S, int flags, void* work, int* env, hipStream_t stream) {
     if (B <= 0 || n_pad_max <= 0) return 0;
     if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;  // packed adjacency keys
-    const size_t lds1 = (size_t)nM_max * 32 + (size_t)(3 * nJ_max + 1 + 2 * nM_max + n_pad_max / 16) * 4;
+    const size_t lds1 = (size_t)nM_max * 32 + (size_t)(6 * nJ_max + 1 + 2 * nM_max + n_pad_max / 16) * 4;
     if (lds1 > 160 * 1024) return (int)hipErrorInvalidValue;
     if (lds1 > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_joint_blocks_kernel),

@@ -69,6 +69,7 @@ constexpr int NW = 4;                  // waves per work-group
 #define TRS_POTRF_DEPTH 4
 #endif
 constexpr int RS = TRS_POTRF_RS;       // row-chunk slots per wave (16 rows each), 1..4
+static_assert(RS >= 1 && RS <= TRS_WIDE_ITEM, "the envelope slack covers items of at most TRS_WIDE_ITEM chunks");
 constexpr int DEPTH = TRS_POTRF_DEPTH; // k-steps of operand fragments in flight (divides 16)
 
 
@@ -421,16 +422,9 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
 // A matrix whose envelope reaches at most TRS_NARROW_MAX_BELOW row chunks below every diagonal block
 // has so little MFMA work per panel that one wave can carry it alone (trs_potrf_narrow_kernel: one
 // WAVE per matrix, no barriers, the serial 16x16 factorisations of up to 8 matrices per CU overlap);
-// all others go to trs_potrf_kernel (one WORK-GROUP per matrix).  Both kernels are launched and
-// evaluate this same rule, so every matrix is factored exactly once.
-#ifndef TRS_NARROW_MAX_BELOW
-#define TRS_NARROW_MAX_BELOW 12
-#endif
-__device__ __forceinline__ bool is_narrow(const TrsEnv& env, int npanels) {
-    int widest = 0;
-    for (int j = 0; j < npanels; ++j) widest = max(widest, env.last[j] - (4 * j + CT - 1));
-    return widest <= TRS_NARROW_MAX_BELOW;
-}
+// all others go to trs_potrf_kernel (one WORK-GROUP per matrix).  trs_assemble makes the choice
+// (it sizes the written part of the slab by the item size of the chosen kernel) and records it in
+// the envelope metadata; both kernels are launched and each skips the other's matrices.
 
 __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_kernel(
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
@@ -458,8 +452,8 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
     S.loff = ((unsigned)(lane >> 4) * (unsigned)ld + (unsigned)(lane & 15)) * 8u;
     const int nch = npad / 16;  // row chunks of the matrix; the right-hand side is one more, at row n_pad
     const bool has_env = env_all != nullptr;
-    const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr};
-    if (has_env && is_narrow(env, npad / TRS_NB)) return;  // trs_potrf_narrow_kernel's matrix
+    const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr, 0};
+    if (has_env && trs_env_is_narrow(env)) return;  // trs_potrf_narrow_kernel's matrix
 
     Stamps st;
     st.start();
@@ -538,9 +532,7 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
 // the scratch of the scalar 16x16 factorisation.  Same arithmetic, same order of operations per
 // tile as the work-group kernel except that the diagonal-block update is not split in two halves.
 // ======================================================================================================
-#ifndef TRS_NARROW_RS
-#define TRS_NARROW_RS 2
-#endif
+#define TRS_NARROW_RS TRS_NARROW_ITEM
 #ifndef TRS_NARROW_DEPTH
 #define TRS_NARROW_DEPTH 4
 #endif
@@ -550,9 +542,11 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
 constexpr int RSN = TRS_NARROW_RS;      // row chunks per item in the narrow kernel (1 or 2)
 constexpr int DEPTHN = TRS_NARROW_DEPTH;  // k-steps of fragments in flight (divides 4 k-steps = 16 columns)
 
-template <int NV>
+// MASKB: the panel's own rows (B side) are read from column kstart on, but block chunk s is only
+// written from column bks[s] on (its envelope): earlier values are replaced by the zeros they stand for.
+template <int NV, bool MASKB>
 __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const int rowbase, const int kstart,
-                                            const d4 (&W)[CT], const d4 (&t)[CT][CT]) {
+                                            const int (&bks)[CT], const d4 (&W)[CT], const d4 (&t)[CT][CT]) {
     d4 acc[NV][CT];
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -563,10 +557,14 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
         int oa = S.at(kstart, rowbase);
         const int step = S.ld * 32;
         double fb[DEPTHN][CT], fa[DEPTHN][NV];
+        auto bload = [&](int off, int s, int k) {  // fragment of block chunk s at rows k .. k+3 of S
+            const double v = S.load(off + 128 * s);
+            return (!MASKB || k >= bks[s]) ? v : 0.0;
+        };
 #pragma unroll
         for (int d = 0; d < DEPTHN - 1; ++d) {
 #pragma unroll
-            for (int s = 0; s < CT; ++s) fb[d][s] = S.load(ob + d * step + 128 * s);
+            for (int s = 0; s < CT; ++s) fb[d][s] = bload(ob + d * step, s, kstart + 4 * d);
 #pragma unroll
             for (int v = 0; v < NV; ++v) fa[d][v] = S.load(oa + d * step + 128 * v);
         }
@@ -575,7 +573,8 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
             for (int d = 0; d < DEPTHN; ++d) {
                 const int nd = (d + DEPTHN - 1) % DEPTHN;
 #pragma unroll
-                for (int s = 0; s < CT; ++s) fb[nd][s] = S.load(ob + (d + DEPTHN - 1) * step + 128 * s);
+                for (int s = 0; s < CT; ++s)
+                    fb[nd][s] = bload(ob + (d + DEPTHN - 1) * step, s, k0 + 4 * (d + DEPTHN - 1));
 #pragma unroll
                 for (int v = 0; v < NV; ++v) fa[nd][v] = S.load(oa + (d + DEPTHN - 1) * step + 128 * v);
 #pragma unroll
@@ -624,7 +623,7 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
         return;
     }
     const TrsEnv env = trs_env_of(env_all, b, n_pad_max);
-    if (!is_narrow(env, npad / TRS_NB)) return;  // trs_potrf_kernel's matrix
+    if (!trs_env_is_narrow(env)) return;  // trs_potrf_kernel's matrix
     Slab S;
     S.rs = __builtin_amdgcn_make_buffer_rsrc(S_all + (size_t)b * slab_stride, 0,
                                              (int)(slab_stride * sizeof(double)), 0x00020000);
@@ -636,6 +635,9 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
 
     for (int r0 = 0, panel = 0; r0 < npad && bad_col == 0; r0 += TRS_NB, ++panel) {
         const int kd = 16 * env.ft[4 * panel];
+        // first written column of each of the block's four row chunks (their envelope)
+        const int bks[CT] = {16 * env.ft[4 * panel], 16 * env.ft[4 * panel + 1], 16 * env.ft[4 * panel + 2],
+                             16 * env.ft[4 * panel + 3]};
         // D: the ten lower tiles of the diagonal block
         d4 t[CT][CT];
 #pragma unroll
@@ -646,16 +648,21 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
             const int step = S.ld * 32;
             int ok = S.at(kd, r0);
             double fb[DEPTHN][CT];
+            auto bload = [&](int off, int c, int k) {  // zero where chunk c is left of its envelope
+                const double v = S.load(off + 128 * c);
+                return k >= bks[c] ? v : 0.0;
+            };
 #pragma unroll
             for (int d = 0; d < DEPTHN - 1; ++d)
 #pragma unroll
-                for (int c = 0; c < CT; ++c) fb[d][c] = S.load(ok + d * step + 128 * c);
+                for (int c = 0; c < CT; ++c) fb[d][c] = bload(ok + d * step, c, kd + 4 * d);
             for (int k0 = kd; k0 < r0; k0 += 4 * DEPTHN) {
 #pragma unroll
                 for (int d = 0; d < DEPTHN; ++d) {
                     const int nd = (d + DEPTHN - 1) % DEPTHN;
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) fb[nd][c] = S.load(ok + (d + DEPTHN - 1) * step + 128 * c);
+                    for (int c = 0; c < CT; ++c)
+                        fb[nd][c] = bload(ok + (d + DEPTHN - 1) * step, c, k0 + 4 * (d + DEPTHN - 1));
 #pragma unroll
                     for (int u = 0; u < CT; ++u)
 #pragma unroll
@@ -704,10 +711,10 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
         const int lastq = env.last[panel];
         for (int c0 = 4 * panel + CT; c0 <= lastq; c0 += RSN) {
             const int ks = 16 * env.ft[c0];
-            if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1)>(S, r0, c0 * 16, ks, W, t);
-            else narrow_item<1>(S, r0, c0 * 16, ks, W, t);
+            if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1), false>(S, r0, c0 * 16, ks, bks, W, t);
+            else narrow_item<1, false>(S, r0, c0 * 16, ks, bks, W, t);
         }
-        narrow_item<1>(S, r0, npad, kd, W, t);
+        narrow_item<1, true>(S, r0, npad, kd, bks, W, t);  // L y = f rides along: row n_pad
         // this wave's stores must have landed before its own loads of the next panel
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }

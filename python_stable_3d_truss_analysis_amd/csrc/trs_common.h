@@ -37,19 +37,31 @@ __device__ static inline double readlane_f64(double v) {
 //   last[j] j < nch/4: last row chunk q with ft[q] <= 4 j + 3, i.e. the last chunk with any non-zero
 //                     in the 64 columns of panel j (>= 4 j + 3).
 // Cholesky fill stays inside the row envelope, so tiles outside it are exact zeros and are skipped:
-// trs_assemble writes row tiles of panel j only up to chunk last[j] + 3 (the slack covers the
-// 4-chunk work items of the factorisation), plus the load column.
+//   slack           : how many chunks past last[j] the row tiles of panel j are written: the
+//                     factorisation works on items of `slack + 1` consecutive chunks whose tail may
+//                     overhang the envelope (1 for matrices that go to the wave-per-matrix kernel,
+//                     3 for the work-group kernel; see TRS_NARROW_MAX_BELOW).
+// trs_assemble writes row tiles of panel j only up to chunk last[j] + slack, plus the load column.
+#ifndef TRS_NARROW_MAX_BELOW
+#define TRS_NARROW_MAX_BELOW 12  // widest reach below a diagonal block (chunks) for the narrow kernel
+#endif
+#define TRS_NARROW_ITEM 2        // chunks per item of the narrow kernel
+#define TRS_WIDE_ITEM 4          // chunks per item of the work-group kernel
 struct TrsEnv {
     const int* ft;
     const int* last;
+    int slack;
 };
 __host__ __device__ static inline int trs_env_stride(int n_pad_max) { return n_pad_max / 16 + n_pad_max / 64 + 8; }
 __host__ __device__ static inline TrsEnv trs_env_of(const int* env, int b, int n_pad_max) {
     const int* base = env + (size_t)b * trs_env_stride(n_pad_max);
-    return TrsEnv{base, base + n_pad_max / 16};
+    return TrsEnv{base, base + n_pad_max / 16, base[n_pad_max / 16 + n_pad_max / 64]};
 }
 // chunks written / read for the rows of panel j: exclusive upper bound, in chunks
 __host__ __device__ static inline int trs_env_row_end(const TrsEnv& e, int j, int nch) {
-    const int end = e.last[j] + 4;
+    const int end = e.last[j] + 1 + e.slack;
     return end < nch ? end : nch;
 }
+// the matrix goes to the wave-per-matrix kernel (slack == TRS_NARROW_ITEM - 1) or to the
+// work-group kernel
+__host__ __device__ static inline bool trs_env_is_narrow(const TrsEnv& e) { return e.slack == TRS_NARROW_ITEM - 1; }

@@ -89,7 +89,8 @@ def test_stages_against_oracle(gpu, name):
     S = dev.S.cpu().numpy()[0]
     for c in (0, n // 2, n - 1):
         lo = c // 16 * 16
-        hi = min(npad, 16 * (int(env_last[c // 64]) + 4))      # end of the written part of the row
+        slack = int(env[dev.rows // 16 + dev.rows // 64])       # 1: wave-per-matrix kernel, 3: work-group kernel
+        hi = min(npad, 16 * (int(env_last[c // 64]) + 1 + slack))   # end of the written part of the row
         assert H.max_scaled_err(S[c, lo:min(hi, n)], ref["K_ff"][c, lo:min(hi, n)]) <= 1e-14
         assert not ref["K_ff"][c, min(hi, n):].any()            # beyond it K is structurally zero
         assert np.isnan(S[c, hi:npad]).all() or hi >= npad      # ... and nothing was written there
