@@ -275,6 +275,35 @@ class DeviceBatch:
                            self.info.cpu().numpy())
 
 
+def rcm_permutation(packed: PackedBatch):
+    """Reverse Cuthill-McKee joint order of every truss (native, `csrc/reorder.c`):
+    perm[b, k] = old id of the joint that becomes joint k.  Shrinks the envelope of the reduced
+    stiffness matrix of trusses that are not numbered along their long axis (cube trusses)."""
+    import ctypes
+    from .generate import _load
+    lib = _load()
+    lib.trs_rcm_order.restype = ctypes.c_int
+    perm = np.empty([packed.B, packed.nJ_max], dtype=np.int32)
+    ptr = lambda a: np.ascontiguousarray(a).ctypes.data_as(ctypes.c_void_p)
+    conn, cbits, nJ, nM = (np.ascontiguousarray(a) for a in (packed.conn, packed.cbits, packed.nJ, packed.nM))
+    rc = lib.trs_rcm_order(ctypes.c_int(packed.B), ctypes.c_int(packed.nJ_max), ctypes.c_int(packed.nM_max),
+                           ptr(conn), ptr(cbits), ptr(nJ), ptr(nM), perm.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"trs_rcm_order failed ({rc})")
+    return perm
+
+
+def permute_joints(packed: PackedBatch, perm):
+    """The same trusses with joint k := old joint perm[b, k] (members keep their order)."""
+    rows = np.arange(packed.B)[:, None]
+    inverse = np.empty_like(perm)
+    inverse[rows, perm] = np.arange(perm.shape[1], dtype=perm.dtype)[None, :]
+    conn = inverse[rows[:, :, None], packed.conn]
+    conn = np.where(np.arange(packed.nM_max)[None, :, None] < packed.nM[:, None, None], conn, 0).astype(np.int32)
+    return PackedBatch(packed.xyz[rows, perm], conn, packed.E, packed.A, packed.rho, packed.cbits[rows, perm],
+                       packed.loads[rows, perm], packed.nJ, packed.nM, packed.dim, packed.n_free)
+
+
 def size_buckets(packed: PackedBatch, max_slab_bytes=32 << 30):
     """Group the trusses of a ragged batch for launching: same padded system size n_pad per group
     (the slab and every work-group of a launch are then uniform) and at most `max_slab_bytes` of
@@ -289,13 +318,23 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=32 << 30):
     return groups
 
 
-def solve_batch(trusses_or_packed, device=None, max_slab_bytes=32 << 30):
+def solve_batch(trusses_or_packed, device=None, max_slab_bytes=32 << 30, reorder=False):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
 
     A ragged batch is bucketed by padded system size (`size_buckets`): one launch pipeline per
-    bucket, inputs trimmed to the bucket's own maxima, results scattered back to batch order."""
+    bucket, inputs trimmed to the bucket's own maxima, results scattered back to batch order.
+    `reorder=True` renumbers the joints of every truss by reverse Cuthill-McKee first (results come
+    back in the original numbering): worth it when the trusses are not numbered along their long
+    axis, e.g. generated cube trusses."""
     packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
         else pack_trusses(list(trusses_or_packed))
+    if reorder:
+        perm = rcm_permutation(packed)
+        res = solve_batch(permute_joints(packed, perm), device, max_slab_bytes, reorder=False)
+        rows = np.arange(packed.B)[:, None]
+        displace, external = np.empty_like(res.displace), np.empty_like(res.external)
+        displace[rows, perm], external[rows, perm] = res.displace, res.external
+        return BatchResult(displace, external, res.internal, res.info)
     groups = size_buckets(packed, max_slab_bytes)
     if len(groups) <= 1:
         dev = DeviceBatch(packed, device)

@@ -12,6 +12,14 @@ namespace {
 
 constexpr int BS = 64;  // rows per block
 
+// broadcast of lane `src` (wave-uniform, not necessarily a compile-time constant)
+__device__ __forceinline__ double lane_bcast_dyn(double v, int src) {
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), s);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict__ S_all,
                                                         const int* __restrict__ n_free, const int ld,
                                                         const size_t slab_stride,
@@ -65,9 +73,13 @@ __global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict
         }
         __syncthreads();
         if (wave == 0) {
+            // back substitution inside the 64 x 64 triangle: lane c owns the running right-hand side
+            // of row c; the pivot row's value is broadcast with v_readlane (uniform lane index), the
+            // reciprocals of the diagonal are formed once, in parallel
             double tc = tb[lane], mine = 0.0;
+            const double rinv = 1.0 / Ub[lane * (BS + 1) + lane];
             for (int cc = BS - 1; cc >= 0; --cc) {
-                const double ucc = __shfl(tc, cc) / Ub[cc * (BS + 1) + cc];
+                const double ucc = lane_bcast_dyn(tc, cc) * lane_bcast_dyn(rinv, cc);
                 if (lane == cc) mine = ucc;
                 if (lane < cc) tc -= Ub[lane * (BS + 1) + cc] * ucc;
             }

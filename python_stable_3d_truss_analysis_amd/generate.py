@@ -19,7 +19,7 @@ from .type import GenerateMethod, LinkType, MemberType
 from .utils import HipExtensionError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-GENLIB_PATH = os.path.join(_HERE, "libtrs_cubegen.so")
+GENLIB_PATH = os.path.join(_HERE, "libtrs_host.so")
 _gen = None
 
 

@@ -107,3 +107,10 @@ def test_generated_ragged_batch_on_gpu_matches_oracle():
     # every truss: global equilibrium of the external forces
     total = res.external.sum(axis=1)
     assert np.abs(total).max() <= 1e-6 * np.abs(res.external).max()
+    # RCM-renumbered solve (narrower envelopes, results mapped back): same answers
+    rcm = batch.solve_batch(p, reorder=True)
+    assert not rcm.info.any()
+    scale = np.abs(res.displace).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(rcm.displace - res.displace) / scale).max() <= 1e-8
+    assert np.abs(rcm.internal - res.internal).max() <= 1e-8 * np.abs(res.internal).max()
+    assert np.abs(rcm.external - res.external).max() <= 1e-7 * np.abs(res.external).max()

@@ -192,3 +192,35 @@ def test_size_buckets_and_trimmed_cover_a_ragged_batch():
     sub = p.take(groups[0]).trimmed()
     assert sub.nJ_max == int(sub.nJ.max()) and sub.nM_max == int(sub.nM.max())
     assert sub.n_free.tolist() == p.n_free[groups[0]].tolist()
+
+
+def test_rcm_permutation_is_valid_and_shrinks_the_cube_envelope():
+    """Native RCM (csrc/reorder.c): a permutation per truss; the joint bandwidth of generated cube
+    trusses drops well below the generator order; bar-942 (already banded) stays solvable either way."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    p = gen.generate_cube_batch([30, 60, 120, 190], gridRange=(6, 6, 6), seed=2)
+    perm = batch.rcm_permutation(p)
+    q = batch.permute_joints(p, perm)
+
+    def free_bandwidth(pk, b):
+        nJ, nM = int(pk.nJ[b]), int(pk.nM[b])
+        free = pk.cbits[b, :nJ] != 7
+        pos = np.cumsum(free) - 1
+        c = pk.conn[b, :nM]
+        both = free[c[:, 0]] & free[c[:, 1]]
+        return int(np.abs(pos[c[both, 0]] - pos[c[both, 1]]).max())
+
+    for b in range(p.B):
+        nJ = int(p.nJ[b])
+        assert sorted(perm[b, :nJ].tolist()) == list(range(nJ)) and perm[b, nJ:].tolist() == list(range(nJ, p.nJ_max))
+        assert free_bandwidth(q, b) < 0.6 * free_bandwidth(p, b)
+        # same truss: member lengths and section data unchanged, supports/loads moved with the joints
+        lens = lambda pk: np.linalg.norm(pk.xyz[b][pk.conn[b, :pk.nM[b], 1]] - pk.xyz[b][pk.conn[b, :pk.nM[b], 0]], axis=1)
+        np.testing.assert_allclose(lens(q), lens(p), rtol=0, atol=0)
+        np.testing.assert_array_equal(q.loads[b], p.loads[b][perm[b]])
+        assert int(q.n_free[b]) == int(p.n_free[b])
+    # the oracle gives the same physics in either numbering
+    from python_stable_3d_truss_analysis_amd.generate import packed_to_json
+    r0, r1 = orc.solve(packed_to_json(p, 0)), orc.solve(packed_to_json(q, 0))
+    np.testing.assert_allclose(r1["u"], r0["u"][perm[0, :int(p.nJ[0])]], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(r1["N"], r0["N"], rtol=1e-9, atol=1e-9)
