@@ -27,7 +27,7 @@ namespace {
 
 // ---- per-truss workspace layout (all offsets in bytes, 16-byte aligned) ---------------------------
 struct AsmWork {
-    size_t vals, cols, rowinfo, rowrhs, total;
+    size_t vals, cols, rowinfo, rowrhs, geom, total;
     int nent_max;
 };
 __host__ __device__ inline AsmWork asm_work_layout(int nJ_max, int nM_max, int n_pad_max) {
@@ -37,7 +37,9 @@ __host__ __device__ inline AsmWork asm_work_layout(int nJ_max, int nM_max, int n
     w.cols = w.vals + (size_t)w.nent_max * 48;      // int[nent_max][4]
     w.rowinfo = w.cols + (size_t)w.nent_max * 16;   // int2[n_pad_max]: (first entry, count | axis << 16)
     w.rowrhs = w.rowinfo + (size_t)n_pad_max * 8;   // double[n_pad_max]
-    w.total = (w.rowrhs + (size_t)n_pad_max * 8 + 255) / 256 * 256;
+    w.geom = w.rowrhs + (size_t)n_pad_max * 8;      // double[nM_max][4]: k, c (only for trusses whose
+                                                    // member geometry does not fit LDS)
+    w.total = (w.geom + (size_t)nM_max * 32 + 255) / 256 * 256;
     return w;
 }
 
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
     const double* __restrict__ A, const double* __restrict__ loads,
     const int* __restrict__ free_index, const int* __restrict__ n_free, const int* __restrict__ nJ_arr,
     const int* __restrict__ nM_arr, const int nJ_max, const int nM_max, const int n_pad_max,
-    unsigned char* __restrict__ work_all, int* __restrict__ env_all) {
+    unsigned char* __restrict__ work_all, int* __restrict__ env_all, const int geom_in_lds) {
     extern __shared__ unsigned char lds_raw[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nJ = nJ_arr[b], nM = nM_arr[b];
@@ -58,10 +60,11 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
     int* rowinfo = reinterpret_cast<int*>(work + lay.rowinfo);
     double* rowrhs = reinterpret_cast<double*>(work + lay.rowrhs);
 
-    // LDS carve: member geometry first (doubles), then the integer arrays
-    double* mk = reinterpret_cast<double*>(lds_raw);          // [nM_max]   E A / L
-    double* mc = mk + nM_max;                                 // [nM_max][3] direction cosines
-    int* cnt = reinterpret_cast<int*>(mc + 3 * (size_t)nM_max);  // [nJ_max]   member ends per joint
+    // member geometry: in LDS when it fits, else in the truss's workspace (L2); then the integer arrays
+    double* mk = geom_in_lds ? reinterpret_cast<double*>(lds_raw)
+                             : reinterpret_cast<double*>(work + lay.geom);  // [nM_max]   E A / L
+    double* mc = mk + nM_max;                                               // [nM_max][3] direction cosines
+    int* cnt = reinterpret_cast<int*>(lds_raw + (geom_in_lds ? (size_t)nM_max * 32 : 0));  // [nJ_max]
     int* start = cnt + nJ_max;                                // [nJ_max+1] exclusive scan of cnt
     int* fill = start + nJ_max + 1;                           // [nJ_max]   fill cursor / entry count
     int* adj = fill + nJ_max;                                 // [2 nM_max] (other joint << 16) | member
@@ -324,14 +327,16 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
                                    double* S, int flags, void* work, int* env, hipStream_t stream) {
     if (B <= 0 || n_pad_max <= 0) return 0;
     if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;  // packed adjacency keys
-    const size_t lds1 = (size_t)nM_max * 32 + (size_t)(6 * nJ_max + 1 + 2 * nM_max + n_pad_max / 16) * 4;
+    const size_t lds_ints = (size_t)(6 * nJ_max + 1 + 2 * nM_max + n_pad_max / 16) * 4;
+    const int geom_in_lds = (size_t)nM_max * 32 + lds_ints <= 64 * 1024;
+    const size_t lds1 = lds_ints + (geom_in_lds ? (size_t)nM_max * 32 : 0);
     if (lds1 > 160 * 1024) return (int)hipErrorInvalidValue;
     if (lds1 > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_joint_blocks_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     hipLaunchKernelGGL(trs_joint_blocks_kernel, dim3(B), dim3(256), lds1, stream, xyz, conn, E, A,
                        loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max,
-                       static_cast<unsigned char*>(work), env);
+                       static_cast<unsigned char*>(work), env, geom_in_lds);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     // Rows per block: the largest TR <= TRS_EXPAND_TR_MAX whose LDS (tile + row directory) stays

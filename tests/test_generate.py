@@ -114,3 +114,23 @@ def test_generated_ragged_batch_on_gpu_matches_oracle():
     assert (np.abs(rcm.displace - res.displace) / scale).max() <= 1e-8
     assert np.abs(rcm.internal - res.internal).max() <= 1e-8 * np.abs(res.internal).max()
     assert np.abs(rcm.external - res.external).max() <= 1e-7 * np.abs(res.external).max()
+
+
+@pytest.mark.gpu
+def test_large_cube_trusses_on_gpu():
+    """Beyond the bundled sizes: an 8x8x8 grid with 250-400 cubes (n up to ~2000 free DOFs), generator
+    order and RCM order, against the oracle on one sample and equilibrium / agreement on all."""
+    p = gen.generate_cube_batch([250, 320, 400, 400, 5], gridRange=(8, 8, 8), seed=21)
+    assert int(p.n_free.max()) > 1500
+    res = batch.solve_batch(p)
+    rcm = batch.solve_batch(p, reorder=True)
+    assert not res.info.any() and not rcm.info.any()
+    total = res.external.sum(axis=1)
+    assert np.abs(total).max() <= 1e-6 * np.abs(res.external).max()
+    scale = np.abs(res.displace).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(rcm.displace - res.displace) / scale).max() <= 1e-7
+    b = 1
+    ref = orc.solve(gen.packed_to_json(p, b))
+    nJ, nM = int(p.nJ[b]), int(p.nM[b])
+    assert H.max_scaled_err(res.displace[b, :nJ], ref["u"]) <= 1e-7
+    assert H.max_scaled_err(rcm.internal[b, :nM], ref["N"]) <= 1e-7
