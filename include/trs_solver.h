@@ -68,8 +68,9 @@ int trs_dofmap(int B, int nJ_max, const uint8_t *cbits, const int32_t *nJ,
  * `env` is an int32 array of B * trs_env_ints(n_max) entries. */
 int trs_env_ints(int n_max);
 
-/* Bytes of assembly workspace PER TRUSS (joint stiffness blocks + row directory) for a batch
- * with these maxima; the caller passes B times this many bytes as `work`. */
+/* Bytes of assembly workspace PER TRUSS for a batch with these maxima (member stiffness and
+ * direction cosines, used only when they do not fit the CU's LDS); the caller passes B times this
+ * many bytes as `work`. */
 size_t trs_assemble_work_bytes(int nJ_max, int nM_max, int n_max);
 
 /* Assembly of the reduced stiffness matrix and load vector.  Replaces Member.k/cosines/matK

@@ -4,80 +4,107 @@
 // (truss.py:307-316), GetExternalForceVector (truss.py:303-304) and the row/column elimination
 // matK[mask,:][:,mask], vecF[mask] (truss.py:343).
 //
-// Two kernels, no atomics on floating-point data, bit-reproducible:
+// One kernel, one work-group per truss, no atomics on floating-point data, bit-reproducible, and no
+// intermediate in HBM: the only global traffic is the truss's inputs (read once) and its slab rows
+// (written once).
 //
-//  1. trs_joint_blocks_kernel - one work-group per truss, edge-parallel.  Every member's
-//     k, c = (x1 - x0)/L are computed once (one thread per member); a sorted joint adjacency is
-//     built in LDS (integer counting sort + per-joint insertion sort by (other joint, member));
-//     one thread per joint then walks its list IN THAT FIXED ORDER and emits the joint's 3x3
-//     stiffness blocks - the diagonal block (sum over incident members) and one block per distinct
-//     neighbour (parallel members merged) - as "entries" (3 reduced column indices + the 6 unique
-//     values of the symmetric block) into a per-truss workspace, plus a per-row directory
-//     (rowinfo, rowrhs).  ~0.15 MB per truss, ~1 % of the run time.
+//  phase 0 (edge-parallel, all in LDS): every member's k, c = (x1 - x0)/L computed once (one thread
+//     per member); a sorted joint adjacency (integer counting sort + per-joint insertion sort by
+//     (other joint, member)); one thread per joint sums its diagonal 3x3 block IN THAT FIXED ORDER
+//     and finds the joint's smallest coupled column (the envelope, trs_common.h).
 //
-//  2. trs_expand_kernel - owner-computes, HBM-write bound.  One persistent work-group per truss walks
-//     the slab TR rows at a time: scatter the rows' entries into an LDS tile (pure data movement:
-//     every (row, column) is written by exactly one thread), add the load column and the identity
-//     padding, then write each row to HBM exactly once with 16-byte coalesced stores, zeroing the
-//     tile behind the reads.  The next block's entries are prefetched during the stores.
+//  phase 1 (owner-computes, HBM-write bound): the work-group walks the slab TR rows at a time.  A
+//     row's threads walk its joint's adjacency list; the head of every run of parallel members forms
+//     that neighbour's block row from the cached k, c and drops it into an LDS tile (every
+//     (row, column) is written by exactly one thread), then each row goes to HBM exactly once with
+//     16-byte coalesced stores, the tile being zeroed behind the reads.  Rows wider than the tile
+//     are written in column segments.
 #include "trs_common.h"
 #include "../../include/trs_solver.h"
 
 namespace {
 
-// ---- per-truss workspace layout (all offsets in bytes, 16-byte aligned) ---------------------------
-struct AsmWork {
-    size_t vals, cols, rowinfo, rowrhs, geom, total;
-    int nent_max;
+#ifndef TRS_ASM_THREADS
+#define TRS_ASM_THREADS 512
+#endif
+constexpr int NT = TRS_ASM_THREADS;  // threads per work-group
+constexpr int TPR = 32;              // threads per slab row (two rows per wave)
+constexpr int TR = NT / TPR;         // slab rows per block
+
+// LDS carve-up shared by host and device (bytes, every part 16-byte aligned)
+struct AsmLds {
+    size_t geom, diag, rhs, tile, ints, total;
 };
-__host__ __device__ inline AsmWork asm_work_layout(int nJ_max, int nM_max, int n_pad_max) {
-    AsmWork w;
-    w.nent_max = nJ_max + 2 * nM_max;               // one diagonal entry per joint + one per member end
-    w.vals = 0;                                     // double[nent_max][6]
-    w.cols = w.vals + (size_t)w.nent_max * 48;      // int[nent_max][4]
-    w.rowinfo = w.cols + (size_t)w.nent_max * 16;   // int2[n_pad_max]: (first entry, count | axis << 16)
-    w.rowrhs = w.rowinfo + (size_t)n_pad_max * 8;   // double[n_pad_max]
-    w.geom = w.rowrhs + (size_t)n_pad_max * 8;      // double[nM_max][4]: k, c (only for trusses whose
-                                                    // member geometry does not fit LDS)
-    w.total = (w.geom + (size_t)nM_max * 32 + 255) / 256 * 256;
-    return w;
+__host__ __device__ inline AsmLds asm_lds_layout(int nJ_max, int nM_max, int n_pad_max, int WT,
+                                                 int geom_in_lds) {
+    AsmLds l;
+    l.geom = 0;                                                  // double[nM_max][4]: k | c
+    l.diag = l.geom + (geom_in_lds ? (size_t)nM_max * 32 : 0);   // double[nJ_max][6]
+    l.rhs = l.diag + (size_t)nJ_max * 48;                        // double[n_pad_max]
+    l.tile = l.rhs + (size_t)n_pad_max * 8;                      // double[TR][WT + 16]
+    l.ints = l.tile + (size_t)TR * (WT + 16) * 8;
+    const size_t nints = (size_t)6 * nJ_max + 1 + 2 * (size_t)nM_max + n_pad_max / 16 +
+                         n_pad_max / 64 + n_pad_max + 4;
+    l.total = (l.ints + nints * 4 + 15) / 16 * 16;
+    return l;
 }
 
-// ---- kernel 1 ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
+template <bool GEOM_IN_LDS>  // a compile-time address space for k, c: LDS loads, not flat ones
+__global__ __launch_bounds__(NT) void trs_assemble_kernel(
     const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
     const double* __restrict__ A, const double* __restrict__ loads,
     const int* __restrict__ free_index, const int* __restrict__ n_free, const int* __restrict__ nJ_arr,
     const int* __restrict__ nM_arr, const int nJ_max, const int nM_max, const int n_pad_max,
-    unsigned char* __restrict__ work_all, int* __restrict__ env_all, const int geom_in_lds) {
+    const int ld, const size_t slab_stride, double* __restrict__ S_all, const int flags,
+    unsigned char* __restrict__ work_all, const size_t work_stride, int* __restrict__ env_all,
+    const int WT) {
     extern __shared__ unsigned char lds_raw[];
+    constexpr int geom_in_lds = GEOM_IN_LDS ? 1 : 0;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nJ = nJ_arr[b], nM = nM_arr[b];
-    const AsmWork lay = asm_work_layout(nJ_max, nM_max, n_pad_max);
-    unsigned char* work = work_all + (size_t)b * lay.total;
-    double* ent_vals = reinterpret_cast<double*>(work + lay.vals);
-    int* ent_cols = reinterpret_cast<int*>(work + lay.cols);
-    int* rowinfo = reinterpret_cast<int*>(work + lay.rowinfo);
-    double* rowrhs = reinterpret_cast<double*>(work + lay.rowrhs);
+    const int n = n_free[b];
+    const int npad = trs_round_up(n, TRS_NB);
+    if (npad == 0) return;
+    const int nch = npad / 16;
 
-    // member geometry: in LDS when it fits, else in the truss's workspace (L2); then the integer arrays
-    double* mk = geom_in_lds ? reinterpret_cast<double*>(lds_raw)
-                             : reinterpret_cast<double*>(work + lay.geom);  // [nM_max]   E A / L
-    double* mc = mk + nM_max;                                               // [nM_max][3] direction cosines
-    int* cnt = reinterpret_cast<int*>(lds_raw + (geom_in_lds ? (size_t)nM_max * 32 : 0));  // [nJ_max]
-    int* start = cnt + nJ_max;                                // [nJ_max+1] exclusive scan of cnt
-    int* fill = start + nJ_max + 1;                           // [nJ_max]   fill cursor / entry count
-    int* adj = fill + nJ_max;                                 // [2 nM_max] (other joint << 16) | member
-    int* chunkmin = adj + 2 * nM_max;                         // [n_pad_max/16] first tile per row chunk
-    int* fi = chunkmin + n_pad_max / 16;                      // [3 nJ_max] free index of every DOF
+    const AsmLds lay = asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, geom_in_lds);
+    // member geometry: in LDS when it fits, else in the truss's workspace (stays in L2)
+    double* mk;  // [nM_max] E A / L
+    if constexpr (GEOM_IN_LDS)
+        mk = reinterpret_cast<double*>(lds_raw + lay.geom);
+    else
+        mk = reinterpret_cast<double*>(work_all + (size_t)b * work_stride);
+    double* mc = mk + nM_max;                                        // [nM_max][3] direction cosines
+    double* diag = reinterpret_cast<double*>(lds_raw + lay.diag);    // diagonal 3x3 block per joint
+    double* rhs = reinterpret_cast<double*>(lds_raw + lay.rhs);      // reduced load vector
+    double* T = reinterpret_cast<double*>(lds_raw + lay.tile);       // row tile
+    int* fi = reinterpret_cast<int*>(lds_raw + lay.ints);            // [3 nJ_max] free index per DOF
+    int* cnt = fi + 3 * nJ_max;                                      // [nJ_max]   joint degree
+    int* start = cnt + nJ_max;                                       // [nJ_max+1] exclusive scan
+    int* fill = start + nJ_max + 1;                                  // [nJ_max]   fill cursor
+    int* adj = fill + nJ_max;                                        // [2 nM_max] (other << 16) | member
+    int* chunkmin = adj + 2 * nM_max;                                // [n_pad_max/16] first tile per chunk
+    int* lastl = chunkmin + n_pad_max / 16;                          // [n_pad_max/64] envelope: last chunk
+    int* rowdof = lastl + n_pad_max / 64;                            // [n_pad_max] DOF of a reduced row
+    int* misc = rowdof + n_pad_max;                                  // [4] envelope slack
 
+    // ---- phase 0 ---------------------------------------------------------------------------------------
     const double* X = xyz + (size_t)b * 3 * nJ_max;
+    const double* F = loads + (size_t)b * 3 * nJ_max;
     const int* fi_global = free_index + (size_t)b * 3 * nJ_max;
-    for (int d = tid; d < 3 * nJ; d += 256) fi[d] = fi_global[d];
-    for (int j = tid; j < nJ; j += 256) cnt[j] = 0;
-    for (int q = tid; q < n_pad_max / 16; q += 256) chunkmin[q] = q;  // padding rows: diagonal only
+    for (int d = tid; d < 3 * nJ; d += NT) {
+        const int c = fi_global[d];
+        fi[d] = c;
+        if (c >= 0) {
+            rowdof[c] = d;
+            rhs[c] = F[d];  // truss.py:303-304, vecF[mask]
+        }
+    }
+    for (int j = tid; j < nJ; j += NT) cnt[j] = 0;
+    for (int q = tid; q < nch; q += NT) chunkmin[q] = q;  // padding rows: diagonal only
+    for (int x = tid * 2; x < TR * (WT + 16); x += 2 * NT) *reinterpret_cast<d2*>(T + x) = d2{0.0, 0.0};
     __syncthreads();
-    for (int m = tid; m < nM; m += 256) {
+    for (int m = tid; m < nM; m += NT) {
         const size_t mm = (size_t)b * nM_max + m;
         const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
         double d[3], len2 = 0.0;
@@ -87,7 +114,7 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
             len2 += d[a] * d[a];
         }
         const double len = sqrt(len2);
-        mk[m] = E[mm] * A[mm] / len;                    // truss.py:56-58
+        mk[m] = E[mm] * A[mm] / len;                             // truss.py:56-58
 #pragma unroll
         for (int a = 0; a < 3; ++a) mc[3 * m + a] = d[a] / len;  // truss.py:60-63
         atomicAdd(&cnt[j0], 1);
@@ -110,17 +137,17 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
         }
         if (tid == 0) start[nJ] = base;
     }
-    for (int j = tid; j < nJ; j += 256) fill[j] = 0;
+    for (int j = tid; j < nJ; j += NT) fill[j] = 0;
     __syncthreads();
-    for (int m = tid; m < nM; m += 256) {
+    for (int m = tid; m < nM; m += NT) {
         const size_t mm = (size_t)b * nM_max + m;
         const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
         adj[start[j0] + atomicAdd(&fill[j0], 1)] = (j1 << 16) | m;
         adj[start[j1] + atomicAdd(&fill[j1], 1)] = (j0 << 16) | m;
     }
     __syncthreads();
-    // one thread per joint: sort its list by (other joint, member), then emit its blocks
-    for (int a = tid; a < nJ; a += 256) {
+    // one thread per joint: sort its list by (other joint, member); diagonal block; envelope
+    for (int a = tid; a < nJ; a += NT) {
         int* list = adj + start[a];
         const int deg = cnt[a];
         for (int i = 1; i < deg; ++i) {  // insertion sort, deg is small (<= ~20 for real trusses)
@@ -132,192 +159,192 @@ __global__ __launch_bounds__(256) void trs_joint_blocks_kernel(
             }
             list[p + 1] = key;
         }
-        const int e0 = a + start[a];  // first entry of this joint: the diagonal block
-        double diag[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        int nent = 1, i = 0;
-        int mincol = 0x7fffffff;  // smallest reduced column coupled to this joint's rows (envelope)
+        double dg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int mincol = 0x7fffffff;  // smallest reduced column coupled to this joint's rows
 #pragma unroll
         for (int s = 0; s < 3; ++s)
             if (fi[3 * a + s] >= 0) mincol = min(mincol, fi[3 * a + s]);
-        while (i < deg) {
-            const int other = list[i] >> 16;
+        for (int i = 0; i < deg; ++i) {
+            const int other = list[i] >> 16, m = list[i] & 0xffff;
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 if (fi[3 * other + s] >= 0) mincol = min(mincol, fi[3 * other + s]);
-            double blk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            do {  // run of parallel members between the same two joints, in member order
-                const int m = list[i] & 0xffff;
-                const double k = mk[m], cx = mc[3 * m], cy = mc[3 * m + 1], cz = mc[3 * m + 2];
-                const double v[6] = {k * (cx * cx), k * (cx * cy), k * (cx * cz),
-                                     k * (cy * cy), k * (cy * cz), k * (cz * cz)};  // truss.py:65-77
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    diag[q] += v[q];
-                    blk[q] -= v[q];
-                }
-                ++i;
-            } while (i < deg && (list[i] >> 16) == other);
-            const size_t e = (size_t)e0 + nent;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) ent_vals[6 * e + q] = blk[q];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) ent_cols[4 * e + s] = fi[3 * other + s];
-            ++nent;
+            const double k = mk[m], cx = mc[3 * m], cy = mc[3 * m + 1], cz = mc[3 * m + 2];
+            dg[0] += k * (cx * cx);  // truss.py:65-77, summed over the joint's members in list order
+            dg[1] += k * (cx * cy);
+            dg[2] += k * (cx * cz);
+            dg[3] += k * (cy * cy);
+            dg[4] += k * (cy * cz);
+            dg[5] += k * (cz * cz);
         }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) ent_vals[6 * (size_t)e0 + q] = diag[q];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) ent_cols[4 * (size_t)e0 + s] = fi[3 * a + s];
-        fill[a] = nent;
+        for (int q = 0; q < 6; ++q) diag[6 * a + q] = dg[q];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
             if (fi[3 * a + s] >= 0) atomicMin(&chunkmin[fi[3 * a + s] / 16], mincol / 16);
     }
     __syncthreads();
-    const double* F = loads + (size_t)b * 3 * nJ_max;
-    for (int dof = tid; dof < 3 * nJ; dof += 256) {
-        const int c = fi[dof];
-        if (c >= 0) {
-            const int a = dof / 3, r = dof % 3;
-            rowinfo[2 * c] = a + start[a];
-            rowinfo[2 * c + 1] = fill[a] | (r << 16);
-            rowrhs[c] = F[dof];  // truss.py:303-304, vecF[mask]
+    const bool full = (flags & TRS_ASM_FULL_SYMMETRIC) != 0;
+    const bool has_env = env_all != nullptr;
+    int slack = 0;
+    if (has_env) {
+        // envelope metadata (trs_common.h): monotone first-tile per chunk, last chunk per panel
+        if (tid == 0) {
+            int* env = env_all + (size_t)b * trs_env_stride(n_pad_max);
+            int* ft = env;
+            int* last = env + n_pad_max / 16;
+            int running = nch;
+            for (int q = nch - 1; q >= 0; --q) {
+                running = min(running, chunkmin[q]);
+                ft[q] = running;
+                chunkmin[q] = running;
+            }
+            int q = 0, widest = 0;
+            for (int j = 0; j < nch / 4; ++j) {
+                while (q + 1 < nch && chunkmin[q + 1] <= 4 * j + 3) ++q;
+                last[j] = q;
+                lastl[j] = q;
+                widest = max(widest, q - (4 * j + 3));
+            }
+            // which factorisation kernel will take this matrix decides the item size, hence the slack
+            const int sl = (widest <= TRS_NARROW_MAX_BELOW ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1;
+            env[n_pad_max / 16 + n_pad_max / 64] = sl;
+            misc[0] = sl;
         }
+        __syncthreads();
+        slack = misc[0];
     }
-    // envelope metadata (trs_common.h): monotone first-tile per chunk, last chunk per panel
-    if (env_all != nullptr && tid == 0) {
-        int* env = env_all + (size_t)b * trs_env_stride(n_pad_max);
-        const int nch = trs_round_up(n_free[b], TRS_NB) / 16;
-        int* ft = env;
-        int* last = env + n_pad_max / 16;
-        int running = nch;
-        for (int q = nch - 1; q >= 0; --q) {
-            running = min(running, chunkmin[q]);
-            ft[q] = running;
+
+    // ---- phase 1 ---------------------------------------------------------------------------------------
+    double* S = S_all + (size_t)b * slab_stride;
+    const int rr = tid / TPR, e_first = tid % TPR;
+    const int Wstride = WT + 16;
+    // Thread TPR-1 of a row carries the joint's own block, threads 0 .. TPR-2 the heads of the runs of
+    // its adjacency list (stride TPR-1).  The first piece of every thread is formed one block AHEAD,
+    // while the previous block's stores drain, so the scatter itself is three LDS writes.
+    int pq0 = -1, pq1 = -1, pq2 = -1, pdeg = 0;
+    double pv0 = 0.0, pv1 = 0.0, pv2 = 0.0;
+    // block row of the neighbour at list position i (head of a run), row r of the joint
+    auto run_values = [&](const int* list, int deg, int i, int r, int& q0, int& q1, int& q2,
+                          double& v0, double& v1, double& v2) {
+        const int other = list[i] >> 16;
+        q0 = q1 = q2 = -1;
+        if (i > 0 && (list[i - 1] >> 16) == other) return;  // not the head of a run
+        q0 = fi[3 * other];
+        q1 = fi[3 * other + 1];
+        q2 = fi[3 * other + 2];
+        v0 = v1 = v2 = 0.0;
+        int q = i;
+        do {  // parallel members between the same two joints, in member order
+            const int m = list[q] & 0xffff;
+            const double k = mk[m], cr = mc[3 * m + r];
+            v0 -= k * (cr * mc[3 * m]);
+            v1 -= k * (cr * mc[3 * m + 1]);
+            v2 -= k * (cr * mc[3 * m + 2]);
+            ++q;
+        } while (q < deg && (list[q] >> 16) == other);
+    };
+    auto prepare = [&](int c0) {
+        pq0 = pq1 = pq2 = -1;
+        pdeg = 0;
+        const int c = c0 + rr;
+        if (c >= n) return;
+        const int dof = rowdof[c];
+        const int a = dof / 3, r = dof - 3 * a;
+        if (e_first == TPR - 1) {
+            const double* dg = diag + 6 * a;  // row r of [xx xy xz; xy yy yz; xz yz zz]
+            pv0 = dg[r];
+            pv1 = dg[r == 0 ? 1 : (r == 1 ? 3 : 4)];
+            pv2 = dg[r == 0 ? 2 : (r == 1 ? 4 : 5)];
+            pq0 = fi[3 * a];
+            pq1 = fi[3 * a + 1];
+            pq2 = fi[3 * a + 2];
+        } else {
+            pdeg = cnt[a];
+            if (e_first < pdeg) run_values(adj + start[a], pdeg, e_first, r, pq0, pq1, pq2, pv0, pv1, pv2);
         }
-        int q = 0, widest = 0;
-        for (int j = 0; j < nch / 4; ++j) {
-            while (q + 1 < nch && ft[q + 1] <= 4 * j + 3) ++q;
-            last[j] = q;
-            widest = max(widest, q - (4 * j + 3));
+    };
+    prepare(0);
+    for (int c0 = 0; c0 < npad; c0 += TR) {
+        // stored part of these rows: columns [i_lo, i_hi) (diagonal tile .. end of the envelope of
+        // the panel the rows belong to); the 16-wide load-column chunk rides with the last segment
+        const int i_lo = full ? 0 : (c0 & ~15);
+        const int i_hi = (has_env && !full) ? 16 * min(nch, lastl[c0 / TRS_NB] + 1 + slack) : npad;
+        for (int seg_lo = i_lo; seg_lo < i_hi; seg_lo += WT) {
+            const int seg_hi = min(i_hi, seg_lo + WT);
+            const int Ws = seg_hi - seg_lo;  // multiple of 16
+            const bool is_last = seg_hi == i_hi;
+            const int W = Ws + (is_last ? 16 : 0);
+            {   // scatter: every (row, column) of the tile is written by exactly one thread
+                double* row = T + (size_t)rr * Wstride - seg_lo;
+                if (pq0 >= seg_lo && pq0 < seg_hi) row[pq0] = pv0;
+                if (pq1 >= seg_lo && pq1 < seg_hi) row[pq1] = pv1;
+                if (pq2 >= seg_lo && pq2 < seg_hi) row[pq2] = pv2;
+                if (pdeg > e_first + TPR - 1) {  // joints with more than TPR-1 list entries: rare
+                    const int dof = rowdof[c0 + rr];
+                    const int a = dof / 3, r = dof - 3 * a;
+                    for (int i = e_first + TPR - 1; i < pdeg; i += TPR - 1) {
+                        int q0, q1, q2;
+                        double v0, v1, v2;
+                        run_values(adj + start[a], pdeg, i, r, q0, q1, q2, v0, v1, v2);
+                        if (q0 >= seg_lo && q0 < seg_hi) row[q0] = v0;
+                        if (q1 >= seg_lo && q1 < seg_hi) row[q1] = v1;
+                        if (q2 >= seg_lo && q2 < seg_hi) row[q2] = v2;
+                    }
+                }
+                if (e_first == TPR - 1) {
+                    const int cc = c0 + rr;
+                    if (is_last) row[seg_lo + Ws] = cc < n ? rhs[cc] : 0.0;      // load column
+                    if (cc >= n && cc >= seg_lo && cc < seg_hi) row[cc] = 1.0;   // identity padding
+                }
+            }
+            // A row's tile slice is written and read by the same wave only (TPR divides 64), and a
+            // wave's LDS operations complete in order: no work-group barrier in this loop, the waves
+            // drift apart and hide each other's latencies.
+            __builtin_amdgcn_wave_barrier();
+            {   // all TR rows in parallel: TPR threads per row, 16 bytes per thread and pass
+                double* dst = S + (size_t)(c0 + rr) * ld;
+                double* src = T + (size_t)rr * Wstride;
+                for (int x = e_first * 2; x < W; x += 2 * TPR) {
+                    const int col = x < Ws ? seg_lo + x : npad + (x - Ws);  // envelope part | load column
+                    *reinterpret_cast<d2*>(dst + col) = *reinterpret_cast<const d2*>(src + x);
+                    *reinterpret_cast<d2*>(src + x) = d2{0.0, 0.0};
+                }
+            }
+            if (is_last && c0 + TR < npad) prepare(c0 + TR);  // overlaps with the stores in flight
+            __builtin_amdgcn_wave_barrier();
         }
-        // which factorisation kernel will take this matrix decides the item size, hence the slack
-        env[n_pad_max / 16 + n_pad_max / 64] =
-            (widest <= TRS_NARROW_MAX_BELOW ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1;
     }
 }
 
-// ---- kernel 2 ------------------------------------------------------------------------------------------
-// One persistent work-group per truss walks the slab in blocks of TR rows.  Per block: scatter the
-// prefetched entries into the (all-zero) LDS tile, issue the loads of the next block's entries,
-// barrier, then every thread reads 16-byte pieces of the tile, streams them to HBM and writes zeros
-// back behind itself (the tile is clean again without a separate pass), barrier.  The row directory
-// of the whole truss is cached in LDS up front, so a block costs one exposed-latency-free round.
-template <int TR>
-__global__ __launch_bounds__(256) void trs_expand_kernel(const unsigned char* __restrict__ work_all,
-                                                         const int* __restrict__ n_free,
-                                                         const int nJ_max, const int nM_max,
-                                                         const int n_pad_max, const int ld,
-                                                         const size_t slab_stride,
-                                                         double* __restrict__ S_all, const int flags,
-                                                         const int* __restrict__ env_all) {
-    extern __shared__ double lds[];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int n = n_free[b];
-    const int npad = trs_round_up(n, TRS_NB);
-    if (npad == 0) return;
-    const int Wmax = n_pad_max + 16;
-    double* T = lds;                                                 // [TR][Wmax] row tile
-    int2* dir = reinterpret_cast<int2*>(lds + (size_t)TR * Wmax);    // [npad] row directory
-
-    const AsmWork lay = asm_work_layout(nJ_max, nM_max, n_pad_max);
-    const unsigned char* work = work_all + (size_t)b * lay.total;
-    const double* ent_vals = reinterpret_cast<const double*>(work + lay.vals);
-    const int4* ent_cols = reinterpret_cast<const int4*>(work + lay.cols);
-    const int2* rowinfo = reinterpret_cast<const int2*>(work + lay.rowinfo);
-    const double* rowrhs = reinterpret_cast<const double*>(work + lay.rowrhs);
-    double* S = S_all + (size_t)b * slab_stride;
-
-    for (int c = tid; c < npad; c += 256) dir[c] = c < n ? rowinfo[c] : int2{0, 0};
-    for (int x = tid * 2; x < TR * Wmax; x += 512) *reinterpret_cast<d2*>(T + x) = d2{0.0, 0.0};
-    __syncthreads();
-
-    constexpr int TPR = 256 / TR;  // threads per row
-    const int rr = tid / TPR, e_first = tid % TPR;
-    // entry prefetched for the running block: (cols, 3 values of the row's block row)
-    int4 pcols = int4{-1, -1, -1, -1};
-    double pv0 = 0.0, pv1 = 0.0, pv2 = 0.0, prhs = 0.0;
-    auto fetch = [&](int c0) {
-        pcols = int4{-1, -1, -1, -1};
-        const int c = c0 + rr;
-        if (c < npad) {
-            const int2 info = dir[c];
-            const int count = info.y & 0xffff, r = info.y >> 16;
-            if (e_first < count) {
-                const size_t ent = (size_t)info.x + e_first;
-                pcols = ent_cols[ent];
-                const double* v = ent_vals + 6 * ent;  // row r of [xx xy xz; xy yy yz; xz yz zz]
-                pv0 = v[r];
-                pv1 = v[r == 0 ? 1 : (r == 1 ? 3 : 4)];
-                pv2 = v[r == 0 ? 2 : (r == 1 ? 4 : 5)];
-            }
+// tile width and geometry placement for a batch shape; returns 0 when nothing fits
+struct AsmPlan {
+    int WT, geom_in_lds;
+    size_t lds;
+};
+inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
+    // prefer two work-groups per CU (80 KiB each) with the member geometry in LDS, then geometry in
+    // the workspace, then one work-group per CU
+    const size_t budgets[2] = {80 * 1024, 160 * 1024};
+    for (size_t budget : budgets) {
+        for (int g = 1; g >= 0; --g) {
+            const size_t fixed = asm_lds_layout(nJ_max, nM_max, n_pad_max, -16, g).total;
+            if (fixed + (size_t)TR * (64 + 16) * 8 > budget) continue;
+            int WT = (int)((budget - fixed) / (TR * 8)) - 16;
+            WT = WT / 16 * 16;
+            if (WT > n_pad_max) WT = n_pad_max;
+            return AsmPlan{WT, g, asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, g).total};
         }
-        if (tid < TR && c0 + tid < n) prhs = rowrhs[c0 + tid];
-    };
-    const bool full = (flags & TRS_ASM_FULL_SYMMETRIC) != 0;
-    const bool has_env = env_all != nullptr && !full;
-    const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr, 0};
-    fetch(0);
-    for (int c0 = 0; c0 < npad; c0 += TR) {
-        // stored part of these rows: columns [i_lo, i_hi) (diagonal tile .. end of the envelope of
-        // the panel the rows belong to) followed in the tile by the 16-wide load-column chunk
-        const int i_lo = full ? 0 : (c0 & ~15);
-        const int i_hi = has_env ? 16 * trs_env_row_end(env, c0 / TRS_NB, npad / 16) : npad;
-        const int Wm = i_hi - i_lo;  // multiple of 16
-        const int W = Wm + 16;
-        {   // scatter: every (row, column) of the tile is written by exactly one thread
-            double* row = T + (size_t)rr * W - i_lo;
-            if (pcols.x >= i_lo && pcols.x < i_hi) row[pcols.x] = pv0;
-            if (pcols.y >= i_lo && pcols.y < i_hi) row[pcols.y] = pv1;
-            if (pcols.z >= i_lo && pcols.z < i_hi) row[pcols.z] = pv2;
-            const int c = c0 + rr;
-            if (c < n) {  // joints with more than TPR - 1 neighbours: rare, not prefetched
-                const int2 info = dir[c];
-                const int count = info.y & 0xffff, r = info.y >> 16;
-                for (int e = e_first + TPR; e < count; e += TPR) {
-                    const size_t ent = (size_t)info.x + e;
-                    const int4 cols = ent_cols[ent];
-                    const double* v = ent_vals + 6 * ent;
-                    if (cols.x >= i_lo && cols.x < i_hi) row[cols.x] = v[r];
-                    if (cols.y >= i_lo && cols.y < i_hi) row[cols.y] = v[r == 0 ? 1 : (r == 1 ? 3 : 4)];
-                    if (cols.z >= i_lo && cols.z < i_hi) row[cols.z] = v[r == 0 ? 2 : (r == 1 ? 4 : 5)];
-                }
-            }
-            if (tid < TR) {
-                const int cc = c0 + tid;
-                T[(size_t)tid * W + Wm] = cc < n ? prhs : 0.0;            // load column
-                if (cc >= n) T[(size_t)tid * W + cc - i_lo] = 1.0;        // identity padding
-            }
-        }
-        if (c0 + TR < npad) fetch(c0 + TR);  // next block's loads fly during the store phase
-        __syncthreads();
-        {   // all TR rows in parallel: TPR threads per row, 16 bytes per thread and pass
-            double* dst = S + (size_t)(c0 + rr) * ld;
-            double* src = T + (size_t)rr * W;
-            for (int x = e_first * 2; x < W; x += 2 * TPR) {
-                const int col = x < Wm ? i_lo + x : npad + (x - Wm);  // envelope part | load column
-                *reinterpret_cast<d2*>(dst + col) = *reinterpret_cast<const d2*>(src + x);
-                *reinterpret_cast<d2*>(src + x) = d2{0.0, 0.0};
-            }
-        }
-        __syncthreads();
     }
+    return AsmPlan{0, 0, 0};
 }
 
 }  // namespace
 
 extern "C" size_t trs_assemble_work_bytes(int nJ_max, int nM_max, int n_max) {
-    return asm_work_layout(nJ_max, nM_max, trs_round_up(n_max < 1 ? 1 : n_max, TRS_NB)).total;
+    (void)nJ_max;
+    (void)n_max;
+    return ((size_t)(nM_max < 1 ? 1 : nM_max) * 32 + 255) / 256 * 256;  // member geometry fallback
 }
 
 extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
@@ -327,45 +354,22 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
                                    double* S, int flags, void* work, int* env, hipStream_t stream) {
     if (B <= 0 || n_pad_max <= 0) return 0;
     if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;  // packed adjacency keys
-    const size_t lds_ints = (size_t)(6 * nJ_max + 1 + 2 * nM_max + n_pad_max / 16) * 4;
-    const int geom_in_lds = (size_t)nM_max * 32 + lds_ints <= 64 * 1024;
-    const size_t lds1 = lds_ints + (geom_in_lds ? (size_t)nM_max * 32 : 0);
-    if (lds1 > 160 * 1024) return (int)hipErrorInvalidValue;
-    if (lds1 > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_joint_blocks_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL(trs_joint_blocks_kernel, dim3(B), dim3(256), lds1, stream, xyz, conn, E, A,
-                       loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max,
-                       static_cast<unsigned char*>(work), env, geom_in_lds);
-    int rc = (int)hipGetLastError();
-    if (rc) return rc;
-    // Rows per block: the largest TR <= TRS_EXPAND_TR_MAX whose LDS (tile + row directory) stays
-    // under 64 KiB, so that at least two persistent work-groups share a CU.
-#ifndef TRS_EXPAND_TR_MAX
-#define TRS_EXPAND_TR_MAX 8
-#endif
-    const size_t row_bytes = (size_t)(n_pad_max + 16) * sizeof(double);
-    const size_t dir_bytes = (size_t)n_pad_max * 8;
-    const unsigned char* w = static_cast<const unsigned char*>(work);
-#define TRS_LAUNCH_EXPAND(TRV)                                                                          \
-    do {                                                                                                \
-        const size_t lds2 = TRV * row_bytes + dir_bytes;                                                \
-        if (lds2 > 48 * 1024)                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_expand_kernel<TRV>),            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);           \
-        hipLaunchKernelGGL(trs_expand_kernel<TRV>, dim3(B), dim3(256), lds2, stream, w, n_free, nJ_max, \
-                           nM_max, n_pad_max, ld, slab_stride, S, flags, env);                          \
+    const AsmPlan plan = asm_plan(nJ_max, nM_max, n_pad_max);
+    if (plan.WT <= 0) return (int)hipErrorInvalidValue;
+#define TRS_LAUNCH_ASSEMBLE(GL)                                                                          \
+    do {                                                                                                 \
+        if (plan.lds > 48 * 1024)                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_assemble_kernel<GL>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);        \
+        hipLaunchKernelGGL(trs_assemble_kernel<GL>, dim3(B), dim3(NT), plan.lds, stream, xyz, conn, E,  \
+                           A, loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max, ld,          \
+                           slab_stride, S, flags, static_cast<unsigned char*>(work),                     \
+                           trs_assemble_work_bytes(nJ_max, nM_max, 0), env, plan.WT);                    \
     } while (0)
-    if (TRS_EXPAND_TR_MAX >= 8 && 8 * row_bytes + dir_bytes <= 65536) {
-        TRS_LAUNCH_EXPAND(8);
-    } else if (TRS_EXPAND_TR_MAX >= 4 && 4 * row_bytes + dir_bytes <= 65536) {
-        TRS_LAUNCH_EXPAND(4);
-    } else if (TRS_EXPAND_TR_MAX >= 2 && 2 * row_bytes + dir_bytes <= 65536) {
-        TRS_LAUNCH_EXPAND(2);
-    } else {
-        if (row_bytes + dir_bytes > 160 * 1024) return (int)hipErrorInvalidValue;
-        TRS_LAUNCH_EXPAND(1);
-    }
-#undef TRS_LAUNCH_EXPAND
+    if (plan.geom_in_lds)
+        TRS_LAUNCH_ASSEMBLE(true);
+    else
+        TRS_LAUNCH_ASSEMBLE(false);
+#undef TRS_LAUNCH_ASSEMBLE
     return (int)hipGetLastError();
 }
