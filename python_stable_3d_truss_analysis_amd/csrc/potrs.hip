@@ -3,14 +3,22 @@
 // (slientruss3d/truss.py:343).  HBM-bound: U is streamed once, row by row (contiguous rows).
 //
 // One work-group per truss.  Blocks of 64 rows from the bottom up: all four waves form
-// t = y - U[rows, solved columns] . u for the block (16 independent coalesced loads in flight per
-// lane and 64-column chunk, 16-lane reductions) and stage the 64 x 64 diagonal block in LDS;
-// wave 0 then solves the triangle.
+// t = y - U[rows, solved columns] . u for the block (coalesced loads, 16-lane reductions) and stage
+// the 64 x 64 diagonal block in LDS; wave 0 then solves the triangle.  The loads of a block do not
+// depend on the solution, only the multiplications do: they are issued one block ahead, so the
+// serial chain over the blocks sees the triangle solves and not the memory latencies.
 #include "trs_common.h"
 
 namespace {
 
 constexpr int BS = 64;  // rows per block
+#ifndef TRS_POTRS_PF
+#define TRS_POTRS_PF 1
+#endif
+#ifndef TRS_POTRS_WAVES_PER_SIMD
+#define TRS_POTRS_WAVES_PER_SIMD 4
+#endif
+constexpr int PF = TRS_POTRS_PF;  // 64-column chunks of the off-diagonal part requested a block ahead
 
 // broadcast of lane `src` (wave-uniform, not necessarily a compile-time constant)
 __device__ __forceinline__ double lane_bcast_dyn(double v, int src) {
@@ -20,7 +28,7 @@ __device__ __forceinline__ double lane_bcast_dyn(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict__ S_all,
+__global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kernel(const double* __restrict__ S_all,
                                                         const int* __restrict__ n_free, const int ld,
                                                         const size_t slab_stride,
                                                         double* __restrict__ uf, const int ld_uf,
@@ -40,17 +48,58 @@ __global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict
     const int wrow = 16 * wave + 4 * g;  // first of this lane's four rows inside the block
 
     const int nch = npad / 16;
-    for (int cb = npad - BS; cb >= 0; cb -= BS) {
+    const TrsEnv env = env_all != nullptr ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr, 0};
+    // columns beyond the envelope of a 64-row block are exact zeros of U (and were never written)
+    auto block_col_end = [&](int cb) {
+        return env_all != nullptr ? 16 * trs_env_row_end(env, cb / BS, nch) : npad;
+    };
+
+    // Everything a block needs from HBM is requested ONE BLOCK AHEAD, before the previous block's
+    // triangle solve: its diagonal 64 x 64 part, its load-column entries and the first PF 64-column
+    // chunks of its off-diagonal part (held in registers), so that a block exposes at most one memory
+    // latency and narrow envelopes none beyond the first.
+    double dv[16], ov[PF][16], yv[4];
+    auto request = [&](int cb) {
         const double* rows = S + (size_t)(cb + wrow) * ld;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        // columns beyond the envelope of these rows are exact zeros of U (and were never written)
-        int col_end = npad;
-        if (env_all != nullptr)
-            col_end = 16 * trs_env_row_end(trs_env_of(env_all, b, n_pad_max), cb / BS, nch);
-        for (int i0 = cb + BS; i0 < col_end; i0 += BS) {
+        const int col_end = block_col_end(cb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)  // tiles left of the wave's diagonal tile: never written, never used
+                if (k >= wave) dv[4 * q + k] = rows[(size_t)q * ld + cb + 16 * k + l];
+            yv[q] = rows[(size_t)q * ld + npad];
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (i0 + 16 * k < col_end) {  // uniform: the envelope ends on a 16-column boundary
+                const int c0 = cb + BS * (p + 1) + 16 * k;
+                if (c0 < col_end) {  // uniform: the envelope ends on a 16-column boundary
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ov[p][4 * q + k] = rows[(size_t)q * ld + c0 + l];
+                }
+            }
+    };
+    request(npad - BS);
+    for (int cb = npad - BS; cb >= 0; cb -= BS) {
+        const double* rows = S + (size_t)(cb + wrow) * ld;
+        const int col_end = block_col_end(cb);
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c0 = cb + BS * (p + 1) + 16 * k;
+                if (c0 < col_end) {
+                    const double ui = us[c0 + l];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] += ov[p][4 * q + k] * ui;
+                }
+            }
+        for (int i0 = cb + BS * (PF + 1); i0 < col_end; i0 += BS) {  // wide envelopes: streamed
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + 16 * k < col_end) {
                     const int col = i0 + 16 * k + l;
                     const double ui = us[col];
 #pragma unroll
@@ -63,14 +112,15 @@ __global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                Ub[(wrow + q) * (BS + 1) + 16 * k + l] = rows[(size_t)q * ld + cb + 16 * k + l];
+                if (k >= wave) Ub[(wrow + q) * (BS + 1) + 16 * k + l] = dv[4 * q + k];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double v = acc[q];
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
-            if (l == 0) tb[wrow + q] = rows[(size_t)q * ld + npad] - v;  // y - U[c, solved] u
+            if (l == 0) tb[wrow + q] = yv[q] - v;  // y - U[c, solved] u
         }
+        if (cb >= BS) request(cb - BS);  // in flight during the triangle solve
         __syncthreads();
         if (wave == 0) {
             // back substitution inside the 64 x 64 triangle: lane c owns the running right-hand side
@@ -78,6 +128,7 @@ __global__ __launch_bounds__(256) void trs_potrs_kernel(const double* __restrict
             // reciprocals of the diagonal are formed once, in parallel
             double tc = tb[lane], mine = 0.0;
             const double rinv = 1.0 / Ub[lane * (BS + 1) + lane];
+#pragma unroll 8
             for (int cc = BS - 1; cc >= 0; --cc) {
                 const double ucc = lane_bcast_dyn(tc, cc) * lane_bcast_dyn(rinv, cc);
                 if (lane == cc) mine = ucc;
