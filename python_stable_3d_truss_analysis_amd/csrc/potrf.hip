@@ -79,78 +79,94 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// Cholesky of one symmetric 16x16 tile by the calling wave, plus the inverse of its factor.
-// Runs in the factor wave, which holds no streaming accumulators, so it can afford a row-owner
-// copy of the tile in registers: lane li (every quarter-wave holds the same copy) owns row li,
-// a[k] = T[li][k].  Pivots, the column of the running step and the entries of L needed by the
-// inverse are broadcast with v_readlane (compile-time lanes, SGPR results): no LDS traffic and
-// no cross-lane waits inside the 16 sequential steps.
+// acc -= A * B : the BLGP field of the f64 MFMA is NEG[2:0] (bit 0 negates A; probed on gfx950
+// with tools/mfma_neg_test.hip).
+__device__ __forceinline__ d4 mfma_f64_negA(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+}
+
+// Cholesky of one symmetric 16x16 tile by the calling wave, plus the inverse of its factor, in
+// 4-column blocks so that everything of O(16^2) per step runs on the matrix core:
+//   * the 4 columns of block b are gathered row-owner-wise (lane li: c[q] = T[li][4b+q]; one LDS
+//     round) and factored with v_readlane broadcasts (compile-time lanes, SGPR results): 4 pivots
+//     and 6 multipliers per block instead of 16 and 120 per tile;
+//   * the lane-(lq, li) selection p = L[li][4b+lq] of those columns is at once the A and the B
+//     fragment of the rank-4 trailing update T -= P P^T (ONE MFMA, NEG-A), and, masked, register b of
+//     the result U = L^T in D-form;
+//   * inv(L) by block rows: W[b,:] = inv(L_bb) (I - sum_{k<b} L[:,k] W[k,:])[b,:] - one MFMA with the
+//     embedded 4x4 inverse (formed from the SGPR multipliers) as A and register b of the running
+//     D-form right-hand side as B, and one MFMA (A = p, B = the new W rows) to update the latter.
+// VALU work per tile drops from ~1150 to ~450 instructions; 11 dependent MFMAs replace the rest.
 //   t       : in  the symmetric tile in D-form (t[r] = T[c = lq + 4 r][i = li]);
 //             out U = L^T in D-form with exact zeros below the diagonal
-//   sc      : LDS scratch (layout conversion D-form <-> row owner, inverse hand-over)
+//   sc      : LDS scratch (block gather)
 //   wfrag   : receives inv(L) as A-fragments (layout of PanelLds::W[s])
 // Leaves the 0-based index of the first non-positive pivot, or -1, in sc.bad.
 struct ChScratch {
-    double U[16][17];   // the tile on entry (row-major, symmetric)
-    double Wt[16][17];  // Wt[t][c] = inv(L)[t][c]
-    double rdiag[16];   // 1 / L[j][j]
-    int bad;            // 0-based index of the first non-positive pivot, or -1
+    double G[16][4];  // G[row][q] = T[row][4 b + q] of the running block
+    int bad;          // 0-based index of the first non-positive pivot, or -1
 };
 
+// 1/sqrt(d) for a wave-uniform positive d: hardware estimate + one third-order correction
+__device__ __forceinline__ double rsqrt_refined(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
 // Not inlined: ONE copy of this long straight-line routine keeps the kernel's code inside the
-// instruction cache (four inlined copies pushed it to 73 KB and every call ran from cold lines).
-// The tile travels by value in registers; the pivot status goes through sc.bad.
+// instruction cache.  The tile travels by value in registers; the pivot status goes through sc.bad.
 __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sc.U[lq + 4 * r][li] = t[r];
-    __builtin_amdgcn_wave_barrier();
-    double a[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = sc.U[li][k];
     int bad = -1;
+    d4 R, u;  // R: running right-hand side of inv(L) (D-form, starts as the identity); u: result
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        double d = lane_bcast(a[j], j);
-        if (!(d > 0.0)) {
-            if (bad < 0) bad = j;
-            d = 1.0;
+    for (int r = 0; r < 4; ++r) R[r] = (lq + 4 * r == li) ? 1.0 : 0.0;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int j0 = 4 * b;
+        // row-owner copy of the block's 4 columns (by symmetry row j0+q of the D-form tile)
+        sc.G[li][lq] = t[b];
+        __builtin_amdgcn_wave_barrier();
+        double c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = sc.G[li][q];
+        __builtin_amdgcn_wave_barrier();
+        double rinv[4], m[4][4];  // wave-uniform: 1 / L[j0+q][j0+q], L[j0+q2][j0+q]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double d = lane_bcast(c[q], j0 + q);
+            if (!(d > 0.0)) {
+                if (bad < 0) bad = j0 + q;
+                d = 1.0;
+            }
+            rinv[q] = rsqrt_refined(d);
+            c[q] *= rinv[q];  // L[li][j0+q] for li >= j0+q (li == j0+q: d / sqrt(d))
+#pragma unroll
+            for (int q2 = q + 1; q2 < 4; ++q2) {
+                m[q2][q] = lane_bcast(c[q], j0 + q2);
+                c[q2] -= c[q] * m[q2][q];
+            }
         }
-        const double rinv = rsqrt(d);
-        if (lane == 0) sc.rdiag[j] = rinv;
-        const double ltj = a[j] * rinv;  // L[li][j] for li >= j (li == j: d / sqrt(d))
-        a[j] = ltj;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) a[c] -= ltj * lane_bcast(ltj, c);
-        __builtin_amdgcn_sched_barrier(0);
+        const double p = lq == 0 ? c[0] : lq == 1 ? c[1] : lq == 2 ? c[2] : c[3];  // L[li][j0+lq]
+        u[b] = (j0 + lq <= li) ? p : 0.0;
+        if (b < 3) t = mfma_f64_negA(p, p, t);  // rows / columns below j0+4: T -= L[:,blk] L[:,blk]^T
+        // column lq of inv(L_bb) by forward substitution on the uniform multipliers: e[k] = M[k][lq]
+        const double e0 = lq == 0 ? rinv[0] : 0.0;
+        const double e1 = (lq == 1 ? rinv[1] : 0.0) - rinv[1] * (m[1][0] * e0);
+        const double e2 = (lq == 2 ? rinv[2] : 0.0) - rinv[2] * (m[2][0] * e0 + m[2][1] * e1);
+        const double e3 = (lq == 3 ? rinv[3] : 0.0) - rinv[3] * (m[3][0] * e0 + m[3][1] * e1 + m[3][2] * e2);
+        const int i = li - j0;
+        const double ma = i == 0 ? e0 : i == 1 ? e1 : i == 2 ? e2 : i == 3 ? e3 : 0.0;  // A: M embedded
+        const d4 wb = mfma_f64(ma, R[b], zero);  // register b = W[j0+lq][li], the others are zero
+        // A-fragment layout of PanelLds::W: wfrag[r*64 + lane'] = W[t = li'][c = 4 r + lq']; the element
+        // (t = j0+lq, c = li) held here lands at 16 li + j0 + lq
+        wfrag[16 * li + j0 + lq] = wb[b];
+        if (b < 3) R = mfma_f64_negA(p, wb[b], R);  // R -= L[:,blk] W[blk,:]
     }
-    // U = L^T in D-form: comp r of lane (lq, li) is U[lq + 4 r][li] = L[li][lq + 4 r]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double v = lq == 0 ? a[4 * r] : lq == 1 ? a[4 * r + 1] : lq == 2 ? a[4 * r + 2] : a[4 * r + 3];
-        t[r] = (lq + 4 * r <= li) ? v : 0.0;
-    }
-    // W = inv(L): lane li computes column li by forward substitution,
-    // W[t][c] = (delta(t,c) - sum_{k<t} L[t][k] W[k][c]) / L[t][t], L[t][k] broadcast from lane t.
-    __builtin_amdgcn_wave_barrier();
-    double w[16];
-#pragma unroll
-    for (int tt = 0; tt < 16; ++tt) {
-        double s = (tt == li) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < tt; ++k) s -= lane_bcast(a[k], tt) * w[k];
-        w[tt] = s * sc.rdiag[tt];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int tt = 0; tt < 16; ++tt)
-        if ((tt >> 2) == lq) sc.Wt[tt][li] = w[tt];  // quarter lq hands over rows 4 lq .. 4 lq + 3
-    __builtin_amdgcn_wave_barrier();
-    // A-fragment layout: wfrag[r*64 + lane] = W[t = li][c = 4 r + lq]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) wfrag[r * 64 + lane] = sc.Wt[li][4 * r + lq];
     if (lane == 0) sc.bad = bad;
-    return t;
+    return u;
 }
 
 // pair index of a strictly-lower tile (u, s), s < u < 4, and of a lower tile incl. diagonal
@@ -196,12 +212,6 @@ struct Slab {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, loff, soff, 0);
     }
 };
-
-// acc -= A * B : the BLGP field of the f64 MFMA is NEG[2:0] (bit 0 negates A; probed on gfx950
-// with tools/mfma_neg_test.hip).
-__device__ __forceinline__ d4 mfma_f64_negA(double a, double b, d4 c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
-}
 
 // D-form tile (rows c0 .. c0+15 of S = panel columns, columns i0 .. i0+15 of S = matrix rows):
 // comp r of lane (lq, li) <-> S[c0 + lq + 4 r][i0 + li].
