@@ -648,24 +648,30 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
         // first written column of each of the block's four row chunks (their envelope)
         const int bks[CT] = {16 * env.ft[4 * panel], 16 * env.ft[4 * panel + 1], 16 * env.ft[4 * panel + 2],
                              16 * env.ft[4 * panel + 3]};
-        // D: the ten lower tiles of the diagonal block
-        d4 t[CT][CT];
+        // D: the ten lower tiles of the diagonal block, and the load column's four tiles (L y = f rides
+        // along as row n_pad: same k range and B-side fragments as the block, which are read once)
+        d4 t[CT][CT], y[CT];
 #pragma unroll
         for (int u = 0; u < CT; ++u)
 #pragma unroll
             for (int s = 0; s <= u; ++s) tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+#pragma unroll
+        for (int s = 0; s < CT; ++s) tile_load(y[s], S, r0 + 16 * s, npad);
         if (r0 > kd) {
             const int step = S.ld * 32;
             int ok = S.at(kd, r0);
-            double fb[DEPTHN][CT];
+            int oy = S.at(kd, npad);
+            double fb[DEPTHN][CT], fy[DEPTHN];
             auto bload = [&](int off, int c, int k) {  // zero where chunk c is left of its envelope
                 const double v = S.load(off + 128 * c);
                 return k >= bks[c] ? v : 0.0;
             };
 #pragma unroll
-            for (int d = 0; d < DEPTHN - 1; ++d)
+            for (int d = 0; d < DEPTHN - 1; ++d) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c) fb[d][c] = bload(ok + d * step, c, kd + 4 * d);
+                fy[d] = S.load(oy + d * step);
+            }
             for (int k0 = kd; k0 < r0; k0 += 4 * DEPTHN) {
 #pragma unroll
                 for (int d = 0; d < DEPTHN; ++d) {
@@ -673,12 +679,16 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
 #pragma unroll
                     for (int c = 0; c < CT; ++c)
                         fb[nd][c] = bload(ok + (d + DEPTHN - 1) * step, c, k0 + 4 * (d + DEPTHN - 1));
+                    fy[nd] = S.load(oy + (d + DEPTHN - 1) * step);
 #pragma unroll
                     for (int u = 0; u < CT; ++u)
 #pragma unroll
                         for (int s = 0; s <= u; ++s) t[u][s] = mfma_f64_negA(fb[d][s], fb[d][u], t[u][s]);
+#pragma unroll
+                    for (int s = 0; s < CT; ++s) y[s] = mfma_f64_negA(fb[d][s], fy[d], y[s]);
                 }
                 ok += DEPTHN * step;
+                oy += DEPTHN * step;
             }
         }
         // F: factor the block in registers
@@ -717,14 +727,26 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
         for (int u = 0; u < CT; ++u)
 #pragma unroll
             for (int s = 0; s <= u; ++s) tile_store(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
-        // items: the chunks below the block that reach into this panel, then the load column
+        // the load column against the factored block: y_s = inv(L_ss) (y_s - sum_{s'<s} L_{s,s'} y_s')
+#pragma unroll
+        for (int s = 0; s < CT; ++s) {
+            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x = mfma_f64(W[s][r], y[s][r], x);
+            y[s] = x;
+#pragma unroll
+            for (int s2 = s + 1; s2 < CT; ++s2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[s2] = mfma_f64_negA(t[s2][s][r], y[s][r], y[s2]);
+            tile_store(y[s], S, r0 + 16 * s, npad);
+        }
+        // items: the chunks below the block that reach into this panel
         const int lastq = env.last[panel];
         for (int c0 = 4 * panel + CT; c0 <= lastq; c0 += RSN) {
             const int ks = 16 * env.ft[c0];
             if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1), false>(S, r0, c0 * 16, ks, bks, W, t);
             else narrow_item<1, false>(S, r0, c0 * 16, ks, bks, W, t);
         }
-        narrow_item<1, true>(S, r0, npad, kd, bks, W, t);  // L y = f rides along: row n_pad
         // this wave's stores must have landed before its own loads of the next panel
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
