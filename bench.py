@@ -37,14 +37,14 @@ def load_case(name):
         return json.load(fh)
 
 
-def algorithmic_counts(n, nJ, nM, env_last=None, slack=3):
-    """Per-truss algorithmic work (DESIGN.md section 'Kernels').  With an envelope only the row
-    tiles up to chunk last[panel] + 3 are written / read (csrc/trs_common.h)."""
+def algorithmic_counts(n, nJ, nM, env_cend=None):
+    """Per-truss algorithmic work (DESIGN.md section 'Kernels').  With an envelope only the tiles
+    t .. cend[t]-1 of the rows of chunk t are written / read (csrc/trs_common.h)."""
     npad = (n + 63) // 64 * 64
     nch = npad // 16
     inputs = 8 * nM + 16 * nM + 24 * nJ + nJ + 24 * nJ
     # upper part by 16-row tiles incl. diagonal tiles, + rhs column chunk (16 wide)
-    row_end = (lambda c: npad) if env_last is None else (lambda c: 16 * min(nch, int(env_last[c // 64]) + 1 + slack))
+    row_end = (lambda c: npad) if env_cend is None else (lambda c: 16 * int(env_cend[c // 16]))
     upper = sum((row_end(c) + 16 - (c // 16) * 16) for c in range(npad)) * 8
     return {
         "potrf_flops": n ** 3 / 3.0 + n ** 2,           # factor + fused forward substitution
@@ -199,7 +199,8 @@ def main():
             narrow = slack == 1   # the kernel choice recorded by trs_assemble (csrc/trs_common.h)
             potrf_kernel = "trs_potrf_narrow_kernel" if narrow else "trs_potrf_kernel"
             tile_flops = potrf_tile_flops(n, env_ft, env_last, rs=2 if narrow else 4)
-            counts = algorithmic_counts(n, nJ, nM, env_last, slack)
+            env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nchm]
+            counts = algorithmic_counts(n, nJ, nM, env_cend)
         else:
             tile_flops = potrf_tile_flops(n)
             counts = algorithmic_counts(n, nJ, nM)

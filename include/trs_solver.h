@@ -62,8 +62,8 @@ int trs_dofmap(int B, int nJ_max, const uint8_t *cbits, const int32_t *nJ,
 
 /* Envelope metadata (optional; pass NULL everywhere to treat every matrix as dense).
  * trs_assemble derives, per truss, the row envelope of the reduced stiffness matrix at 16-row
- * granularity (first tile per row chunk, last row chunk per 64-column panel; layout in
- * csrc/trs_common.h) and writes only the slab tiles inside it; trs_potrf_batched and
+ * granularity (first tile per row chunk, last row chunk per 64-column panel, stored extent per
+ * 16-row chunk; layout in csrc/trs_common.h) and writes only the slab tiles inside it; trs_potrf_batched and
  * trs_potrs_batched skip the tiles outside it, which are exact zeros of the Cholesky factor.
  * `env` is an int32 array of B * trs_env_ints(n_max) entries. */
 int trs_env_ints(int n_max);

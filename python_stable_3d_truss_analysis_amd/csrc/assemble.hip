@@ -43,8 +43,7 @@ __host__ __device__ inline AsmLds asm_lds_layout(int nJ_max, int nM_max, int n_p
     l.rhs = l.diag + (size_t)nJ_max * 48;                        // double[n_pad_max]
     l.tile = l.rhs + (size_t)n_pad_max * 8;                      // double[TR][WT + 16]
     l.ints = l.tile + (size_t)TR * (WT + 16) * 8;
-    const size_t nints = (size_t)6 * nJ_max + 1 + 2 * (size_t)nM_max + n_pad_max / 16 +
-                         n_pad_max / 64 + n_pad_max + 4;
+    const size_t nints = (size_t)6 * nJ_max + 1 + 2 * (size_t)nM_max + 2 * (n_pad_max / 16) + n_pad_max;
     l.total = (l.ints + nints * 4 + 15) / 16 * 16;
     return l;
 }
@@ -84,9 +83,8 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     int* fill = start + nJ_max + 1;                                  // [nJ_max]   fill cursor
     int* adj = fill + nJ_max;                                        // [2 nM_max] (other << 16) | member
     int* chunkmin = adj + 2 * nM_max;                                // [n_pad_max/16] first tile per chunk
-    int* lastl = chunkmin + n_pad_max / 16;                          // [n_pad_max/64] envelope: last chunk
-    int* rowdof = lastl + n_pad_max / 64;                            // [n_pad_max] DOF of a reduced row
-    int* misc = rowdof + n_pad_max;                                  // [4] envelope slack
+    int* cendl = chunkmin + n_pad_max / 16;                          // [n_pad_max/16] envelope: stored extent
+    int* rowdof = cendl + n_pad_max / 16;                            // [n_pad_max] DOF of a reduced row
 
     // ---- phase 0 ---------------------------------------------------------------------------------------
     const double* X = xyz + (size_t)b * 3 * nJ_max;
@@ -186,13 +184,14 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     __syncthreads();
     const bool full = (flags & TRS_ASM_FULL_SYMMETRIC) != 0;
     const bool has_env = env_all != nullptr;
-    int slack = 0;
     if (has_env) {
-        // envelope metadata (trs_common.h): monotone first-tile per chunk, last chunk per panel
+        // envelope metadata (trs_common.h): monotone first tile per chunk, last chunk per panel,
+        // stored extent per chunk
         if (tid == 0) {
             int* env = env_all + (size_t)b * trs_env_stride(n_pad_max);
             int* ft = env;
             int* last = env + n_pad_max / 16;
+            int* cend = env + trs_env_cend_offset(n_pad_max);
             int running = nch;
             for (int q = nch - 1; q >= 0; --q) {
                 running = min(running, chunkmin[q]);
@@ -200,19 +199,24 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 chunkmin[q] = running;
             }
             int q = 0, widest = 0;
-            for (int j = 0; j < nch / 4; ++j) {
-                while (q + 1 < nch && chunkmin[q + 1] <= 4 * j + 3) ++q;
-                last[j] = q;
-                lastl[j] = q;
-                widest = max(widest, q - (4 * j + 3));
+            for (int t = 0; t < nch; ++t) {  // lastc[t] = last chunk q with ft[q] <= t
+                while (q + 1 < nch && chunkmin[q + 1] <= t) ++q;
+                cendl[t] = q;
+                if ((t & 3) == 3) {
+                    last[t >> 2] = q;
+                    widest = max(widest, q - t);
+                }
             }
-            // which factorisation kernel will take this matrix decides the item size, hence the slack
-            const int sl = (widest <= TRS_NARROW_MAX_BELOW ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1;
-            env[n_pad_max / 16 + n_pad_max / 64] = sl;
-            misc[0] = sl;
+            // which factorisation kernel will take this matrix decides the shape of the stored part
+            const bool narrow = widest <= TRS_NARROW_MAX_BELOW;
+            env[n_pad_max / 16 + n_pad_max / 64] = (narrow ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1;
+            for (int t = 0; t < nch; ++t) {
+                const int e = narrow ? max(cendl[t] + 1, (t | 3) + 1) : cendl[t | 3] + 1 + (TRS_WIDE_ITEM - 1);
+                cendl[t] = min(nch, e);
+                cend[t] = cendl[t];
+            }
         }
         __syncthreads();
-        slack = misc[0];
     }
 
     // ---- phase 1 ---------------------------------------------------------------------------------------
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         // stored part of these rows: columns [i_lo, i_hi) (diagonal tile .. end of the envelope of
         // the panel the rows belong to); the 16-wide load-column chunk rides with the last segment
         const int i_lo = full ? 0 : (c0 & ~15);
-        const int i_hi = (has_env && !full) ? 16 * min(nch, lastl[c0 / TRS_NB] + 1 + slack) : npad;
+        const int i_hi = (has_env && !full) ? 16 * cendl[c0 / 16] : npad;
         for (int seg_lo = i_lo; seg_lo < i_hi; seg_lo += WT) {
             const int seg_hi = min(i_hi, seg_lo + WT);
             const int Ws = seg_hi - seg_lo;  // multiple of 16

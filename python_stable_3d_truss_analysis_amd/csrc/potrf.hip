@@ -211,6 +211,17 @@ struct Slab {
     __device__ __forceinline__ void store(int soff, double v) const {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, loff, soff, 0);
     }
+    // Tiles outside the stored envelope are skipped WITHOUT branches: the buffer range check is on
+    // the VGPR offset, so an access with lane offset `gone` returns 0 / is dropped and makes no
+    // memory traffic (probed with tools/buffer_oob_test.hip).
+    static constexpr unsigned gone = 0x80000000u;
+    __device__ __forceinline__ unsigned lane_off(bool exists) const { return exists ? loff : gone; }
+    __device__ __forceinline__ double load_at(unsigned voff, int soff) const {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+    }
+    __device__ __forceinline__ void store_at(unsigned voff, int soff, double v) const {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
+    }
 };
 
 // D-form tile (rows c0 .. c0+15 of S = panel columns, columns i0 .. i0+15 of S = matrix rows):
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
     S.loff = ((unsigned)(lane >> 4) * (unsigned)ld + (unsigned)(lane & 15)) * 8u;
     const int nch = npad / 16;  // row chunks of the matrix; the right-hand side is one more, at row n_pad
     const bool has_env = env_all != nullptr;
-    const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr, 0};
+    const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr, nullptr, 0};
     if (has_env && trs_env_is_narrow(env)) return;  // trs_potrf_narrow_kernel's matrix
 
     Stamps st;
@@ -552,41 +563,57 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
 constexpr int RSN = TRS_NARROW_RS;      // row chunks per item in the narrow kernel (1 or 2)
 constexpr int DEPTHN = TRS_NARROW_DEPTH;  // k-steps of fragments in flight (divides 4 k-steps = 16 columns)
 
-// MASKB: the panel's own rows (B side) are read from column kstart on, but block chunk s is only
-// written from column bks[s] on (its envelope): earlier values are replaced by the zeros they stand for.
-template <int NV, bool MASKB>
-__device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const int rowbase, const int kstart,
-                                            const int (&bks)[CT], const d4 (&W)[CT], const d4 (&t)[CT][CT]) {
+// One item of the narrow kernel: NV row chunks c0, c0+1 below the diagonal block of panel r0 / 64.
+// Tile (chunk q, column tile tt) is stored iff q < cend[tt] (trs_common.h); what is not stored is an
+// exact zero of L: its loads return 0 and its stores are dropped through the lane offset.
+//   kstart = 16 ft[c0]: first column of chunk c0's envelope; chunk c0+1 may start later (ft1).
+template <int NV>
+__device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const int c0, const int kstart,
+                                            const int ft1, const int* __restrict__ cend,
+                                            const d4 (&W)[CT], const d4 (&t)[CT][CT]) {
+    const int rowbase = 16 * c0;
     d4 acc[NV][CT];
+    unsigned vo[NV][CT];
+#pragma unroll
+    for (int s = 0; s < CT; ++s) {
+        const int ce = cend[r0 / 16 + s];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) vo[v][s] = S.lane_off(c0 + v < ce);
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int s = 0; s < CT; ++s) tile_load(acc[v][s], S, r0 + 16 * s, rowbase + 16 * v);
+        for (int s = 0; s < CT; ++s) {
+            const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[v][s][r] = S.load_at(vo[v][s], o + r * (S.ld * 32));
+        }
     if (r0 > kstart) {
         int ob = S.at(kstart, r0);
         int oa = S.at(kstart, rowbase);
         const int step = S.ld * 32;
         double fb[DEPTHN][CT], fa[DEPTHN][NV];
-        auto bload = [&](int off, int s, int k) {  // fragment of block chunk s at rows k .. k+3 of S
-            const double v = S.load(off + 128 * s);
-            return (!MASKB || k >= bks[s]) ? v : 0.0;
+        // chunk c0's rows exist from kstart on, and so do the block's (ft is non-decreasing); chunk
+        // c0+1 only from column 16 ft1 on
+        auto aload = [&](int off, int v, int k) {
+            return S.load_at(S.lane_off(v == 0 || k >= 16 * ft1), off + 128 * v);
         };
 #pragma unroll
         for (int d = 0; d < DEPTHN - 1; ++d) {
 #pragma unroll
-            for (int s = 0; s < CT; ++s) fb[d][s] = bload(ob + d * step, s, kstart + 4 * d);
+            for (int s = 0; s < CT; ++s) fb[d][s] = S.load(ob + d * step + 128 * s);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) fa[d][v] = S.load(oa + d * step + 128 * v);
+            for (int v = 0; v < NV; ++v) fa[d][v] = aload(oa + d * step, v, kstart + 4 * d);
         }
         for (int k0 = kstart; k0 < r0; k0 += 4 * DEPTHN) {
 #pragma unroll
             for (int d = 0; d < DEPTHN; ++d) {
                 const int nd = (d + DEPTHN - 1) % DEPTHN;
 #pragma unroll
-                for (int s = 0; s < CT; ++s)
-                    fb[nd][s] = bload(ob + (d + DEPTHN - 1) * step, s, k0 + 4 * (d + DEPTHN - 1));
+                for (int s = 0; s < CT; ++s) fb[nd][s] = S.load(ob + (d + DEPTHN - 1) * step + 128 * s);
 #pragma unroll
-                for (int v = 0; v < NV; ++v) fa[nd][v] = S.load(oa + (d + DEPTHN - 1) * step + 128 * v);
+                for (int v = 0; v < NV; ++v)
+                    fa[nd][v] = aload(oa + (d + DEPTHN - 1) * step, v, k0 + 4 * (d + DEPTHN - 1));
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -615,7 +642,11 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int s = 0; s < CT; ++s) tile_store(acc[v][s], S, r0 + 16 * s, rowbase + 16 * v);
+        for (int s = 0; s < CT; ++s) {
+            const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S.store_at(vo[v][s], o + r * (S.ld * 32), acc[v][s][r]);
+        }
 }
 
 __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narrow_kernel(
@@ -663,8 +694,7 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
             int oy = S.at(kd, npad);
             double fb[DEPTHN][CT], fy[DEPTHN];
             auto bload = [&](int off, int c, int k) {  // zero where chunk c is left of its envelope
-                const double v = S.load(off + 128 * c);
-                return k >= bks[c] ? v : 0.0;
+                return S.load_at(S.lane_off(k >= bks[c]), off + 128 * c);
             };
 #pragma unroll
             for (int d = 0; d < DEPTHN - 1; ++d) {
@@ -744,8 +774,8 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
         const int lastq = env.last[panel];
         for (int c0 = 4 * panel + CT; c0 <= lastq; c0 += RSN) {
             const int ks = 16 * env.ft[c0];
-            if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1), false>(S, r0, c0 * 16, ks, bks, W, t);
-            else narrow_item<1, false>(S, r0, c0 * 16, ks, bks, W, t);
+            if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1)>(S, r0, c0, ks, env.ft[c0 + 1], env.cend, W, t);
+            else narrow_item<1>(S, r0, c0, ks, 0, env.cend, W, t);
         }
         // this wave's stores must have landed before its own loads of the next panel
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

@@ -48,11 +48,10 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
     const int wrow = 16 * wave + 4 * g;  // first of this lane's four rows inside the block
 
     const int nch = npad / 16;
-    const TrsEnv env = env_all != nullptr ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr, 0};
-    // columns beyond the envelope of a 64-row block are exact zeros of U (and were never written)
-    auto block_col_end = [&](int cb) {
-        return env_all != nullptr ? 16 * trs_env_row_end(env, cb / BS, nch) : npad;
-    };
+    const TrsEnv env = env_all != nullptr ? trs_env_of(env_all, b, n_pad_max)
+                                           : TrsEnv{nullptr, nullptr, nullptr, 0};
+    // columns beyond the stored extent of a wave's 16 rows are exact zeros of U (and were never written)
+    auto block_col_end = [&](int cb) { return env_all != nullptr ? 16 * env.cend[cb / 16 + wave] : npad; };
 
     // Everything a block needs from HBM is requested ONE BLOCK AHEAD, before the previous block's
     // triangle solve: its diagonal 64 x 64 part, its load-column entries and the first PF 64-column

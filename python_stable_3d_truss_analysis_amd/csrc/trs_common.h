@@ -33,15 +33,19 @@ __device__ static inline double readlane_f64(double v) {
 // tiles of the padded system (nch = n_pad / 16):
 //   ft[q]   q < nch : first tile of row chunk q that can hold a non-zero of L (row envelope of the
 //                     lower triangle), made non-decreasing in q (running minimum from the end), so
-//                     that the set of chunks reaching into a panel is a contiguous range;
+//                     that the set of chunks reaching into a column tile is a contiguous range;
 //   last[j] j < nch/4: last row chunk q with ft[q] <= 4 j + 3, i.e. the last chunk with any non-zero
-//                     in the 64 columns of panel j (>= 4 j + 3).
-// Cholesky fill stays inside the row envelope, so tiles outside it are exact zeros and are skipped:
-//   slack           : how many chunks past last[j] the row tiles of panel j are written: the
-//                     factorisation works on items of `slack + 1` consecutive chunks whose tail may
-//                     overhang the envelope (1 for matrices that go to the wave-per-matrix kernel,
-//                     3 for the work-group kernel; see TRS_NARROW_MAX_BELOW).
-// trs_assemble writes row tiles of panel j only up to chunk last[j] + slack, plus the load column.
+//                     in the 64 columns of panel j (>= 4 j + 3);
+//   slack           : which factorisation kernel takes the matrix (trs_env_is_narrow) and, for the
+//                     work-group kernel, how many chunks past last[j] its items may overhang;
+//   cend[t] t < nch : the STORED extent of slab rows 16 t .. 16 t + 15 (column tile t of L): tiles
+//                     t .. cend[t]-1 plus the load column are written by trs_assemble, factored and
+//                     read back; nothing else of those rows is ever touched.
+//                       wave-per-matrix kernel: cend[t] = max(lastc[t] + 1, end of t's diagonal block),
+//                         lastc[t] = last chunk q with ft[q] <= t - the exact envelope at tile
+//                         granularity (tiles outside are skipped with out-of-range buffer offsets);
+//                       work-group kernel:      cend[t] = last[t / 4] + 1 + slack (rectangular per panel).
+// Cholesky fill stays inside the row envelope, so tiles outside it are exact zeros.
 #ifndef TRS_NARROW_MAX_BELOW
 #define TRS_NARROW_MAX_BELOW 12  // widest reach below a diagonal block (chunks) for the narrow kernel
 #endif
@@ -50,17 +54,16 @@ __device__ static inline double readlane_f64(double v) {
 struct TrsEnv {
     const int* ft;
     const int* last;
+    const int* cend;
     int slack;
 };
-__host__ __device__ static inline int trs_env_stride(int n_pad_max) { return n_pad_max / 16 + n_pad_max / 64 + 8; }
+// ints per truss: ft[nch_max] | last[nch_max / 4] | slack + 7 reserved | cend[nch_max]
+__host__ __device__ static inline int trs_env_stride(int n_pad_max) { return 2 * (n_pad_max / 16) + n_pad_max / 64 + 8; }
+__host__ __device__ static inline int trs_env_cend_offset(int n_pad_max) { return n_pad_max / 16 + n_pad_max / 64 + 8; }
 __host__ __device__ static inline TrsEnv trs_env_of(const int* env, int b, int n_pad_max) {
     const int* base = env + (size_t)b * trs_env_stride(n_pad_max);
-    return TrsEnv{base, base + n_pad_max / 16, base[n_pad_max / 16 + n_pad_max / 64]};
-}
-// chunks written / read for the rows of panel j: exclusive upper bound, in chunks
-__host__ __device__ static inline int trs_env_row_end(const TrsEnv& e, int j, int nch) {
-    const int end = e.last[j] + 1 + e.slack;
-    return end < nch ? end : nch;
+    return TrsEnv{base, base + n_pad_max / 16, base + trs_env_cend_offset(n_pad_max),
+                  base[n_pad_max / 16 + n_pad_max / 64]};
 }
 // the matrix goes to the wave-per-matrix kernel (slack == TRS_NARROW_ITEM - 1) or to the
 // work-group kernel

@@ -82,6 +82,16 @@ def test_stages_against_oracle(gpu, name):
     assert (env_ft <= ft).all() and (env_ft <= np.arange(nch)).all() and (np.diff(env_ft) >= 0).all()
     assert (env_last >= np.array(last)).all()
     assert env_last.tolist() == [max(q for q in range(nch) if env_ft[q] <= 4 * j + 3) for j in range(nch // 4)]
+    # stored extent per 16-row chunk (csrc/trs_common.h): exact at tile granularity for the
+    # wave-per-matrix kernel (slack 1), rectangular per panel for the work-group kernel (slack 3)
+    nchm = dev.rows // 16
+    slack = int(env[nchm + dev.rows // 64])
+    env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nch]
+    lastc = [max(q for q in range(nch) if env_ft[q] <= t) for t in range(nch)]
+    if slack == 1:
+        assert env_cend.tolist() == [min(nch, max(lastc[t] + 1, (t | 3) + 1)) for t in range(nch)]
+    else:
+        assert env_cend.tolist() == [min(nch, int(env_last[t // 4]) + 1 + 3) for t in range(nch)]
 
     # --- assemble (production layout: upper part by 16-tiles) -----------------------------------
     dev.S.fill_(float("nan"))
@@ -89,8 +99,7 @@ def test_stages_against_oracle(gpu, name):
     S = dev.S.cpu().numpy()[0]
     for c in (0, n // 2, n - 1):
         lo = c // 16 * 16
-        slack = int(env[dev.rows // 16 + dev.rows // 64])       # 1: wave-per-matrix kernel, 3: work-group kernel
-        hi = min(npad, 16 * (int(env_last[c // 64]) + 1 + slack))   # end of the written part of the row
+        hi = 16 * int(env_cend[c // 16])                        # end of the written part of the row
         assert H.max_scaled_err(S[c, lo:min(hi, n)], ref["K_ff"][c, lo:min(hi, n)]) <= 1e-14
         assert not ref["K_ff"][c, min(hi, n):].any()            # beyond it K is structurally zero
         assert np.isnan(S[c, hi:npad]).all() or hi >= npad      # ... and nothing was written there

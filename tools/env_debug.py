@@ -7,11 +7,11 @@ dev = batch.DeviceBatch(batch.pack_json([data]))
 dev.S.zero_()
 dev.dofmap(); dev.assemble()
 S0 = dev.S.clone(); env = dev.env[0].cpu().numpy()
-nch = 44; ft = env[:nch]; last = env[nch:nch+11]; slack = int(env[nch+11])
+nch = 44; ft = env[:nch]; last = env[nch:nch+11]; slack = int(env[nch+11]); cend = env[nch+11+8:nch+11+8+nch]
 hits = []
 for t in range(12):
     for q in range(t, nch + 1):           # nch = the rhs chunk columns 704..719
-        if q < nch and q < min(nch, last[t//4]+1+slack): continue   # written region
+        if q < nch and q < cend[t]: continue   # written region
         if q == nch: continue
         dev.S.copy_(S0)
         dev.S[0, 16*t:16*t+16, 16*q:16*q+16] = float('nan')
