@@ -185,35 +185,53 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     const bool full = (flags & TRS_ASM_FULL_SYMMETRIC) != 0;
     const bool has_env = env_all != nullptr;
     if (has_env) {
-        // envelope metadata (trs_common.h): monotone first tile per chunk, last chunk per panel,
-        // stored extent per chunk
-        if (tid == 0) {
+        // envelope metadata (trs_common.h), by wave 0 with shuffles (LDS operations of one wave
+        // complete in order, so no barrier is needed between the steps)
+        if (tid < 64) {
             int* env = env_all + (size_t)b * trs_env_stride(n_pad_max);
             int* ft = env;
             int* last = env + n_pad_max / 16;
             int* cend = env + trs_env_cend_offset(n_pad_max);
-            int running = nch;
-            for (int q = nch - 1; q >= 0; --q) {
-                running = min(running, chunkmin[q]);
-                ft[q] = running;
-                chunkmin[q] = running;
-            }
-            int q = 0, widest = 0;
-            for (int t = 0; t < nch; ++t) {  // lastc[t] = last chunk q with ft[q] <= t
-                while (q + 1 < nch && chunkmin[q + 1] <= t) ++q;
-                cendl[t] = q;
-                if ((t & 3) == 3) {
-                    last[t >> 2] = q;
-                    widest = max(widest, q - t);
+            // ft = running minimum of chunkmin from the end, 64 chunks per step
+            int carry = nch;
+            for (int base = (nch - 1) / 64 * 64; base >= 0; base -= 64) {
+                const int q = base + tid;
+                int v = q < nch ? chunkmin[q] : nch;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_down(v, off);
+                    if (tid + off < 64) v = min(v, o);
                 }
+                v = min(v, carry);
+                if (q < nch) {
+                    chunkmin[q] = v;
+                    ft[q] = v;
+                }
+                carry = __shfl(v, 0);
             }
+            __builtin_amdgcn_wave_barrier();
+            // lastc[t] = last chunk q with ft[q] <= t: chunk q owns the tiles ft[q] .. ft[q+1]-1
+            for (int q = tid; q < nch; q += 64) {
+                const int hi = q + 1 < nch ? chunkmin[q + 1] : nch;
+                for (int t = chunkmin[q]; t < hi; ++t) cendl[t] = q;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int widest = 0;
+            for (int j = tid; j < nch / 4; j += 64) {
+                const int l = cendl[4 * j + 3];
+                last[j] = l;
+                widest = max(widest, l - (4 * j + 3));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) widest = max(widest, __shfl_xor(widest, off));
             // which factorisation kernel will take this matrix decides the shape of the stored part
             const bool narrow = widest <= TRS_NARROW_MAX_BELOW;
-            env[n_pad_max / 16 + n_pad_max / 64] = (narrow ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1;
-            for (int t = 0; t < nch; ++t) {
+            if (tid == 0) env[n_pad_max / 16 + n_pad_max / 64] = (narrow ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1;
+            for (int t = tid; t < nch; t += 64) {  // t | 3 lies in the same step: reads precede the writes
                 const int e = narrow ? max(cendl[t] + 1, (t | 3) + 1) : cendl[t | 3] + 1 + (TRS_WIDE_ITEM - 1);
+                __builtin_amdgcn_wave_barrier();
                 cendl[t] = min(nch, e);
-                cend[t] = cendl[t];
+                cend[t] = min(nch, e);
             }
         }
         __syncthreads();
