@@ -28,7 +28,11 @@ namespace {
 #define TRS_ASM_THREADS 512
 #endif
 constexpr int NT = TRS_ASM_THREADS;  // threads per work-group
-constexpr int TPR = 32;              // threads per slab row (two rows per wave)
+#ifndef TRS_ASM_TPR
+#define TRS_ASM_TPR 16
+#endif
+constexpr int TPR = TRS_ASM_TPR;     // threads per slab row (64 / TPR rows per wave)
+static_assert(64 % TPR == 0 && 16 % (64 / TPR) == 0, "a wave's rows must lie in one 16-row chunk");
 constexpr int TR = NT / TPR;         // slab rows per block
 
 // LDS carve-up shared by host and device (bytes, every part 16-byte aligned)
@@ -75,7 +79,9 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         mk = reinterpret_cast<double*>(work_all + (size_t)b * work_stride);
     double* mc = mk + nM_max;                                        // [nM_max][3] direction cosines
     double* diag = reinterpret_cast<double*>(lds_raw + lay.diag);    // diagonal 3x3 block per joint
-    double* rhs = reinterpret_cast<double*>(lds_raw + lay.rhs);      // reduced load vector
+    double* rhs = reinterpret_cast<double*>(lds_raw + lay.rhs);      // reduced load vector (a global load
+                                                                     // in the row loop would have to wait
+                                                                     // for the stores queued before it)
     double* T = reinterpret_cast<double*>(lds_raw + lay.tile);       // row tile
     int* fi = reinterpret_cast<int*>(lds_raw + lay.ints);            // [3 nJ_max] free index per DOF
     int* cnt = fi + 3 * nJ_max;                                      // [nJ_max]   joint degree
@@ -290,8 +296,9 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     for (int c0 = 0; c0 < npad; c0 += TR) {
         // stored part of these rows: columns [i_lo, i_hi) (diagonal tile .. end of the envelope of
         // the panel the rows belong to); the 16-wide load-column chunk rides with the last segment
-        const int i_lo = full ? 0 : (c0 & ~15);
-        const int i_hi = (has_env && !full) ? 16 * cendl[c0 / 16] : npad;
+        const int chunk = __builtin_amdgcn_readfirstlane(c0 + rr) >> 4;  // of this wave's rows
+        const int i_lo = full ? 0 : 16 * chunk;
+        const int i_hi = (has_env && !full) ? 16 * cendl[chunk] : npad;
         for (int seg_lo = i_lo; seg_lo < i_hi; seg_lo += WT) {
             const int seg_hi = min(i_hi, seg_lo + WT);
             const int Ws = seg_hi - seg_lo;  // multiple of 16
@@ -351,7 +358,7 @@ inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
     for (size_t budget : budgets) {
         for (int g = 1; g >= 0; --g) {
             const size_t fixed = asm_lds_layout(nJ_max, nM_max, n_pad_max, -16, g).total;
-            if (fixed + (size_t)TR * (64 + 16) * 8 > budget) continue;
+            if (fixed + (size_t)TR * (32 + 16) * 8 > budget) continue;
             int WT = (int)((budget - fixed) / (TR * 8)) - 16;
             WT = WT / 16 * 16;
             if (WT > n_pad_max) WT = n_pad_max;

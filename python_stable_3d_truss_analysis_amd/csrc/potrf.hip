@@ -553,7 +553,9 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
 // the scratch of the scalar 16x16 factorisation.  Same arithmetic, same order of operations per
 // tile as the work-group kernel except that the diagonal-block update is not split in two halves.
 // ======================================================================================================
+#ifndef TRS_NARROW_RS
 #define TRS_NARROW_RS TRS_NARROW_ITEM
+#endif
 #ifndef TRS_NARROW_DEPTH
 #define TRS_NARROW_DEPTH 4
 #endif
