@@ -557,7 +557,7 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
 #define TRS_NARROW_RS TRS_NARROW_ITEM
 #endif
 #ifndef TRS_NARROW_DEPTH
-#define TRS_NARROW_DEPTH 4
+#define TRS_NARROW_DEPTH 2
 #endif
 #ifndef TRS_NARROW_WAVES_PER_SIMD
 #define TRS_NARROW_WAVES_PER_SIMD 2
@@ -572,8 +572,8 @@ constexpr int DEPTHN = TRS_NARROW_DEPTH;  // k-steps of fragments in flight (div
 template <int NV>
 __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const int c0, const int kstart,
                                             const int ft1, const int* __restrict__ cend,
-                                            const d4 (&W)[CT], const d4 (&t)[CT][CT]) {
-    const int rowbase = 16 * c0;
+                                            const double* Wl, const d4 (&t)[CT][CT]) {
+    const int rowbase = 16 * c0, lane = threadIdx.x & 63;
     d4 acc[NV][CT];
     unsigned vo[NV][CT];
 #pragma unroll
@@ -631,7 +631,7 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
         for (int v = 0; v < NV; ++v) {  // X_s^T = inv(L_ss) T_s^T
             d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x = mfma_f64(W[s][r], acc[v][s][r], x);
+            for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + r * 64 + lane], acc[v][s][r], x);
             acc[v][s] = x;
         }
 #pragma unroll
@@ -655,7 +655,9 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
     int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max, const int B) {
     __shared__ ChScratch scratch[4];
-    __shared__ double wtmp[4][256];
+    __shared__ double wlds[4][CT][256];  // per wave: inv(L_ss), s = 0..3, as A-fragments (PanelLds::W layout)
+    __shared__ double ylds[4][CT][4][4];  // per wave: the load column (lanes li == 0 of its tiles), parked
+                                          // during the factorisation
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wave;
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
     S.ld = ld;
     S.loff = ((unsigned)(lane >> 4) * (unsigned)ld + (unsigned)(lane & 15)) * 8u;
     ChScratch& sc = scratch[wave];
-    double* wfrag = wtmp[wave];
+    double* Wl = &wlds[wave][0][0];
     int bad_col = 0;
 
     for (int r0 = 0, panel = 0; r0 < npad && bad_col == 0; r0 += TRS_NB, ++panel) {
@@ -723,26 +725,33 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
                 oy += DEPTHN * step;
             }
         }
-        // F: factor the block in registers
-        d4 W[CT];
+        // the load column's tiles wait in LDS while the block is factored (32 VGPRs less at the peak)
+#pragma unroll
+        for (int s = 0; s < CT; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)  // only column 0 of the 16-wide load chunk is not zero
+                if ((lane & 15) == 0) ylds[wave][s][r][lane >> 4] = y[s][r];
+        // F: factor the block in registers; inv(L_ss) stays in LDS (operand fragments, read where used)
 #pragma unroll
         for (int s = 0; s < CT; ++s) {
             if (bad_col == 0) {
-                t[s][s] = chol16_invert(t[s][s], sc, wfrag);
+                t[s][s] = chol16_invert(t[s][s], sc, Wl + s * 256);
                 __builtin_amdgcn_wave_barrier();
                 const int bad = sc.bad;
                 if (bad >= 0) bad_col = r0 + 16 * s + bad + 1;
             }
             if (bad_col == 0) {
+                if (s + 1 < CT) {
+                    double wf[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) W[s][r] = wfrag[r * 64 + lane];
-                __builtin_amdgcn_wave_barrier();
+                    for (int r = 0; r < 4; ++r) wf[r] = Wl[s * 256 + r * 64 + lane];
 #pragma unroll
-                for (int u = s + 1; u < CT; ++u) {
-                    d4 x = d4{0.0, 0.0, 0.0, 0.0};
+                    for (int u = s + 1; u < CT; ++u) {
+                        d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x = mfma_f64(W[s][r], t[u][s][r], x);
-                    t[u][s] = x;
+                        for (int r = 0; r < 4; ++r) x = mfma_f64(wf[r], t[u][s][r], x);
+                        t[u][s] = x;
+                    }
                 }
 #pragma unroll
                 for (int u = s + 1; u < CT; ++u)
@@ -750,8 +759,6 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
                     for (int s2 = s + 1; s2 <= u; ++s2)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) t[u][s2] = mfma_f64_negA(t[s2][s][r], t[u][s][r], t[u][s2]);
-            } else {
-                W[s] = d4{0.0, 0.0, 0.0, 0.0};
             }
         }
         if (bad_col != 0) break;
@@ -761,10 +768,14 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
             for (int s = 0; s <= u; ++s) tile_store(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
         // the load column against the factored block: y_s = inv(L_ss) (y_s - sum_{s'<s} L_{s,s'} y_s')
 #pragma unroll
+        for (int s = 0; s < CT; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[s][r] = (lane & 15) == 0 ? ylds[wave][s][r][lane >> 4] : 0.0;
+#pragma unroll
         for (int s = 0; s < CT; ++s) {
             d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x = mfma_f64(W[s][r], y[s][r], x);
+            for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + r * 64 + lane], y[s][r], x);
             y[s] = x;
 #pragma unroll
             for (int s2 = s + 1; s2 < CT; ++s2)
@@ -776,8 +787,8 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
         const int lastq = env.last[panel];
         for (int c0 = 4 * panel + CT; c0 <= lastq; c0 += RSN) {
             const int ks = 16 * env.ft[c0];
-            if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1)>(S, r0, c0, ks, env.ft[c0 + 1], env.cend, W, t);
-            else narrow_item<1>(S, r0, c0, ks, 0, env.cend, W, t);
+            if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1)>(S, r0, c0, ks, env.ft[c0 + 1], env.cend, Wl, t);
+            else narrow_item<1>(S, r0, c0, ks, 0, env.cend, Wl, t);
         }
         // this wave's stores must have landed before its own loads of the next panel
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
