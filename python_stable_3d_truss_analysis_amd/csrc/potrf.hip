@@ -46,12 +46,15 @@ struct Stamps {
         if ((threadIdx.x & 63) == 0)
             for (int i = 0; i < 8; ++i) atomicAdd(&g_trs_stamps[i], acc[i]);
     }
+    // attribute memory waits to the phase that issued the accesses
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 };
 #else
 struct Stamps {
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void flush() {}
+    __device__ __forceinline__ void drain() {}
 };
 #endif
 
@@ -98,7 +101,8 @@ __device__ __forceinline__ d4 mfma_f64_negA(double a, double b, d4 c) {
 //     D-form right-hand side as B, and one MFMA (A = p, B = the new W rows) to update the latter.
 // VALU work per tile drops from ~1150 to ~450 instructions; 11 dependent MFMAs replace the rest.
 //   t       : in  the symmetric tile in D-form (t[r] = T[c = lq + 4 r][i = li]);
-//             out U = L^T in D-form with exact zeros below the diagonal
+//             out U = L^T in D-form on and above the diagonal, the strictly-lower part of inv(L)
+//             below it (read by trs_potrs_kernel; no other reader touches that part)
 //   sc      : LDS scratch (block gather)
 //   wfrag   : receives inv(L) as A-fragments (layout of PanelLds::W[s])
 // Leaves the 0-based index of the first non-positive pivot, or -1, in sc.bad.
@@ -150,7 +154,6 @@ __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
             }
         }
         const double p = lq == 0 ? c[0] : lq == 1 ? c[1] : lq == 2 ? c[2] : c[3];  // L[li][j0+lq]
-        u[b] = (j0 + lq <= li) ? p : 0.0;
         if (b < 3) t = mfma_f64_negA(p, p, t);  // rows / columns below j0+4: T -= L[:,blk] L[:,blk]^T
         // column lq of inv(L_bb) by forward substitution on the uniform multipliers: e[k] = M[k][lq]
         const double e0 = lq == 0 ? rinv[0] : 0.0;
@@ -163,6 +166,9 @@ __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
         // A-fragment layout of PanelLds::W: wfrag[r*64 + lane'] = W[t = li'][c = 4 r + lq']; the element
         // (t = j0+lq, c = li) held here lands at 16 li + j0 + lq
         wfrag[16 * li + j0 + lq] = wb[b];
+        // result tile: U on and above the diagonal; the otherwise unused strictly-lower part carries
+        // inv(L) (its diagonal is 1 / diag(U)) for the 16 x 16 steps of the back substitution
+        u[b] = (j0 + lq <= li) ? p : wb[b];
         if (b < 3) R = mfma_f64_negA(p, wb[b], R);  // R -= L[:,blk] W[blk,:]
     }
     if (lane == 0) sc.bad = bad;
@@ -677,6 +683,8 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
     ChScratch& sc = scratch[wave];
     double* Wl = &wlds[wave][0][0];
     int bad_col = 0;
+    Stamps st;  // 0 tile loads, 1 block update, 2 factorisation, 3 load column + block stores, 4 items, 5 fence
+    st.start();
 
     for (int r0 = 0, panel = 0; r0 < npad && bad_col == 0; r0 += TRS_NB, ++panel) {
         const int kd = 16 * env.ft[4 * panel];
@@ -692,6 +700,8 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
             for (int s = 0; s <= u; ++s) tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
 #pragma unroll
         for (int s = 0; s < CT; ++s) tile_load(y[s], S, r0 + 16 * s, npad);
+        st.drain();
+        st.mark(0);
         if (r0 > kd) {
             const int step = S.ld * 32;
             int ok = S.at(kd, r0);
@@ -725,6 +735,7 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
                 oy += DEPTHN * step;
             }
         }
+        st.mark(1);
         // the load column's tiles wait in LDS while the block is factored (32 VGPRs less at the peak)
 #pragma unroll
         for (int s = 0; s < CT; ++s)
@@ -761,6 +772,7 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
                         for (int r = 0; r < 4; ++r) t[u][s2] = mfma_f64_negA(t[s2][s][r], t[u][s][r], t[u][s2]);
             }
         }
+        st.mark(2);
         if (bad_col != 0) break;
 #pragma unroll
         for (int u = 0; u < CT; ++u)
@@ -783,6 +795,7 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
                 for (int r = 0; r < 4; ++r) y[s2] = mfma_f64_negA(t[s2][s][r], y[s][r], y[s2]);
             tile_store(y[s], S, r0 + 16 * s, npad);
         }
+        st.mark(3);
         // items: the chunks below the block that reach into this panel
         const int lastq = env.last[panel];
         for (int c0 = 4 * panel + CT; c0 <= lastq; c0 += RSN) {
@@ -790,9 +803,12 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
             if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1)>(S, r0, c0, ks, env.ft[c0 + 1], env.cend, Wl, t);
             else narrow_item<1>(S, r0, c0, ks, 0, env.cend, Wl, t);
         }
+        st.mark(4);
         // this wave's stores must have landed before its own loads of the next panel
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        st.mark(5);
     }
+    st.flush();
     if (lane == 0) info[b] = bad_col;
 }
 

@@ -28,6 +28,9 @@ __device__ __forceinline__ double lane_bcast_dyn(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// TILESTEP selects the form of the 64 x 64 triangle solve at compile time (one form per
+// instantiation keeps the kernel inside 128 VGPRs): true for the envelope mode, false for dense.
+template <bool TILESTEP>
 __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kernel(const double* __restrict__ S_all,
                                                         const int* __restrict__ n_free, const int ld,
                                                         const size_t slab_stride,
@@ -121,10 +124,45 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
         }
         if (cb >= BS) request(cb - BS);  // in flight during the triangle solve
         __syncthreads();
-        if (wave == 0) {
-            // back substitution inside the 64 x 64 triangle: lane c owns the running right-hand side
-            // of row c; the pivot row's value is broadcast with v_readlane (uniform lane index), the
-            // reciprocals of the diagonal are formed once, in parallel
+        if (wave == 0 && TILESTEP) {
+            // Back substitution inside the 64 x 64 triangle in four 16 x 16 steps.  trs_potrf left the
+            // strictly-lower part of inv(L_ss) below the diagonal of every diagonal tile, so a step is
+            // u_s = inv(L_ss)^T t_s (a 16 x 16 product spread over the four quarter-waves) followed by
+            // t -= U[:, s] u_s for the rows above (lane = row, u_s broadcast with v_readlane).
+            double tr = tb[lane];  // running right-hand side of row `lane`
+            const double rdiag = 1.0 / Ub[lane * (BS + 1) + lane];
+#pragma unroll
+            for (int s = 3; s >= 0; --s) {
+                if ((lane >> 4) == s) tb[lane] = tr;  // t_s, final
+                __builtin_amdgcn_wave_barrier();
+                // lane (g, l): sum over j = 4 g .. 4 g + 3 of inv(L_ss)[j][l] t_s[j]
+                double part = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = 4 * g + jj;
+                    const double tj = tb[16 * s + j];
+                    const double w = Ub[(16 * s + j) * (BS + 1) + 16 * s + l];
+                    part += (j > l ? w : 0.0) * tj;
+                }
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                // diagonal term 1 / U[l][l] t_s[l]: the value sits in lane 16 s + l
+                const double dterm = __shfl(tr * rdiag, 16 * s + l);
+                const double usl = part + dterm;  // u_s[l], the same in all four quarter-waves
+                if (g == 0) us[cb + 16 * s + l] = usl;
+                if (s > 0) {
+#pragma unroll
+                    for (int l2 = 0; l2 < 16; ++l2) {
+                        const double ul = lane_bcast_dyn(usl, l2);
+                        if (lane < 16 * s) tr -= Ub[lane * (BS + 1) + 16 * s + l2] * ul;
+                    }
+                }
+            }
+        } else if (wave == 0) {
+            // Dense mode: the plain 64-step substitution - lane c owns the running right-hand side of
+            // row c, the pivot row's value is broadcast with v_readlane.  Next to three other
+            // work-groups streaming U through the same CU its VALU chain hides completely, which the
+            // LDS-heavier tile-step form above does not (measured 1.42 vs 1.78 ms per 4096).
             double tc = tb[lane], mine = 0.0;
             const double rinv = 1.0 / Ub[lane * (BS + 1) + lane];
 #pragma unroll 8
@@ -149,10 +187,17 @@ extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_st
     if (B <= 0 || n_pad_max <= 0) return 0;
     const size_t lds = (size_t)(n_pad_max + BS * (BS + 1) + BS) * sizeof(double);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel),
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(trs_potrs_kernel, dim3(B), dim3(256), lds, stream, S, n_free, ld, slab_stride,
-                       uf, ld_uf, env, n_pad_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (env != nullptr)
+        hipLaunchKernelGGL(trs_potrs_kernel<true>, dim3(B), dim3(256), lds, stream, S, n_free, ld,
+                           slab_stride, uf, ld_uf, env, n_pad_max);
+    else
+        hipLaunchKernelGGL(trs_potrs_kernel<false>, dim3(B), dim3(256), lds, stream, S, n_free, ld,
+                           slab_stride, uf, ld_uf, env, n_pad_max);
     return (int)hipGetLastError();
 }

@@ -119,6 +119,11 @@ def test_stages_against_oracle(gpu, name):
     np.testing.assert_array_equal(np.diag(U)[n:], np.ones(npad - n))
     yref = np.linalg.solve(Lref, f_free)
     assert H.max_scaled_err(y[:n], yref) <= 1e-9
+    # the strictly-lower part of every 16 x 16 diagonal tile carries inv(L_tile) for trs_potrs
+    for t0 in range(0, n - 15, 16):
+        Linv = np.linalg.inv(Lref[t0:t0 + 16, t0:t0 + 16])
+        got = np.tril(S[t0:t0 + 16, t0:t0 + 16], -1)
+        assert H.max_scaled_err(got, np.tril(Linv, -1)) <= 1e-9
 
     # --- potrs ----------------------------------------------------------------------------------
     dev.potrs()

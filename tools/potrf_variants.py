@@ -69,6 +69,8 @@ def main():
             libs[tag].trs_debug_stamps(buf, 1)
             tot = float(sum(buf)) or 1.0
             names = ("diag_gemm", "factor_rest", "item_gemm", "item_wait_f", "item_trsm_store", "end_barrier", "wait_d", "chol16")
+            if not args.dense:  # the wave-per-matrix kernel's phases
+                names = ("tile_loads", "block_update", "factorisation", "load_column+stores", "items", "fence", "-", "-")
             print(f"{tag} stamp shares: " + ", ".join(f"{n} {buf[i] / tot:.3f}" for i, n in enumerate(names)))
         med = {s: float(np.median(v)) for s, v in times[tag].items()}
         mn = {s: float(np.min(v)) for s, v in times[tag].items()}
