@@ -30,7 +30,9 @@
  *      other entries with i >= 16*floor(c/16), i < n_pad + 16 are 0; entries left of the
  *      diagonal tile are never read or written unless TRS_ASM_FULL_SYMMETRIC is given.
  *    After trs_potrf_batched:  S[c][i] = U[c][i] (i >= c) with K_ff = U^T U (U = L^T), and
- *    S[c][n_pad] = y[c], the forward-substituted right-hand side (L y = f_f).
+ *    S[c][n_pad] = y[c], the forward-substituted right-hand side (L y = f_f).  Inside every
+ *    16 x 16 diagonal tile the entries below the diagonal (c > i, same tile) hold the strictly
+ *    lower part of inv(L_tile) (its diagonal is 1 / U[c][c]); trs_potrs_batched uses it.
  */
 #ifndef TRS_SOLVER_H
 #define TRS_SOLVER_H
