@@ -56,24 +56,36 @@ def algorithmic_counts(n, nJ, nM, env_cend=None):
     }
 
 
-def potrf_tile_flops(n, env_ft=None, env_last=None, rs=4):
-    """FLOPs of the MFMA work trs_potrf_kernel executes for one matrix (2048 per 16x16x4 MFMA), from
-    the same tile envelope the kernel uses (mirror of its panel loop; dense when env is None):
-    diagonal-block update, block factorisation, item updates + triangular solves, load-column item."""
+def potrf_tile_flops(n, env_ft=None, env_last=None, env_cend=None, narrow=False):
+    """FLOPs of the MFMA work the factorisation kernel executes for one matrix (2048 per 16x16x4
+    MFMA): a host mirror of its panel loop with the same tile envelope (dense when env is None).
+    Per panel: diagonal-block update, block factorisation (64 MFMAs between the tiles + 10 inside each
+    of the four 16x16 factorisations), load column, item updates + triangular solves.  The
+    wave-per-matrix kernel (`narrow`) issues no MFMA whose operand tile lies outside the envelope."""
     npad = (n + 63) // 64 * 64
     nch = npad // 16
+    rs = 2 if narrow else 4
     mfma = 0
     for j in range(npad // 64):
         r0 = 64 * j
         kd = 16 * int(env_ft[4 * j]) if env_ft is not None else 0
-        mfma += 10 * (r0 - kd) // 4 + 64                     # D (ten tiles) + F
+        if narrow:
+            bks = [16 * int(env_ft[4 * j + u]) for u in range(4)]
+            for kk in range(kd, r0, 4):                      # block update + load column, per k-step
+                mfma += sum(u + 2 for u in range(4) if kk >= bks[u])
+            mfma += 40                                         # load column against the factored block
+        else:
+            mfma += (10 + 4) * (r0 - kd) // 4 + 40            # ten block tiles + load-column chunk
+        mfma += 64 + 40                                        # F
         lastq = int(env_last[j]) if env_last is not None else nch - 1
         below = lastq - (4 * j + 3)
         for c0 in range(4 * j + 4, 4 * j + 4 + below, rs):
             nv = min(rs, 4 * j + 4 + below - c0)
             ks = 16 * int(env_ft[c0]) if env_ft is not None else 0
-            mfma += nv * 4 * (r0 - ks) // 4 + nv * 40          # update + solve against the block
-        mfma += 4 * (r0 - kd) // 4 + 40                       # load-column chunk
+            mfma += nv * 4 * (r0 - ks) // 4                    # update
+            for q in range(c0, c0 + nv):                       # solve against the block
+                e = sum(1 for s in range(4) if q < int(env_cend[4 * j + s])) if narrow else 4
+                mfma += 4 * e + 4 * (e * (e - 1) // 2)
     return 2048.0 * mfma
 
 
@@ -198,8 +210,8 @@ def main():
             slack = int(env[nchm + dev.rows // 64])
             narrow = slack == 1   # the kernel choice recorded by trs_assemble (csrc/trs_common.h)
             potrf_kernel = "trs_potrf_narrow_kernel" if narrow else "trs_potrf_kernel"
-            tile_flops = potrf_tile_flops(n, env_ft, env_last, rs=2 if narrow else 4)
             env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nchm]
+            tile_flops = potrf_tile_flops(n, env_ft, env_last, env_cend, narrow)
             counts = algorithmic_counts(n, nJ, nM, env_cend)
         else:
             tile_flops = potrf_tile_flops(n)

@@ -582,11 +582,15 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
     const int rowbase = 16 * c0, lane = threadIdx.x & 63;
     d4 acc[NV][CT];
     unsigned vo[NV][CT];
+    bool ex[NV][CT];  // stored tiles; ex[v][s] implies ex[v][s2] for s2 > s (cend is non-decreasing)
 #pragma unroll
     for (int s = 0; s < CT; ++s) {
         const int ce = cend[r0 / 16 + s];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) vo[v][s] = S.lane_off(c0 + v < ce);
+        for (int v = 0; v < NV; ++v) {
+            ex[v][s] = c0 + v < ce;
+            vo[v][s] = S.lane_off(ex[v][s]);
+        }
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -625,7 +629,8 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int s = 0; s < CT; ++s) acc[v][s] = mfma_f64_negA(fb[d][s], fa[d][v], acc[v][s]);
+                    for (int s = 0; s < CT; ++s)  // (branching on ex[v][s] here costs 60 VGPRs; not worth it)
+                        acc[v][s] = mfma_f64_negA(fb[d][s], fa[d][v], acc[v][s]);
             }
             ob += DEPTHN * step;
             oa += DEPTHN * step;
@@ -634,18 +639,18 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
 #pragma unroll
     for (int s = 0; s < CT; ++s) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {  // X_s^T = inv(L_ss) T_s^T
-            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+        for (int v = 0; v < NV; ++v)  // tiles outside the envelope are zero and stay zero: no work
+            if (ex[v][s]) {
+                d4 x = d4{0.0, 0.0, 0.0, 0.0};  // X_s^T = inv(L_ss) T_s^T
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + r * 64 + lane], acc[v][s][r], x);
-            acc[v][s] = x;
-        }
+                for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + r * 64 + lane], acc[v][s][r], x);
+                acc[v][s] = x;
 #pragma unroll
-        for (int s2 = s + 1; s2 < CT; ++s2)  // T_{s2}^T -= L_{s2,s} X_s^T
+                for (int s2 = s + 1; s2 < CT; ++s2)  // T_{s2}^T -= L_{s2,s} X_s^T
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[v][s2] = mfma_f64_negA(t[s2][s][r], acc[v][s][r], acc[v][s2]);
+                    for (int r = 0; r < 4; ++r)
+                        acc[v][s2] = mfma_f64_negA(t[s2][s][r], acc[v][s][r], acc[v][s2]);
+            }
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -724,12 +729,16 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
                     for (int c = 0; c < CT; ++c)
                         fb[nd][c] = bload(ok + (d + DEPTHN - 1) * step, c, k0 + 4 * (d + DEPTHN - 1));
                     fy[nd] = S.load(oy + (d + DEPTHN - 1) * step);
+                    // chunk u of the block has non-zeros in these four columns only from bks[u] on
+                    // (non-decreasing in u): products with an all-zero operand are not issued
+                    const int kk = k0 + 4 * d;
 #pragma unroll
                     for (int u = 0; u < CT; ++u)
+                        if (kk >= bks[u]) {
 #pragma unroll
-                        for (int s = 0; s <= u; ++s) t[u][s] = mfma_f64_negA(fb[d][s], fb[d][u], t[u][s]);
-#pragma unroll
-                    for (int s = 0; s < CT; ++s) y[s] = mfma_f64_negA(fb[d][s], fy[d], y[s]);
+                            for (int s = 0; s <= u; ++s) t[u][s] = mfma_f64_negA(fb[d][s], fb[d][u], t[u][s]);
+                            y[u] = mfma_f64_negA(fb[d][u], fy[d], y[u]);
+                        }
                 }
                 ok += DEPTHN * step;
                 oy += DEPTHN * step;
