@@ -16,7 +16,7 @@ for use_env in (True, False):
     if use_env:
         ref_u = res.displace[0].copy()
         env = dev.env[0].cpu().numpy()
-        print("ft", env[:44].tolist()); print("last", env[44:55].tolist())
+        print("ft", env[:44].tolist()); print("last", env[44:55].tolist()); print("cend", env[63:107].tolist())
     print("env" if use_env else "dense", ts, "total", round(sum(ts.values()), 3), "info", int((res.info != 0).sum()),
           "diff_vs_env", float(np.abs(res.displace[0] - ref_u).max() / np.abs(ref_u).max()))
     del dev
