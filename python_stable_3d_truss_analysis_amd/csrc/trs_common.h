@@ -47,7 +47,10 @@ __device__ static inline double readlane_f64(double v) {
 //                       work-group kernel:      cend[t] = last[t / 4] + 1 + slack (rectangular per panel).
 // Cholesky fill stays inside the row envelope, so tiles outside it are exact zeros.
 #ifndef TRS_NARROW_MAX_BELOW
-#define TRS_NARROW_MAX_BELOW 12  // widest reach below a diagonal block (chunks) for the narrow kernel
+#define TRS_NARROW_MAX_BELOW 24  // widest reach below a diagonal block (chunks) for the narrow kernel;
+                                 // measured on 65 536 mixed cube trusses (tools/bench_configs.py):
+                                 // 12 -> 363 K / 772 K solves/s (generator / RCM order), 16 -> 362 / 827,
+                                 // 24 -> 340 / 892, 32 -> 313 / 908, 64 -> 271 / 894
 #endif
 #define TRS_NARROW_ITEM 2        // chunks per item of the narrow kernel
 #define TRS_WIDE_ITEM 4          // chunks per item of the work-group kernel

@@ -16,7 +16,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from python_stable_3d_truss_analysis_amd import MemberType, Truss, batch
+from python_stable_3d_truss_analysis_amd import MemberType, Truss, batch, _capi
+if os.environ.get("TRS_LIB_VARIANT"):  # A/B builds of tools/build_variants.sh
+    _capi.LIB_PATH = os.path.join(ROOT, "python_stable_3d_truss_analysis_amd", "variants",
+                                  f"libtrs_{os.environ['TRS_LIB_VARIANT']}.so")
 from python_stable_3d_truss_analysis_amd import generate as gen
 from python_stable_3d_truss_analysis_amd.ga import GA
 
