@@ -294,14 +294,25 @@ def rcm_permutation(packed: PackedBatch):
 
 
 def permute_joints(packed: PackedBatch, perm):
-    """The same trusses with joint k := old joint perm[b, k] (members keep their order)."""
-    rows = np.arange(packed.B)[:, None]
-    inverse = np.empty_like(perm)
-    inverse[rows, perm] = np.arange(perm.shape[1], dtype=perm.dtype)[None, :]
-    conn = inverse[rows[:, :, None], packed.conn]
-    conn = np.where(np.arange(packed.nM_max)[None, :, None] < packed.nM[:, None, None], conn, 0).astype(np.int32)
-    return PackedBatch(packed.xyz[rows, perm], conn, packed.E, packed.A, packed.rho, packed.cbits[rows, perm],
-                       packed.loads[rows, perm], packed.nJ, packed.nM, packed.dim, packed.n_free)
+    """The same trusses with joint k := old joint perm[b, k] (members keep their order).
+    Native (`csrc/reorder.c`, OpenMP over the batch)."""
+    import ctypes
+    from .generate import _load
+    lib = _load()
+    lib.trs_apply_joint_order.restype = ctypes.c_int
+    B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
+    src = [np.ascontiguousarray(a, dtype=t) for a, t in (
+        (perm, np.int32), (packed.nM, np.int32), (packed.xyz, np.float64), (packed.conn, np.int32),
+        (packed.cbits, np.uint8), (packed.loads, np.float64))]
+    xyz, conn = np.empty_like(src[2]), np.empty_like(src[3])
+    cbits, loads = np.empty_like(src[4]), np.empty_like(src[5])
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.trs_apply_joint_order(ctypes.c_int(B), ctypes.c_int(nJ_max), ctypes.c_int(nM_max),
+                                   *(ptr(a) for a in src), ptr(xyz), ptr(conn), ptr(cbits), ptr(loads))
+    if rc != 0:
+        raise RuntimeError(f"trs_apply_joint_order failed ({rc})")
+    return PackedBatch(xyz, conn, packed.E, packed.A, packed.rho, cbits, loads, packed.nJ, packed.nM,
+                       packed.dim, packed.n_free)
 
 
 def size_buckets(packed: PackedBatch, max_slab_bytes=32 << 30):

@@ -129,3 +129,42 @@ int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint
     }
     return rc;
 }
+
+/* Apply a joint order: joint k of the output is joint perm[b][k] of the input (members keep their
+ * order, their end joints are renumbered; padding members stay (0, 0)).  Out-of-place. */
+int trs_apply_joint_order(int B, int nJ_max, int nM_max, const int32_t *perm, const int32_t *nM,
+                          const double *xyz, const int32_t *conn, const uint8_t *cbits,
+                          const double *loads, double *xyz_out, int32_t *conn_out, uint8_t *cbits_out,
+                          double *loads_out) {
+    int rc = 0;
+#pragma omp parallel
+    {
+        int *inverse = (int *)malloc(sizeof(int) * (size_t)(nJ_max + 1));
+        if (!inverse) {
+#pragma omp atomic write
+            rc = -1;
+        } else {
+#pragma omp for schedule(static)
+            for (int b = 0; b < B; ++b) {
+                const int32_t *p = perm + (size_t)b * nJ_max;
+                for (int k = 0; k < nJ_max; ++k) {
+                    const int old = p[k];
+                    inverse[old] = k;
+                    for (int a = 0; a < 3; ++a) {
+                        xyz_out[((size_t)b * nJ_max + k) * 3 + a] = xyz[((size_t)b * nJ_max + old) * 3 + a];
+                        loads_out[((size_t)b * nJ_max + k) * 3 + a] = loads[((size_t)b * nJ_max + old) * 3 + a];
+                    }
+                    cbits_out[(size_t)b * nJ_max + k] = cbits[(size_t)b * nJ_max + old];
+                }
+                for (int m = 0; m < nM_max; ++m) {
+                    const size_t e = ((size_t)b * nM_max + m) * 2;
+                    const int live = m < nM[b];
+                    conn_out[e] = live ? inverse[conn[e]] : 0;
+                    conn_out[e + 1] = live ? inverse[conn[e + 1]] : 0;
+                }
+            }
+            free(inverse);
+        }
+    }
+    return rc;
+}
