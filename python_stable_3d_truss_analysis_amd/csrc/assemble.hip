@@ -352,11 +352,13 @@ struct AsmPlan {
     size_t lds;
 };
 inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
-    // prefer two work-groups per CU (80 KiB each) with the member geometry in LDS, then geometry in
-    // the workspace, then one work-group per CU
+    // Member geometry in LDS first - two work-groups per CU (80 KiB each), else one (160 KiB): a
+    // global load in the row loop has to wait for every store queued before it (one vmcnt counter),
+    // which costs far more than the lost occupancy.  Geometry in the workspace only when even one
+    // work-group per CU cannot hold it.
     const size_t budgets[2] = {80 * 1024, 160 * 1024};
-    for (size_t budget : budgets) {
-        for (int g = 1; g >= 0; --g) {
+    for (int g = 1; g >= 0; --g) {
+        for (size_t budget : budgets) {
             const size_t fixed = asm_lds_layout(nJ_max, nM_max, n_pad_max, -16, g).total;
             if (fixed + (size_t)TR * (32 + 16) * 8 > budget) continue;
             int WT = (int)((budget - fixed) / (TR * 8)) - 16;
