@@ -837,6 +837,9 @@ extern "C" int trs_debug_stamps(unsigned long long* host_out, int reset) {
 extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
                                 double* S, int* info, const int* env, hipStream_t stream) {
     if (B <= 0) return 0;
+    // a slab is addressed through one buffer descriptor with 32-bit byte offsets, the upper half of
+    // the offset range being the "tile not stored" marker (Slab::gone)
+    if (slab_stride * sizeof(double) >= (size_t)1 << 31) return (int)hipErrorInvalidValue;
     if (env != nullptr) {
         hipLaunchKernelGGL(trs_potrf_narrow_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, S, n_free, ld,
                            slab_stride, info, env, n_pad_max, B);
