@@ -122,7 +122,7 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
 // instruction cache.  The tile travels by value in registers; the pivot status goes through sc.bad.
 __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
-    int bad = -1;
+    unsigned badmask = 0;
     d4 R, u;  // R: running right-hand side of inv(L) (D-form, starts as the identity); u: result
 #pragma unroll
     for (int r = 0; r < 4; ++r) R[r] = (lq + 4 * r == li) ? 1.0 : 0.0;
@@ -140,11 +140,10 @@ __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
         double rinv[4], m[4][4];  // wave-uniform: 1 / L[j0+q][j0+q], L[j0+q2][j0+q]
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            double d = lane_bcast(c[q], j0 + q);
-            if (!(d > 0.0)) {
-                if (bad < 0) bad = j0 + q;
-                d = 1.0;
-            }
+            const double d = lane_bcast(c[q], j0 + q);
+            // a non-positive (or NaN) pivot only sets its bit: what follows it is garbage, the
+            // first set bit is the answer
+            badmask |= (d > 0.0) ? 0u : 1u << (j0 + q);
             rinv[q] = rsqrt_refined(d);
             c[q] *= rinv[q];  // L[li][j0+q] for li >= j0+q (li == j0+q: d / sqrt(d))
 #pragma unroll
@@ -171,7 +170,7 @@ __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
         u[b] = (j0 + lq <= li) ? p : wb[b];
         if (b < 3) R = mfma_f64_negA(p, wb[b], R);  // R -= L[:,blk] W[blk,:]
     }
-    if (lane == 0) sc.bad = bad;
+    if (lane == 0) sc.bad = badmask ? __builtin_ctz(badmask) : -1;
     return u;
 }
 
