@@ -263,6 +263,29 @@ class DeviceBatch:
             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), self._stream()), "trs_fitness")
         return out
 
+    INPUT_FIELDS = ("xyz", "conn", "E", "A", "rho", "cbits", "loads", "nJ", "nM")
+
+    def pinned_inputs(self, packed: PackedBatch):
+        """Page-locked host copies of a batch's inputs (same padded shapes as this device batch)."""
+        t = self.torch
+        return {f: t.from_numpy(np.ascontiguousarray(getattr(packed, f))).pin_memory() for f in self.INPUT_FIELDS}
+
+    def upload(self, host_inputs):
+        """Replace the resident inputs by another batch of the same padded shapes (asynchronous on
+        the current stream when `host_inputs` come from `pinned_inputs`)."""
+        for f in self.INPUT_FIELDS:
+            getattr(self, f).copy_(host_inputs[f], non_blocking=True)
+
+    def download(self, out=None):
+        """Copy the dense results to (pinned) host tensors, asynchronously; returns the dict."""
+        t = self.torch
+        if out is None:
+            out = {k: t.empty(v.shape, dtype=v.dtype).pin_memory()
+                   for k, v in (("u", self.u), ("f_ext", self.f_ext), ("N", self.N), ("info", self.info))}
+        for k in out:
+            out[k].copy_(getattr(self, k), non_blocking=True)
+        return out
+
     def set_sections(self, A, E, rho):
         """Replace the member sections (host arrays [B,nM_max]); geometry stays resident."""
         for dst, src in ((self.A, A), (self.E, E), (self.rho, rho)):
