@@ -4,7 +4,7 @@
 # Usage: tools/profile_pmc.sh <tag> [bench args...]      -> gpurun_out/<tag>/{stats,pmc_*}/...
 set -u
 TAG=${1:-prof}; shift || true
-ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-dense-ref --no-pcie}
+ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-dense-ref --no-pcie --cube-batch 0}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
