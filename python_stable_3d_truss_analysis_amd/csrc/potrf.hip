@@ -567,16 +567,16 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
 #ifndef TRS_NARROW_WAVES_PER_SIMD
 #define TRS_NARROW_WAVES_PER_SIMD 2
 #endif
-constexpr int RSN = TRS_NARROW_RS;      // row chunks per item in the narrow kernel (1 or 2)
+constexpr int RSN = TRS_NARROW_RS;      // row chunks per item in the narrow kernel (1, 2 or 4)
 constexpr int DEPTHN = TRS_NARROW_DEPTH;  // k-steps of fragments in flight (divides 4 k-steps = 16 columns)
 
 // One item of the narrow kernel: NV row chunks c0, c0+1 below the diagonal block of panel r0 / 64.
 // Tile (chunk q, column tile tt) is stored iff q < cend[tt] (trs_common.h); what is not stored is an
 // exact zero of L: its loads return 0 and its stores are dropped through the lane offset.
-//   kstart = 16 ft[c0]: first column of chunk c0's envelope; chunk c0+1 may start later (ft1).
+//   kstart = 16 ft[c0]: first column of chunk c0's envelope; the chunks after it may start later.
 template <int NV>
 __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const int c0, const int kstart,
-                                            const int ft1, const int* __restrict__ cend,
+                                            const int* __restrict__ ft, const int* __restrict__ cend,
                                             const double* Wl, const d4 (&t)[CT][CT]) {
     const int rowbase = 16 * c0, lane = threadIdx.x & 63;
     d4 acc[NV][CT];
@@ -605,9 +605,12 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
         const int step = S.ld * 32;
         double fb[DEPTHN][CT], fa[DEPTHN][NV];
         // chunk c0's rows exist from kstart on, and so do the block's (ft is non-decreasing); chunk
-        // c0+1 only from column 16 ft1 on
+        // c0+v only from column 16 ft[c0+v] on
+        int kv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) kv[v] = 16 * ft[c0 + v];
         auto aload = [&](int off, int v, int k) {
-            return S.load_at(S.lane_off(v == 0 || k >= 16 * ft1), off + 128 * v);
+            return S.load_at(S.lane_off(v == 0 || k >= kv[v]), off + 128 * v);
         };
 #pragma unroll
         for (int d = 0; d < DEPTHN - 1; ++d) {
@@ -806,10 +809,19 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
         st.mark(3);
         // items: the chunks below the block that reach into this panel
         const int lastq = env.last[panel];
-        for (int c0 = 4 * panel + CT; c0 <= lastq; c0 += RSN) {
+        for (int c0 = 4 * panel + CT; c0 <= lastq;) {
             const int ks = 16 * env.ft[c0];
-            if (RSN >= 2 && lastq - c0 + 1 >= 2) narrow_item<(RSN >= 2 ? 2 : 1)>(S, r0, c0, ks, env.ft[c0 + 1], env.cend, Wl, t);
-            else narrow_item<1>(S, r0, c0, ks, 0, env.cend, Wl, t);
+            const int left = lastq - c0 + 1;
+            if (RSN >= 4 && left >= 4) {
+                narrow_item<(RSN >= 4 ? 4 : 1)>(S, r0, c0, ks, env.ft, env.cend, Wl, t);
+                c0 += 4;
+            } else if (RSN >= 2 && left >= 2) {
+                narrow_item<(RSN >= 2 ? 2 : 1)>(S, r0, c0, ks, env.ft, env.cend, Wl, t);
+                c0 += 2;
+            } else {
+                narrow_item<1>(S, r0, c0, ks, env.ft, env.cend, Wl, t);
+                c0 += 1;
+            }
         }
         st.mark(4);
         // this wave's stores must have landed before its own loads of the next panel

@@ -72,11 +72,15 @@ def config4(out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cubes", type=int, default=65536)
+    ap.add_argument("--only", choices=("ga", "generator", "rcm"), help="run one configuration only")
     args = ap.parse_args()
     out = {}
-    config4(out)
-    config3(args.cubes, out, False, "config3_generator_order")
-    config3(args.cubes, out, True, "config3_rcm_order")
+    if args.only in (None, "ga"):
+        config4(out)
+    if args.only in (None, "generator"):
+        config3(args.cubes, out, False, "config3_generator_order")
+    if args.only in (None, "rcm"):
+        config3(args.cubes, out, True, "config3_rcm_order")
     print(json.dumps(out))
 
 
