@@ -447,10 +447,11 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
 // ---- which kernel factors a matrix --------------------------------------------------------------------
 // A matrix whose envelope reaches at most TRS_NARROW_MAX_BELOW row chunks below every diagonal block
 // has so little MFMA work per panel that one wave can carry it alone (trs_potrf_narrow_kernel: one
-// WAVE per matrix, no barriers, the serial 16x16 factorisations of up to 8 matrices per CU overlap);
+// WAVE per matrix, no barriers, the serial 16x16 factorisations of up to 12 matrices per CU overlap);
 // all others go to trs_potrf_kernel (one WORK-GROUP per matrix).  trs_assemble makes the choice
-// (it sizes the written part of the slab by the item size of the chosen kernel) and records it in
-// the envelope metadata; both kernels are launched and each skips the other's matrices.
+// (it shapes the stored part of the slab for the chosen kernel: exact tile envelope / rectangular per
+// panel) and records it in the envelope metadata; both kernels are launched and each skips the
+// other's matrices.
 
 __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_kernel(
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
@@ -552,11 +553,13 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
 }
 
 // ======================================================================================================
-// Narrow-envelope variant: one WAVE per matrix, four matrices per work-group, no barriers, no LDS
-// hand-offs.  The wave keeps the panel's ten diagonal-block tiles, the four inv(L_ss) and the six
-// L_{u,s} operand tiles in registers (they are MFMA fragments as they stand), so the only LDS use is
-// the scratch of the scalar 16x16 factorisation.  Same arithmetic, same order of operations per
-// tile as the work-group kernel except that the diagonal-block update is not split in two halves.
+// Narrow-envelope variant: one WAVE per matrix, four matrices per work-group, no barriers, no
+// hand-offs between waves.  The wave keeps the panel's ten diagonal-block tiles (the six L_{u,s}
+// among them are MFMA operand fragments as they stand) in registers; its private LDS slice holds the
+// four inv(L_ss) as operand fragments, the load column parked during the factorisation and the
+// scratch of chol16_invert.  152 VGPRs: three waves per SIMD.  The load column rides in the
+// diagonal-block pass; every access to a tile outside the stored envelope goes through the
+// out-of-range lane offset (Slab::gone), and no MFMA is issued for an all-zero operand tile.
 // ======================================================================================================
 #ifndef TRS_NARROW_RS
 #define TRS_NARROW_RS TRS_NARROW_ITEM
