@@ -42,12 +42,18 @@ class GraphStores(dict):
         return dict.__getitem__(self, key)
 
 
+_GRAPH_FACTORY = None
+
+
 def _new_graph():
-    try:
-        from torch_geometric.data import HeteroData
-        return HeteroData()
-    except ImportError:
-        return GraphStores()
+    global _GRAPH_FACTORY
+    if _GRAPH_FACTORY is None:  # looked up once: a failed import is slow when repeated per graph
+        try:
+            from torch_geometric.data import HeteroData
+            _GRAPH_FACTORY = HeteroData
+        except ImportError:
+            _GRAPH_FACTORY = GraphStores
+    return _GRAPH_FACTORY()
 
 
 def _sparsified(values, per_row):
@@ -111,13 +117,7 @@ def graph_arrays(xyz, conn, sections, support, loads, dim, actual, prior, taskTy
     out["j2m"] = np.stack([conn.reshape(-1), np.repeat(members, 2)])
     out["m2j"] = out["j2m"][::-1].copy()
     if metapathType == MetapathType.USE_IMPLICIT:
-        inc = np.zeros([nJ, nM], dtype=bool)
-        inc[conn[:, 0], members] = True
-        inc[conn[:, 1], members] = True
-        jj = (inc.astype(np.int32) @ inc.T.astype(np.int32)) > 0
-        mm = (inc.T.astype(np.int32) @ inc.astype(np.int32)) > 0
-        out["j2j"] = np.stack(np.nonzero(jj))
-        out["m2m"] = np.stack(np.nonzero(mm))
+        out["j2j"], out["m2m"] = _implicit_edges(conn, nJ, nM)
     return out
 
 
@@ -140,26 +140,78 @@ def _to_graph(arrays, weight, source):
     return g
 
 
+def _implicit_edges(conn, nJ, nM):
+    members = np.arange(nM)
+    inc = np.zeros([nJ, nM], dtype=bool)
+    inc[conn[:, 0], members] = True
+    inc[conn[:, 1], members] = True
+    jj = (inc.astype(np.int32) @ inc.T.astype(np.int32)) > 0
+    mm = (inc.T.astype(np.int32) @ inc.astype(np.int32)) > 0
+    return np.stack(np.nonzero(jj)), np.stack(np.nonzero(mm))
+
+
 def hetero_tensors_batch(packed: PackedBatch, actual: BatchResult, prior: BatchResult, fixedArea,
                          taskType=TaskType.OPTIMIZATION, metapathType=MetapathType.NO_IMPLICIT,
                          forceScale=1., displaceScale=1., positionScale=1., sources=None):
     """Graphs of a whole solved batch: `actual` / `prior` are the dense results of the two batched
-    solves (`prior` may be None).  Returns one graph per truss."""
+    solves (`prior` may be None).  Returns one graph per truss.
+
+    The features of ALL trusses are formed natively (`csrc/graphfeat.c`, OpenMP over the batch; same
+    formulas as `graph_arrays`, which stays the single-truss path) straight into float32 batch
+    tensors; a truss's graph holds slices of those batch tensors."""
+    import ctypes
+    import torch
+    from .generate import _load
+    if taskType not in (TaskType.OPTIMIZATION, TaskType.REGRESSION):
+        raise InvalidTaskTypeError(f"Invalid task type [{taskType}].")
+    if (np.asarray(packed.dim) != 3).any():
+        raise NotImplementedError("graph features are defined for 3D trusses (utils.py:105-113)")
+    B, nJm, nMm = packed.B, packed.nJ_max, packed.nM_max
+    regression = taskType == TaskType.REGRESSION
+    FJ = 7 + (3 if prior is not None else 0)
+    FM = 8 + (1 if prior is not None else 0) + (1 if regression else 0)
+    joint_x = torch.empty([B, nJm, FJ], dtype=torch.float32)
+    member_x = torch.empty([B, nMm, FM], dtype=torch.float32)
+    joint_y = torch.empty([B, nJm, 3], dtype=torch.float32) if regression else None
+    member_y = torch.empty([B, nMm, 1], dtype=torch.float32) if regression else None
+    weight = np.empty([B], dtype=np.float64)
+    c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+    keep = [c(packed.xyz, np.float64), c(packed.conn, np.int32), c(packed.A, np.float64), c(packed.rho, np.float64),
+            c(packed.cbits, np.uint8), c(packed.loads, np.float64), c(packed.nJ, np.int32), c(packed.nM, np.int32)]
+    res = [c(actual.displace, np.float64), c(actual.internal, np.float64)] if regression else [None, None]
+    res += [c(prior.displace, np.float64), c(prior.internal, np.float64)] if prior is not None else [None, None]
+    ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    tptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    lib = _load()
+    lib.trs_graph_features.restype = ctypes.c_int
+    rc = lib.trs_graph_features(
+        ctypes.c_int(B), ctypes.c_int(nJm), ctypes.c_int(nMm), *(ptr(a) for a in keep), *(ptr(a) for a in res),
+        ctypes.c_double(fixedArea if prior is not None else 1.0), ctypes.c_double(forceScale),
+        ctypes.c_double(displaceScale), ctypes.c_double(positionScale), ctypes.c_int(int(regression)),
+        tptr(joint_x), tptr(member_x), tptr(joint_y), tptr(member_y), ptr(weight))
+    if rc != 0:
+        raise RuntimeError(f"trs_graph_features failed ({rc})")
+    conn = torch.from_numpy(keep[1].astype(np.int64))
+    j2m = torch.stack([conn.reshape(B, -1), torch.arange(nMm).repeat_interleave(2).expand(B, -1)], dim=1)
+    m2j = torch.flip(j2m, dims=[1])
     graphs = []
-    for b in range(packed.B):
-        dim, nJ, nM = int(packed.dim[b]), int(packed.nJ[b]), int(packed.nM[b])
-        sections = np.stack([packed.A[b, :nM], packed.E[b, :nM], packed.rho[b, :nM]], axis=1)
-        conn = packed.conn[b, :nM]
-        xyz = packed.xyz[b, :nJ, :dim]
-        mask = 7 if dim == 3 else 3
-        arrays = graph_arrays(
-            xyz, conn, sections, (packed.cbits[b, :nJ] & mask) != 0, packed.loads[b, :nJ, :dim], dim,
-            (actual.displace[b, :nJ, :dim], actual.internal[b, :nM]),
-            None if prior is None else (prior.displace[b, :nJ, :dim], prior.internal[b, :nM], fixedArea),
-            taskType, metapathType, forceScale, displaceScale, positionScale)
-        length = np.sqrt(((xyz[conn[:, 1]] - xyz[conn[:, 0]]) ** 2).sum(axis=1))
-        weight = float((sections[:, 0] * length * sections[:, 2]).sum())
-        graphs.append(_to_graph(arrays, weight, None if sources is None else sources[b]))
+    for b in range(B):
+        nJ, nM = int(packed.nJ[b]), int(packed.nM[b])
+        g = _new_graph()
+        g["src"] = None if sources is None else sources[b]
+        g["originWeight"] = float(weight[b])
+        g["joint"].x = joint_x[b, :nJ]
+        g["member"].x = member_x[b, :nM]
+        if joint_y is not None:
+            g["joint"].y = joint_y[b, :nJ]
+            g["member"].y = member_y[b, :nM]
+        g["joint", "j2m", "member"].edge_index = j2m[b, :, :2 * nM]
+        g["member", "m2j", "joint"].edge_index = m2j[b, :, :2 * nM]
+        if metapathType == MetapathType.USE_IMPLICIT:
+            jj, mm = _implicit_edges(packed.conn[b, :nM], nJ, nM)
+            g["joint", "j2j", "joint"].edge_index = torch.from_numpy(jj)
+            g["member", "m2m", "member"].edge_index = torch.from_numpy(mm)
+        graphs.append(g)
     return graphs
 
 

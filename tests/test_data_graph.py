@@ -101,3 +101,42 @@ def test_batched_dataset_path_on_gpu():
         assert graphs[b]["joint"].x.shape == (nJ, 10) and graphs[b]["member"].x.shape == (nM, 10)
         ref = orc.solve(gen.packed_to_json(packed, b))
         np.testing.assert_allclose(graphs[b]["joint"].y.numpy(), ref["u"], rtol=1e-5, atol=1e-9)
+
+
+def test_native_batch_features_equal_the_single_truss_path():
+    """`hetero_tensors_batch` (csrc/graphfeat.c) against `graph_arrays` on a ragged generated batch
+    with synthetic results (incl. values below the 1e-10 sparsification threshold): bit-identical
+    float32 features, targets and edges for every (task, prior) combination."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    from python_stable_3d_truss_analysis_amd.batch import BatchResult
+    from python_stable_3d_truss_analysis_amd.data import graph_arrays
+    rng = np.random.default_rng(3)
+    packed = gen.generate_cube_batch([3, 9, 20, 5], gridRange=(4, 4, 4), seed=11)
+    B, nJm, nMm = packed.B, packed.nJ_max, packed.nM_max
+
+    def fake():
+        tiny_j = np.where(rng.random((B, nJm, 1)) < 0.2, 1e-12, 1.0)
+        tiny_m = np.where(rng.random((B, nMm)) < 0.2, 1e-12, 1.0)
+        return BatchResult(rng.standard_normal((B, nJm, 3)) * tiny_j, np.zeros((B, nJm, 3)),
+                           rng.standard_normal((B, nMm)) * tiny_m, np.zeros(B, dtype=np.int32))
+
+    act, pri = fake(), fake()
+    scales = dict(forceScale=3.0, displaceScale=0.5, positionScale=7.0)
+    for task, prior in ((TaskType.REGRESSION, pri), (TaskType.OPTIMIZATION, pri), (TaskType.REGRESSION, None)):
+        graphs = hetero_tensors_batch(packed, act, prior, 0.7, task, MetapathType.USE_IMPLICIT, **scales)
+        for b in range(B):
+            nJ, nM = int(packed.nJ[b]), int(packed.nM[b])
+            sections = np.stack([packed.A[b, :nM], packed.E[b, :nM], packed.rho[b, :nM]], axis=1)
+            ref = graph_arrays(packed.xyz[b, :nJ], packed.conn[b, :nM], sections, (packed.cbits[b, :nJ] & 7) != 0,
+                               packed.loads[b, :nJ], 3, (act.displace[b, :nJ], act.internal[b, :nM]),
+                               None if prior is None else (prior.displace[b, :nJ], prior.internal[b, :nM], 0.7),
+                               task, MetapathType.USE_IMPLICIT, **scales)
+            g = graphs[b]
+            np.testing.assert_array_equal(g["joint"].x.numpy(), ref["joint_x"].astype(np.float32))
+            np.testing.assert_array_equal(g["member"].x.numpy(), ref["member_x"].astype(np.float32))
+            if task == TaskType.REGRESSION:
+                np.testing.assert_array_equal(g["joint"].y.numpy(), ref["joint_y"].astype(np.float32))
+                np.testing.assert_array_equal(g["member"].y.numpy(), ref["member_y"].astype(np.float32))
+            for key, name in ((("joint", "j2m", "member"), "j2m"), (("member", "m2j", "joint"), "m2j"),
+                              (("joint", "j2j", "joint"), "j2j"), (("member", "m2m", "member"), "m2m")):
+                np.testing.assert_array_equal(g[key].edge_index.numpy(), ref[name])
