@@ -146,8 +146,8 @@ def cube_batch_rate(device, B, torch, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="trusses per GPU")
     ap.add_argument("--case", default="bar-942_input_0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
