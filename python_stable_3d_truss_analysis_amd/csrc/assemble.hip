@@ -27,20 +27,21 @@ namespace {
 #ifndef TRS_ASM_THREADS
 #define TRS_ASM_THREADS 512
 #endif
-constexpr int NT = TRS_ASM_THREADS;  // threads per work-group
+constexpr int NT_DEFAULT = TRS_ASM_THREADS;  // threads per work-group (two work-groups per CU)
+constexpr int NT_BIG = 1024;                 // ... when a truss needs a whole CU's LDS (one per CU)
 #ifndef TRS_ASM_TPR
 #define TRS_ASM_TPR 16
 #endif
 constexpr int TPR = TRS_ASM_TPR;     // threads per slab row (64 / TPR rows per wave)
 static_assert(64 % TPR == 0 && 16 % (64 / TPR) == 0, "a wave's rows must lie in one 16-row chunk");
-constexpr int TR = NT / TPR;         // slab rows per block
+__host__ __device__ constexpr int tile_rows(int nt) { return nt / TPR; }  // slab rows per block
 
 // LDS carve-up shared by host and device (bytes, every part 16-byte aligned)
 struct AsmLds {
     size_t geom, diag, rhs, tile, ints, total;
 };
 __host__ __device__ inline AsmLds asm_lds_layout(int nJ_max, int nM_max, int n_pad_max, int WT,
-                                                 int geom_in_lds) {
+                                                 int geom_in_lds, int TR) {
     AsmLds l;
     l.geom = 0;                                                  // double[nM_max][4]: k | c
     l.diag = l.geom + (geom_in_lds ? (size_t)nM_max * 32 : 0);   // double[nJ_max][6]
@@ -52,7 +53,7 @@ __host__ __device__ inline AsmLds asm_lds_layout(int nJ_max, int nM_max, int n_p
     return l;
 }
 
-template <bool GEOM_IN_LDS>  // a compile-time address space for k, c: LDS loads, not flat ones
+template <bool GEOM_IN_LDS, int NT>  // a compile-time address space for k, c: LDS loads, not flat ones
 __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
     const double* __restrict__ A, const double* __restrict__ loads,
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     const int WT) {
     extern __shared__ unsigned char lds_raw[];
     constexpr int geom_in_lds = GEOM_IN_LDS ? 1 : 0;
+    constexpr int TR = tile_rows(NT);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nJ = nJ_arr[b], nM = nM_arr[b];
     const int n = n_free[b];
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     if (npad == 0) return;
     const int nch = npad / 16;
 
-    const AsmLds lay = asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, geom_in_lds);
+    const AsmLds lay = asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, geom_in_lds, TR);
     // member geometry: in LDS when it fits, else in the truss's workspace (stays in L2)
     double* mk;  // [nM_max] E A / L
     if constexpr (GEOM_IN_LDS)
@@ -346,28 +348,29 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     }
 }
 
-// tile width and geometry placement for a batch shape; returns 0 when nothing fits
+// tile width, geometry placement and work-group size for a batch shape; WT = 0 when nothing fits
 struct AsmPlan {
-    int WT, geom_in_lds;
+    int WT, geom_in_lds, big;
     size_t lds;
 };
 inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
-    // Member geometry in LDS first - two work-groups per CU (80 KiB each), else one (160 KiB): a
-    // global load in the row loop has to wait for every store queued before it (one vmcnt counter),
-    // which costs far more than the lost occupancy.  Geometry in the workspace only when even one
-    // work-group per CU cannot hold it.
-    const size_t budgets[2] = {80 * 1024, 160 * 1024};
+    // Member geometry in LDS first - two 512-thread work-groups per CU (80 KiB each), else one
+    // 1024-thread work-group with the whole 160 KiB: a global load in the row loop has to wait for
+    // every store queued before it (one vmcnt counter), which costs far more than anything else.
+    // Geometry in the workspace only when even a whole CU's LDS cannot hold it.
     for (int g = 1; g >= 0; --g) {
-        for (size_t budget : budgets) {
-            const size_t fixed = asm_lds_layout(nJ_max, nM_max, n_pad_max, -16, g).total;
+        for (int big = 0; big <= 1; ++big) {
+            const size_t budget = big ? 160 * 1024 : 80 * 1024;
+            const int TR = tile_rows(big ? NT_BIG : NT_DEFAULT);
+            const size_t fixed = asm_lds_layout(nJ_max, nM_max, n_pad_max, -16, g, TR).total;
             if (fixed + (size_t)TR * (32 + 16) * 8 > budget) continue;
             int WT = (int)((budget - fixed) / (TR * 8)) - 16;
             WT = WT / 16 * 16;
             if (WT > n_pad_max) WT = n_pad_max;
-            return AsmPlan{WT, g, asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, g).total};
+            return AsmPlan{WT, g, big, asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, g, TR).total};
         }
     }
-    return AsmPlan{0, 0, 0};
+    return AsmPlan{0, 0, 0, 0};
 }
 
 }  // namespace
@@ -387,20 +390,24 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
     if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;  // packed adjacency keys
     const AsmPlan plan = asm_plan(nJ_max, nM_max, n_pad_max);
     if (plan.WT <= 0) return (int)hipErrorInvalidValue;
-#define TRS_LAUNCH_ASSEMBLE(GL)                                                                          \
+#define TRS_LAUNCH_ASSEMBLE(GL, NTV)                                                                     \
     do {                                                                                                 \
         if (plan.lds > 48 * 1024)                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_assemble_kernel<GL>),            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_assemble_kernel<GL, NTV>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);        \
-        hipLaunchKernelGGL(trs_assemble_kernel<GL>, dim3(B), dim3(NT), plan.lds, stream, xyz, conn, E,  \
-                           A, loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max, ld,          \
+        hipLaunchKernelGGL((trs_assemble_kernel<GL, NTV>), dim3(B), dim3(NTV), plan.lds, stream, xyz,    \
+                           conn, E, A, loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max, ld, \
                            slab_stride, S, flags, static_cast<unsigned char*>(work),                     \
                            trs_assemble_work_bytes(nJ_max, nM_max, 0), env, plan.WT);                    \
     } while (0)
-    if (plan.geom_in_lds)
-        TRS_LAUNCH_ASSEMBLE(true);
+    if (plan.geom_in_lds && !plan.big)
+        TRS_LAUNCH_ASSEMBLE(true, NT_DEFAULT);
+    else if (plan.geom_in_lds)
+        TRS_LAUNCH_ASSEMBLE(true, NT_BIG);
+    else if (!plan.big)
+        TRS_LAUNCH_ASSEMBLE(false, NT_DEFAULT);
     else
-        TRS_LAUNCH_ASSEMBLE(false);
+        TRS_LAUNCH_ASSEMBLE(false, NT_BIG);
 #undef TRS_LAUNCH_ASSEMBLE
     return (int)hipGetLastError();
 }
