@@ -127,6 +127,7 @@ __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) R[r] = (lq + 4 * r == li) ? 1.0 : 0.0;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const double dq[4] = {lq == 0 ? 1.0 : 0.0, lq == 1 ? 1.0 : 0.0, lq == 2 ? 1.0 : 0.0, lq == 3 ? 1.0 : 0.0};
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int j0 = 4 * b;
@@ -155,12 +156,14 @@ __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
         const double p = lq == 0 ? c[0] : lq == 1 ? c[1] : lq == 2 ? c[2] : c[3];  // L[li][j0+lq]
         if (b < 3) t = mfma_f64_negA(p, p, t);  // rows / columns below j0+4: T -= L[:,blk] L[:,blk]^T
         // column lq of inv(L_bb) by forward substitution on the uniform multipliers: e[k] = M[k][lq]
-        const double e0 = lq == 0 ? rinv[0] : 0.0;
-        const double e1 = (lq == 1 ? rinv[1] : 0.0) - rinv[1] * (m[1][0] * e0);
-        const double e2 = (lq == 2 ? rinv[2] : 0.0) - rinv[2] * (m[2][0] * e0 + m[2][1] * e1);
-        const double e3 = (lq == 3 ? rinv[3] : 0.0) - rinv[3] * (m[3][0] * e0 + m[3][1] * e1 + m[3][2] * e2);
-        const int i = li - j0;
-        const double ma = i == 0 ? e0 : i == 1 ? e1 : i == 2 ? e2 : i == 3 ? e3 : 0.0;  // A: M embedded
+        // (dq[k] = 1 in quarter-wave k, else 0: the unit right-hand side without selects)
+        const double e0 = rinv[0] * dq[0];
+        const double e1 = rinv[1] * fma(-m[1][0], e0, dq[1]);
+        const double e2 = rinv[2] * fma(-m[2][1], e1, fma(-m[2][0], e0, dq[2]));
+        const double e3 = rinv[3] * fma(-m[3][2], e2, fma(-m[3][1], e1, fma(-m[3][0], e0, dq[3])));
+        // A operand: M embedded in rows j0 .. j0+3 (row li - j0 = li & 3 there), zero elsewhere
+        const double e01 = (li & 1) ? e1 : e0, e23 = (li & 1) ? e3 : e2;
+        const double ma = (li >> 2) == b ? ((li & 2) ? e23 : e01) : 0.0;
         const d4 wb = mfma_f64(ma, R[b], zero);  // register b = W[j0+lq][li], the others are zero
         // A-fragment layout of PanelLds::W: wfrag[r*64 + lane'] = W[t = li'][c = 4 r + lq']; the element
         // (t = j0+lq, c = li) held here lands at 16 li + j0 + lq
