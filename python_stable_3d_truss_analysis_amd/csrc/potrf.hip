@@ -120,7 +120,12 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
 
 // Not inlined: ONE copy of this long straight-line routine keeps the kernel's code inside the
 // instruction cache.  The tile travels by value in registers; the pivot status goes through sc.bad.
-__device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
+// The scratch and the fragment buffer arrive as LDS-address-space pointers: through generic pointers
+// the accesses of this non-inlined routine would be FLAT instructions, which are slower than ds_*
+// and also wait on the global-memory counter.
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+__device__ __noinline__ d4 chol16_invert_lds(d4 t, lds_f64* G, lds_i32* bad_out, lds_f64* wfrag) {
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
     unsigned badmask = 0;
     d4 R, u;  // R: running right-hand side of inv(L) (D-form, starts as the identity); u: result
@@ -132,11 +137,11 @@ __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
     for (int b = 0; b < 4; ++b) {
         const int j0 = 4 * b;
         // row-owner copy of the block's 4 columns (by symmetry row j0+q of the D-form tile)
-        sc.G[li][lq] = t[b];
+        G[4 * li + lq] = t[b];
         __builtin_amdgcn_wave_barrier();
         double c[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) c[q] = sc.G[li][q];
+        for (int q = 0; q < 4; ++q) c[q] = G[4 * li + q];
         __builtin_amdgcn_wave_barrier();
         double rinv[4], m[4][4];  // wave-uniform: 1 / L[j0+q][j0+q], L[j0+q2][j0+q]
 #pragma unroll
@@ -173,8 +178,11 @@ __device__ __noinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
         u[b] = (j0 + lq <= li) ? p : wb[b];
         if (b < 3) R = mfma_f64_negA(p, wb[b], R);  // R -= L[:,blk] W[blk,:]
     }
-    if (lane == 0) sc.bad = badmask ? __builtin_ctz(badmask) : -1;
+    if (lane == 0) *bad_out = badmask ? __builtin_ctz(badmask) : -1;
     return u;
+}
+__device__ __forceinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
+    return chol16_invert_lds(t, (lds_f64*)&sc.G[0][0], (lds_i32*)&sc.bad, (lds_f64*)wfrag);
 }
 
 // pair index of a strictly-lower tile (u, s), s < u < 4, and of a lower tile incl. diagonal
