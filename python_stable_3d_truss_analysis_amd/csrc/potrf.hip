@@ -594,24 +594,25 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
                                             const double* Wl, const d4 (&t)[CT][CT]) {
     const int rowbase = 16 * c0, lane = threadIdx.x & 63;
     d4 acc[NV][CT];
-    unsigned vo[NV][CT];
-    bool ex[NV][CT];  // stored tiles; ex[v][s] implies ex[v][s2] for s2 > s (cend is non-decreasing)
+    // cend is non-decreasing: chunk c0+v is stored in the panel's tiles smin[v] .. 3 (one scalar
+    // per chunk instead of a flag and a lane offset per tile: the kernel is short of SGPRs)
+    int smin[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) smin[v] = 0;
 #pragma unroll
     for (int s = 0; s < CT; ++s) {
         const int ce = cend[r0 / 16 + s];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            ex[v][s] = c0 + v < ce;
-            vo[v][s] = S.lane_off(ex[v][s]);
-        }
+        for (int v = 0; v < NV; ++v) smin[v] += c0 + v >= ce ? 1 : 0;
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int s = 0; s < CT; ++s) {
             const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
+            const unsigned vo = S.lane_off(s >= smin[v]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[v][s][r] = S.load_at(vo[v][s], o + r * (S.ld * 32));
+            for (int r = 0; r < 4; ++r) acc[v][s][r] = S.load_at(vo, o + r * (S.ld * 32));
         }
     if (r0 > kstart) {
         int ob = S.at(kstart, r0);
@@ -645,7 +646,7 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int s = 0; s < CT; ++s)  // (branching on ex[v][s] here costs 60 VGPRs; not worth it)
+                    for (int s = 0; s < CT; ++s)  // (branching on the stored-tile test here costs 60 VGPRs)
                         acc[v][s] = mfma_f64_negA(fb[d][s], fa[d][v], acc[v][s]);
             }
             ob += DEPTHN * step;
@@ -656,7 +657,7 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
     for (int s = 0; s < CT; ++s) {
 #pragma unroll
         for (int v = 0; v < NV; ++v)  // tiles outside the envelope are zero and stay zero: no work
-            if (ex[v][s]) {
+            if (s >= smin[v]) {
                 d4 x = d4{0.0, 0.0, 0.0, 0.0};  // X_s^T = inv(L_ss) T_s^T
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + r * 64 + lane], acc[v][s][r], x);
@@ -673,8 +674,9 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
 #pragma unroll
         for (int s = 0; s < CT; ++s) {
             const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
+            const unsigned vo = S.lane_off(s >= smin[v]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S.store_at(vo[v][s], o + r * (S.ld * 32), acc[v][s][r]);
+            for (int r = 0; r < 4; ++r) S.store_at(vo, o + r * (S.ld * 32), acc[v][s][r]);
         }
 }
 
