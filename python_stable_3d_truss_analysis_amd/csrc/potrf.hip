@@ -105,10 +105,13 @@ __device__ __forceinline__ d4 mfma_f64_negA(double a, double b, d4 c) {
 //             below it (read by trs_potrs_kernel; no other reader touches that part)
 //   sc      : LDS scratch (block gather)
 //   wfrag   : receives inv(L) as A-fragments (layout of PanelLds::W[s])
-// Leaves the 0-based index of the first non-positive pivot, or -1, in sc.bad.
+// Returns the tile and the 0-based index of the first non-positive pivot, or -1 (wave-uniform).
 struct ChScratch {
     double G[16][4];  // G[row][q] = T[row][4 b + q] of the running block
-    int bad;          // 0-based index of the first non-positive pivot, or -1
+};
+struct Chol16 {
+    d4 u;
+    int bad;
 };
 
 // 1/sqrt(d) for a wave-uniform positive d: hardware estimate + one third-order correction
@@ -119,13 +122,12 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
 }
 
 // Not inlined: ONE copy of this long straight-line routine keeps the kernel's code inside the
-// instruction cache.  The tile travels by value in registers; the pivot status goes through sc.bad.
+// instruction cache.  The tile and the pivot status travel by value in registers.
 // The scratch and the fragment buffer arrive as LDS-address-space pointers: through generic pointers
 // the accesses of this non-inlined routine would be FLAT instructions, which are slower than ds_*
 // and also wait on the global-memory counter.
 typedef __attribute__((address_space(3))) double lds_f64;
-typedef __attribute__((address_space(3))) int lds_i32;
-__device__ __noinline__ d4 chol16_invert_lds(d4 t, lds_f64* G, lds_i32* bad_out, lds_f64* wfrag) {
+__device__ __noinline__ Chol16 chol16_invert_lds(d4 t, lds_f64* G, lds_f64* wfrag) {
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
     unsigned badmask = 0;
     d4 R, u;  // R: running right-hand side of inv(L) (D-form, starts as the identity); u: result
@@ -178,11 +180,12 @@ __device__ __noinline__ d4 chol16_invert_lds(d4 t, lds_f64* G, lds_i32* bad_out,
         u[b] = (j0 + lq <= li) ? p : wb[b];
         if (b < 3) R = mfma_f64_negA(p, wb[b], R);  // R -= L[:,blk] W[blk,:]
     }
-    if (lane == 0) *bad_out = badmask ? __builtin_ctz(badmask) : -1;
-    return u;
+    return Chol16{u, badmask ? __builtin_ctz(badmask) : -1};
 }
-__device__ __forceinline__ d4 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
-    return chol16_invert_lds(t, (lds_f64*)&sc.G[0][0], (lds_i32*)&sc.bad, (lds_f64*)wfrag);
+__device__ __forceinline__ Chol16 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
+    Chol16 out = chol16_invert_lds(t, (lds_f64*)&sc.G[0][0], (lds_f64*)wfrag);
+    out.bad = __builtin_amdgcn_readfirstlane(out.bad);
+    return out;
 }
 
 // pair index of a strictly-lower tile (u, s), s < u < 4, and of a lower tile incl. diagonal
@@ -336,9 +339,10 @@ __device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelL
     for (int s = 0; s < CT; ++s) {
         if (ok) {
             st.mark(1);
-            t[s][s] = chol16_invert(t[s][s], sm.ch, sm.W(s));
+            const Chol16 f = chol16_invert(t[s][s], sm.ch, sm.W(s));
+            t[s][s] = f.u;
             __builtin_amdgcn_wave_barrier();
-            const int bad = sm.ch.bad;
+            const int bad = f.bad;
             st.mark(7);
             if (bad >= 0) {
                 if (lane == 0) sm.info = r0 + 16 * s + bad + 1;
@@ -773,10 +777,10 @@ __global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narr
 #pragma unroll
         for (int s = 0; s < CT; ++s) {
             if (bad_col == 0) {
-                t[s][s] = chol16_invert(t[s][s], sc, Wl + s * 256);
+                const Chol16 f = chol16_invert(t[s][s], sc, Wl + s * 256);
+                t[s][s] = f.u;
                 __builtin_amdgcn_wave_barrier();
-                const int bad = sc.bad;
-                if (bad >= 0) bad_col = r0 + 16 * s + bad + 1;
+                if (f.bad >= 0) bad_col = r0 + 16 * s + f.bad + 1;
             }
             if (bad_col == 0) {
                 if (s + 1 < CT) {
