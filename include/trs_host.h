@@ -1,0 +1,61 @@
+/*
+ * trs_host.h - host-side native helpers around the batched truss solver (library libtrs_host.so;
+ * plain C + OpenMP over the batch, no GPU).  They feed / drain the device path of trs_solver.h with
+ * the same padded batch arrays (PackedBatch in the Python package):
+ *
+ *   xyz [B][nJ_max][3] f64 | conn [B][nM_max][2] i32 | E, A, rho [B][nM_max] f64 |
+ *   cbits [B][nJ_max] u8 (constrained-axis bits x=1,y=2,z=4) | loads [B][nJ_max][3] f64 | nJ, nM [B] i32
+ *
+ * Reference counterparts: slientruss3d/generate.py (random cube trusses), slientruss3d/data.py
+ * (TrussHeteroDataCreator features); the joint reordering has no counterpart (it only shrinks the
+ * envelope the GPU factorisation works on; results are mapped back by the caller).
+ */
+#ifndef TRS_HOST_H
+#define TRS_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Upper bounds of joints / members for polycubes of at most max_cubes cells on a gx*gy*gz grid. */
+int trs_cubegen_bounds(int gx, int gy, int gz, int max_cubes, int allow_parallel, int *nJ_max, int *nM_max);
+
+/* Random polycube trusses (generate.py:40-246: grow a polycube, link the cube vertices, supports,
+ * loads, member types; count-unstable draws are regenerated).  num_cubes[b] cells for truss b; every
+ * truss has its own RNG stream derived from seed.  With xyz == NULL only nJ[b], nM[b] are produced
+ * (sizes-only pass).  Returns 0, -1 when a truss does not fit nJ_max / nM_max, -2 on allocation failure. */
+int trs_cubegen(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num_cubes, int method,
+                int link_type, int allow_parallel, double len_lo, double len_hi,
+                const double *force_range /* [3][2] */, int nforce_lo, int nforce_hi,
+                const double *mtypes /* [n_types][3] = (a, e, density) */, int n_types, int nJ_max,
+                int nM_max, double *xyz, int32_t *conn, double *E, double *A, double *rho,
+                uint8_t *cbits, double *loads, int32_t *nJ, int32_t *nM, int64_t *retries_out);
+
+/* Reverse Cuthill-McKee order of the joints of every truss: perm[b][k] = old id of the joint that
+ * becomes joint k (identity on the padding).  Returns 0 or -2 on allocation failure. */
+int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint8_t *cbits,
+                  const int32_t *nJ, const int32_t *nM, int32_t *perm /* [B][nJ_max] */);
+
+/* Apply a joint order out of place (members keep their order, their end joints are renumbered). */
+int trs_apply_joint_order(int B, int nJ_max, int nM_max, const int32_t *perm, const int32_t *nM,
+                          const double *xyz, const int32_t *conn, const uint8_t *cbits,
+                          const double *loads, double *xyz_out, int32_t *conn_out, uint8_t *cbits_out,
+                          double *loads_out);
+
+/* Graph features of a solved batch of 3D trusses as float32 tensors (data.py:11-282, GetAngles
+ * utils.py:105-113): joint_x [B][nJ_max][7 (+3 with a prior)], member_x [B][nM_max][8 (+1 prior)
+ * (+1 regression)], joint_y [B][nJ_max][3] and member_y [B][nM_max] (regression only), weight [B].
+ * u_* are [B][nJ_max][3], N_* [B][nM_max]; pass NULL for an absent prior / actual result. */
+int trs_graph_features(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
+                       const double *A, const double *rho, const uint8_t *cbits, const double *loads,
+                       const int32_t *nJ, const int32_t *nM, const double *u_act, const double *N_act,
+                       const double *u_pri, const double *N_pri, double fixedArea, double forceScale,
+                       double displaceScale, double positionScale, int regression, float *joint_x,
+                       float *member_x, float *joint_y, float *member_y, double *weight);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
