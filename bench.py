@@ -113,6 +113,35 @@ def cpu_baseline(data, seconds=15.0):
                       f"host has {os.cpu_count()} logical CPUs"}, ref
 
 
+def _pool_worker(args):
+    data, seconds = args
+    from oracle import truss_oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        pass
+    orc.solve(data)
+    t0, runs = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        orc.solve(data)
+        runs += 1
+    return runs, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(data, seconds=8.0):
+    """The same oracle on every host core at once (one forked single-threaded process per logical CPU,
+    bounded sample).  Must run BEFORE this process touches the GPU: the workers are plain forks."""
+    import multiprocessing as mp
+    n = os.cpu_count() or 1
+    with mp.get_context("fork").Pool(n) as pool:
+        out = pool.map(_pool_worker, [(data, seconds)] * n)
+    runs = sum(r for r, _ in out)
+    dt = max(t for _, t in out)
+    return {"value": runs / dt, "unit": "solves/s", "cores": n, "kind": "port",
+            "sample": f"{runs} oracle.solve() calls on bar-942 by {n} single-threaded processes in {dt:.1f} s"}
+
+
 def cube_batch_rate(device, B, torch, batch):
     """Informational: resident-batch throughput on a mixed GenerateRandomCubeTrusses-like batch
     (native generator, joints renumbered by RCM, bucketed by padded size; BASELINE config 3)."""
@@ -153,6 +182,8 @@ def main():
     ap.add_argument("--case", default="bar-942_input_0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pool-seconds", type=float, default=8.0,
+                    help="sample length of the all-host-cores oracle baseline (0 = skip)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational PCIe-inclusive pass")
     ap.add_argument("--cube-batch", type=int, default=16384,
                     help="size of the informational mixed cube-truss batch (0 = skip)")
@@ -170,6 +201,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    data = load_case(args.case)
+    cpu_all = None
+    if world == 1 and not args.no_cpu_baseline and args.cpu_pool_seconds > 0:
+        try:  # forked workers: only safe while this process has not initialised the GPU
+            cpu_all = cpu_baseline_all_cores(data, args.cpu_pool_seconds)
+        except Exception as exc:  # informational only
+            cpu_all = {"error": repr(exc)}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -184,7 +222,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    data = load_case(args.case)
     packed = batch.pack_json([data]).replicate(args.batch)
     dev = batch.DeviceBatch(packed, device, use_envelope=not args.dense)
     n, nJ, nM = int(packed.n_free[0]), int(packed.nJ[0]), int(packed.nM[0])
@@ -349,6 +386,8 @@ def main():
                 "note": "same kernel with the envelope off: n^3/3 + n^2 FLOP per truss (SURVEY 8d)"}
         if not args.no_cpu_baseline:  # the oracle leg: CPU baseline + check of the GPU result against it
             line["cpu_baseline"], ref = cpu_baseline(data, args.cpu_seconds)
+            if cpu_all is not None:
+                line["cpu_baseline_all_cores"] = cpu_all
             line["max_rel_err_vs_oracle"] = {
                 "u": float(np.abs(res.displace[0, :nJ] - ref["u"]).max() / np.abs(ref["u"]).max()),
                 "N": float(np.abs(res.internal[0, :nM] - ref["N"]).max() / np.abs(ref["N"]).max())}
