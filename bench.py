@@ -154,7 +154,7 @@ def cube_batch_rate(device, B, torch, batch):
     t0 = time.perf_counter()
     packed = batch.permute_joints(packed, batch.rcm_permutation(packed))
     t_rcm = time.perf_counter() - t0
-    groups = batch.size_buckets(packed, 32 << 30)
+    groups = batch.size_buckets(packed, 64 << 30)
     total, bad = 0.0, 0
     for idx in groups:
         sub = batch.DeviceBatch(packed.take(idx).trimmed(), device)

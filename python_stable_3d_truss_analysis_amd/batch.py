@@ -338,7 +338,7 @@ def permute_joints(packed: PackedBatch, perm):
                        packed.dim, packed.n_free)
 
 
-def size_buckets(packed: PackedBatch, max_slab_bytes=32 << 30):
+def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30):
     """Group the trusses of a ragged batch for launching: same padded system size n_pad per group
     (the slab and every work-group of a launch are then uniform) and at most `max_slab_bytes` of
     stiffness slab per launch.  Returns a list of index arrays (their union is range(B))."""
@@ -352,7 +352,7 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=32 << 30):
     return groups
 
 
-def solve_batch(trusses_or_packed, device=None, max_slab_bytes=32 << 30, reorder=False):
+def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
 
     A ragged batch is bucketed by padded system size (`size_buckets`): one launch pipeline per

@@ -24,7 +24,7 @@ from python_stable_3d_truss_analysis_amd import generate as gen
 from python_stable_3d_truss_analysis_amd.ga import GA
 
 
-def config3(B, out, reorder, key):
+def config3(B, out, reorder, key, slab_gb=48):
     rng = np.random.default_rng(0)
     t0 = time.perf_counter()
     packed = gen.generate_cube_batch(rng.integers(8, 191, size=B), gridRange=(6, 6, 6), seed=7)
@@ -34,7 +34,7 @@ def config3(B, out, reorder, key):
         t0 = time.perf_counter()
         packed = batch.permute_joints(packed, batch.rcm_permutation(packed))
         t_rcm = time.perf_counter() - t0
-    groups = batch.size_buckets(packed, 48 << 30)
+    groups = batch.size_buckets(packed, int(slab_gb) << 30)
     subs = [packed.take(i).trimmed() for i in groups]
     torch.cuda.synchronize()
     total_gpu = 0.0
@@ -73,14 +73,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cubes", type=int, default=65536)
     ap.add_argument("--only", choices=("ga", "generator", "rcm"), help="run one configuration only")
+    ap.add_argument("--slab-gb", type=int, default=48, help="stiffness-slab memory per launch pipeline")
     args = ap.parse_args()
     out = {}
     if args.only in (None, "ga"):
         config4(out)
     if args.only in (None, "generator"):
-        config3(args.cubes, out, False, "config3_generator_order")
+        config3(args.cubes, out, False, "config3_generator_order", args.slab_gb)
     if args.only in (None, "rcm"):
-        config3(args.cubes, out, True, "config3_rcm_order")
+        config3(args.cubes, out, True, "config3_rcm_order", args.slab_gb)
     print(json.dumps(out))
 
 
