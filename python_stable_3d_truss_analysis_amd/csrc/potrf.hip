@@ -684,16 +684,20 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
         }
 }
 
-__global__ __launch_bounds__(256, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narrow_kernel(
+#ifndef TRS_NARROW_MATRICES_PER_WG
+#define TRS_NARROW_MATRICES_PER_WG 4
+#endif
+constexpr int MPW = TRS_NARROW_MATRICES_PER_WG;  // waves (= matrices) per work-group of the narrow kernel
+__global__ __launch_bounds__(64 * MPW, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narrow_kernel(
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
     int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max, const int B) {
-    __shared__ ChScratch scratch[4];
-    __shared__ double wlds[4][CT][256];  // per wave: inv(L_ss), s = 0..3, as A-fragments (PanelLds::W layout)
-    __shared__ double ylds[4][CT][4][4];  // per wave: the load column (lanes li == 0 of its tiles), parked
+    __shared__ ChScratch scratch[MPW];
+    __shared__ double wlds[MPW][CT][256];  // per wave: inv(L_ss), s = 0..3, as A-fragments (PanelLds::W layout)
+    __shared__ double ylds[MPW][CT][4][4];  // per wave: the load column (lanes li == 0 of its tiles), parked
                                           // during the factorisation
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
+    const int b = blockIdx.x * MPW + wave;
     if (b >= B) return;  // no work-group barrier anywhere in this kernel: waves are independent
     const int npad = trs_round_up(n_free[b], TRS_NB);
     if (npad == 0) {
@@ -872,7 +876,7 @@ extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_st
     // the offset range being the "tile not stored" marker (Slab::gone)
     if (slab_stride * sizeof(double) >= (size_t)1 << 31) return (int)hipErrorInvalidValue;
     if (env != nullptr) {
-        hipLaunchKernelGGL(trs_potrf_narrow_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, S, n_free, ld,
+        hipLaunchKernelGGL(trs_potrf_narrow_kernel, dim3((B + MPW - 1) / MPW), dim3(64 * MPW), 0, stream, S, n_free, ld,
                            slab_stride, info, env, n_pad_max, B);
         const int rc = (int)hipGetLastError();
         if (rc) return rc;
