@@ -342,6 +342,11 @@ def main():
         else:
             roofline.update(bound="hbm", achieved=potrf_gbs, peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=hbm_frac)
+        def hbm_stage(stage, bytes_per_truss):  # algorithmic bytes of a stage against the HBM roof
+            gbs = bytes_per_truss * args.batch / (stage_ms[stage] * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": gbs / PEAK_HBM_GBS, "bytes_per_truss": bytes_per_truss}
+
         line = {
             "metric": "truss solves/sec (batched Solve)",
             "value": total_trusses / elapsed,
@@ -366,6 +371,8 @@ def main():
                                   "note": "bytes of the slab part that is stored (upper 16-row tiles inside the "
                                           "envelope + load column) + inputs; the full symmetric dense "
                                           f"figure of SURVEY 8d would be {counts['assemble_bytes_full_contract']} B"},
+            "potrs_roofline": hbm_stage("potrs", counts["potrs_bytes"]),
+            "recover_roofline": hbm_stage("recover", counts["recover_bytes"]),
             "info_nonzero": int((res.info != 0).sum()),
             "envelope": not args.dense,
         }
