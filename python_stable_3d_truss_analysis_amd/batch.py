@@ -172,22 +172,36 @@ class DeviceBatch:
     Build once, call `solve()` any number of times (e.g. after `set_sections`).  Every tensor
     lives on one device; kernels run on the current stream of that device.
     """
+    INPUT_FIELDS = ("xyz", "conn", "E", "A", "rho", "cbits", "loads", "nJ", "nM")
 
     def __init__(self, packed: PackedBatch, device=None, use_envelope=True):
         """`use_envelope=False` treats every reduced stiffness matrix as dense (no tile skipping)."""
         torch, dev = _require_gpu(device)
-        self.torch, self.device, self.packed = torch, dev, packed
-        self.lib = _capi.load()
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        self.B, self.nJ_max, self.nM_max = packed.B, packed.nJ_max, packed.nM_max
-        self.xyz, self.conn = up(packed.xyz), up(packed.conn)
-        self.E, self.A, self.rho = up(packed.E), up(packed.A), up(packed.rho)
-        self.cbits, self.loads = up(packed.cbits), up(packed.loads)
-        self.nJ, self.nM = up(packed.nJ), up(packed.nM)
-        self.n_max = packed.n_max
+        self.packed = packed
+        self._setup(torch, dev, {f: up(getattr(packed, f)) for f in self.INPUT_FIELDS},
+                    packed.B, packed.nJ_max, packed.nM_max, packed.n_max, use_envelope)
+
+    @classmethod
+    def from_device(cls, tensors, n_max, use_envelope=True):
+        """A batch whose inputs already live on the device: `tensors` maps INPUT_FIELDS to contiguous
+        device tensors of the padded shapes (see PackedBatch); `n_max` bounds the free DOFs per truss
+        (host-known, it sizes the slab)."""
+        torch, dev = _require_gpu(tensors["xyz"].device)
+        self = cls.__new__(cls)
+        self.packed = None
+        self._setup(torch, dev, tensors, int(tensors["xyz"].shape[0]), int(tensors["xyz"].shape[1]),
+                    int(tensors["conn"].shape[1]), int(n_max), use_envelope)
+        return self
+
+    def _setup(self, torch, dev, tensors, B, nJ_max, nM_max, n_max, use_envelope):
+        self.torch, self.device = torch, dev
+        self.lib = _capi.load()
+        self.B, self.nJ_max, self.nM_max, self.n_max = B, nJ_max, nM_max, n_max
+        for f in self.INPUT_FIELDS:
+            setattr(self, f, tensors[f])
         self.ld = self.lib.trs_slab_ld(self.n_max)
         self.rows = self.lib.trs_slab_rows(self.n_max)
-        B = self.B
         self.free_index = torch.empty([B, self.nJ_max * 3], dtype=torch.int32, device=dev)
         self.n_free = torch.empty([B], dtype=torch.int32, device=dev)
         self.S = torch.empty([B, self.rows, self.ld], dtype=torch.float64, device=dev)
@@ -262,8 +276,6 @@ class DeviceBatch:
             self.u.data_ptr(), self.N.data_ptr(), float(allow_stress), float(allow_displace),
             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), self._stream()), "trs_fitness")
         return out
-
-    INPUT_FIELDS = ("xyz", "conn", "E", "A", "rho", "cbits", "loads", "nJ", "nM")
 
     def pinned_inputs(self, packed: PackedBatch):
         """Page-locked host copies of a batch's inputs (same padded shapes as this device batch)."""
@@ -355,35 +367,67 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30):
 def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
 
-    A ragged batch is bucketed by padded system size (`size_buckets`): one launch pipeline per
-    bucket, inputs trimmed to the bucket's own maxima, results scattered back to batch order.
-    `reorder=True` renumbers the joints of every truss by reverse Cuthill-McKee first (results come
-    back in the original numbering): worth it when the trusses are not numbered along their long
-    axis, e.g. generated cube trusses."""
+    The packed inputs go up once; a ragged batch is bucketed by padded system size
+    (`size_buckets`) and every bucket is gathered, solved and scattered back ON THE DEVICE
+    (`index_select` / `index_copy_`), inputs trimmed to the bucket's own maxima; the dense results come
+    down once.  `reorder=True` renumbers the joints of every truss by reverse Cuthill-McKee first
+    (the order is found on the host, natively; inputs are permuted and results mapped back on the
+    device): worth it when the trusses are not numbered along their long axis, e.g. generated cube
+    trusses."""
     packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
         else pack_trusses(list(trusses_or_packed))
+    torch, dev = _require_gpu(device)
+    B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+    full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS}
+    perm = None
     if reorder:
-        perm = rcm_permutation(packed)
-        res = solve_batch(permute_joints(packed, perm), device, max_slab_bytes, reorder=False)
-        rows = np.arange(packed.B)[:, None]
-        displace, external = np.empty_like(res.displace), np.empty_like(res.external)
-        displace[rows, perm], external[rows, perm] = res.displace, res.external
-        return BatchResult(displace, external, res.internal, res.info)
+        perm = up(rcm_permutation(packed).astype(np.int64))                  # [B, nJ_max], joint k := old perm[k]
+        inverse = torch.empty_like(perm)
+        inverse.scatter_(1, perm, torch.arange(nJ_max, device=dev).expand(B, -1))
+        by_joint = perm[:, :, None].expand(-1, -1, 3)
+        full["xyz"] = full["xyz"].gather(1, by_joint)
+        full["loads"] = full["loads"].gather(1, by_joint)
+        full["cbits"] = full["cbits"].gather(1, perm)
+        conn = inverse.gather(1, full["conn"].long().reshape(B, -1)).reshape(B, nM_max, 2)
+        live = torch.arange(nM_max, device=dev)[None, :, None] < full["nM"].long()[:, None, None]
+        full["conn"] = (conn * live).to(torch.int32)
     groups = size_buckets(packed, max_slab_bytes)
-    if len(groups) <= 1:
-        dev = DeviceBatch(packed, device)
-        dev.solve()
-        return dev.result()
-    out = BatchResult(np.zeros([packed.B, packed.nJ_max, 3]), np.zeros([packed.B, packed.nJ_max, 3]),
-                      np.zeros([packed.B, packed.nM_max]), np.zeros([packed.B], dtype=np.int32))
-    for idx in groups:
-        sub = packed.take(idx).trimmed()
-        dev = DeviceBatch(sub, device)
-        dev.solve()
-        res = dev.result()
-        out.displace[idx, :sub.nJ_max] = res.displace
-        out.external[idx, :sub.nJ_max] = res.external
-        out.internal[idx, :sub.nM_max] = res.internal
-        out.info[idx] = res.info
-        del dev
-    return out
+    # largest slab first: the caching allocator then serves every later bucket from the first
+    # bucket's block instead of growing the pool bucket by bucket
+    n_pad_of = lambda idx: (int(packed.n_free[idx].max()) + 63) // 64 * 64
+    groups.sort(key=lambda idx: -len(idx) * n_pad_of(idx) * (n_pad_of(idx) + 16))
+    if len(groups) == 1 and len(groups[0]) == B:
+        bucket = DeviceBatch.from_device(full, packed.n_max)
+        bucket.solve()
+        u, f_ext, N, info = bucket.u, bucket.f_ext, bucket.N, bucket.info
+    else:
+        u = torch.zeros([B, nJ_max, 3], dtype=torch.float64, device=dev)
+        f_ext = torch.zeros_like(u)
+        N = torch.zeros([B, nM_max], dtype=torch.float64, device=dev)
+        info = torch.zeros([B], dtype=torch.int32, device=dev)
+        joint_fields = ("xyz", "cbits", "loads")
+        for idx in groups:
+            rows = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(dev)
+            nJ_b = max(1, int(packed.nJ[idx].max()))
+            nM_b = max(1, int(packed.nM[idx].max()))
+            sub = {}
+            for f in DeviceBatch.INPUT_FIELDS:
+                t = full[f].index_select(0, rows)
+                if f in ("nJ", "nM"):
+                    sub[f] = t
+                else:  # trimmed to the bucket's own maxima
+                    sub[f] = t[:, :(nJ_b if f in joint_fields else nM_b)].contiguous()
+            bucket = DeviceBatch.from_device(sub, int(packed.n_free[idx].max()))
+            bucket.solve()
+            u[:, :nJ_b].index_copy_(0, rows, bucket.u)
+            f_ext[:, :nJ_b].index_copy_(0, rows, bucket.f_ext)
+            N[:, :nM_b].index_copy_(0, rows, bucket.N)
+            info.index_copy_(0, rows, bucket.info)
+            del bucket
+    if perm is not None:  # back to the caller's joint numbering
+        by_joint = perm[:, :, None].expand(-1, -1, 3)
+        u = torch.zeros_like(u).scatter_(1, by_joint, u)
+        f_ext = torch.zeros_like(f_ext).scatter_(1, by_joint, f_ext)
+    torch.cuda.synchronize(dev)
+    return BatchResult(u.cpu().numpy(), f_ext.cpu().numpy(), N.cpu().numpy(), info.cpu().numpy())
