@@ -215,19 +215,19 @@ def hetero_tensors_batch(packed: PackedBatch, actual: BatchResult, prior: BatchR
     return graphs
 
 
-def solve_actual_and_prior(packed: PackedBatch, fixedMemberType=None, device=None):
+def solve_actual_and_prior(packed: PackedBatch, fixedMemberType=None, device=None, reorder=False):
     """The two batched GPU solves behind a dataset: real sections, then every member set to
-    `fixedMemberType` (reference `data.py:107-114`).  Geometry stays resident between the two."""
-    from .batch import DeviceBatch
-    dev = DeviceBatch(packed, device)
-    dev.solve()
-    actual = dev.result()
+    `fixedMemberType` (reference `data.py:107-114`).  Both go through `solve_batch`, i.e. ragged
+    batches are bucketed by size with bounded slab memory."""
+    import dataclasses
+    from .batch import solve_batch
+    actual = solve_batch(packed, device, reorder=reorder)
     prior = None
     if fixedMemberType is not None:
         ones = np.ones_like(packed.A)
-        dev.set_sections(ones * fixedMemberType.a, ones * fixedMemberType.e, ones * fixedMemberType.density)
-        dev.solve()
-        prior = dev.result()
+        fixed = dataclasses.replace(packed, A=ones * fixedMemberType.a, E=ones * fixedMemberType.e,
+                                    rho=ones * fixedMemberType.density)
+        prior = solve_batch(fixed, device, reorder=reorder)
     return actual, prior
 
 
