@@ -69,10 +69,31 @@ def config4(out):
     out["config4"] = {"nPop": 1024, "generation_eval_s": dt, "fitness_evals_per_s": 1024 / dt}
 
 
+def config5(B, out):
+    """Dataset sample = generate -> two batched solves (actual + fixed section) -> graph tensors."""
+    from python_stable_3d_truss_analysis_amd import data as gdata
+    from python_stable_3d_truss_analysis_amd.type import TaskType
+    rng = np.random.default_rng(1)
+    t0 = time.perf_counter()
+    packed = gen.generate_cube_batch(rng.integers(8, 191, size=B), gridRange=(6, 6, 6), seed=11)
+    t1 = time.perf_counter()
+    fixed = MemberType(1., 1e7, 0.1)
+    gdata.solve_actual_and_prior(packed.take(np.arange(min(B, 256))), fixed, reorder=True)   # warm
+    t2 = time.perf_counter()
+    actual, prior = gdata.solve_actual_and_prior(packed, fixed, reorder=True)
+    t3 = time.perf_counter()
+    graphs = gdata.hetero_tensors_batch(packed, actual, prior, fixed.a, TaskType.REGRESSION)
+    t4 = time.perf_counter()
+    out["config5"] = {"B": B, "generate_s": t1 - t0, "two_solves_end_to_end_s": t3 - t2, "graphs_s": t4 - t3,
+                      "samples_per_s": B / ((t1 - t0) + (t3 - t2) + (t4 - t3)), "graphs": len(graphs),
+                      "info_nonzero": int((actual.info != 0).sum() + (prior.info != 0).sum())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cubes", type=int, default=65536)
-    ap.add_argument("--only", choices=("ga", "generator", "rcm"), help="run one configuration only")
+    ap.add_argument("--only", choices=("ga", "generator", "rcm", "dataset"), help="run one configuration only")
+    ap.add_argument("--samples", type=int, default=16384, help="dataset samples of config 5")
     ap.add_argument("--slab-gb", type=int, default=48, help="stiffness-slab memory per launch pipeline")
     args = ap.parse_args()
     out = {}
@@ -80,6 +101,8 @@ def main():
         config4(out)
     if args.only in (None, "generator"):
         config3(args.cubes, out, False, "config3_generator_order", args.slab_gb)
+    if args.only in (None, "dataset"):
+        config5(args.samples, out)
     if args.only in (None, "rcm"):
         config3(args.cubes, out, True, "config3_rcm_order", args.slab_gb)
     print(json.dumps(out))
