@@ -53,7 +53,12 @@ __host__ __device__ inline AsmLds asm_lds_layout(int nJ_max, int nM_max, int n_p
     return l;
 }
 
-template <bool GEOM_IN_LDS, int NT>  // a compile-time address space for k, c: LDS loads, not flat ones
+// MODE fixes, at compile time, the address space of the per-truss tables (LDS loads, not flat ones):
+//   0  everything in LDS                              (bar-942: 64 KB + the row tile)
+//   1  member geometry in the truss's workspace, the rest in LDS
+//   2  everything but the row tile in the workspace   (trusses whose tables exceed a CU's LDS:
+//      more than ~7000 members; the tables then live in L2 / HBM and the kernel is slower)
+template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
     const double* __restrict__ A, const double* __restrict__ loads,
@@ -63,7 +68,6 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     unsigned char* __restrict__ work_all, const size_t work_stride, int* __restrict__ env_all,
     const int WT) {
     extern __shared__ unsigned char lds_raw[];
-    constexpr int geom_in_lds = GEOM_IN_LDS ? 1 : 0;
     constexpr int TR = tile_rows(NT);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nJ = nJ_arr[b], nM = nM_arr[b];
@@ -72,20 +76,25 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     if (npad == 0) return;
     const int nch = npad / 16;
 
-    const AsmLds lay = asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, geom_in_lds, TR);
-    // member geometry: in LDS when it fits, else in the truss's workspace (stays in L2)
-    double* mk;  // [nM_max] E A / L
-    if constexpr (GEOM_IN_LDS)
-        mk = reinterpret_cast<double*>(lds_raw + lay.geom);
+    const AsmLds lay = asm_lds_layout(nJ_max, nM_max, n_pad_max, MODE == 2 ? -16 : WT, MODE != 1, TR);
+    unsigned char* wbase = work_all + (size_t)b * work_stride;
+    unsigned char* tb;  // base of the tables
+    if constexpr (MODE == 2)
+        tb = wbase;
     else
-        mk = reinterpret_cast<double*>(work_all + (size_t)b * work_stride);
-    double* mc = mk + nM_max;                                        // [nM_max][3] direction cosines
-    double* diag = reinterpret_cast<double*>(lds_raw + lay.diag);    // diagonal 3x3 block per joint
-    double* rhs = reinterpret_cast<double*>(lds_raw + lay.rhs);      // reduced load vector (a global load
-                                                                     // in the row loop would have to wait
-                                                                     // for the stores queued before it)
-    double* T = reinterpret_cast<double*>(lds_raw + lay.tile);       // row tile
-    int* fi = reinterpret_cast<int*>(lds_raw + lay.ints);            // [3 nJ_max] free index per DOF
+        tb = lds_raw;
+    double* mk;  // [nM_max] E A / L
+    if constexpr (MODE == 1)
+        mk = reinterpret_cast<double*>(wbase);
+    else
+        mk = reinterpret_cast<double*>(tb + lay.geom);
+    double* mc = mk + nM_max;                                   // [nM_max][3] direction cosines
+    double* diag = reinterpret_cast<double*>(tb + lay.diag);    // diagonal 3x3 block per joint
+    double* rhs = reinterpret_cast<double*>(tb + lay.rhs);      // reduced load vector (in LDS: a global
+                                                                // load in the row loop would have to wait
+                                                                // for the stores queued before it)
+    double* T = reinterpret_cast<double*>(lds_raw + (MODE == 2 ? 0 : lay.tile));  // row tile, always LDS
+    int* fi = reinterpret_cast<int*>(tb + lay.ints);            // [3 nJ_max] free index per DOF
     int* cnt = fi + 3 * nJ_max;                                      // [nJ_max]   joint degree
     int* start = cnt + nJ_max;                                       // [nJ_max+1] exclusive scan
     int* fill = start + nJ_max + 1;                                  // [nJ_max]   fill cursor
@@ -348,16 +357,18 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     }
 }
 
-// tile width, geometry placement and work-group size for a batch shape; WT = 0 when nothing fits
+// tile width, table placement (kernel MODE) and work-group size for a batch shape
 struct AsmPlan {
-    int WT, geom_in_lds, big;
-    size_t lds;
+    int WT, mode, big;
+    size_t lds, work;  // LDS per work-group, workspace bytes per truss
 };
 inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
-    // Member geometry in LDS first - two 512-thread work-groups per CU (80 KiB each), else one
-    // 1024-thread work-group with the whole 160 KiB: a global load in the row loop has to wait for
+    // Tables and member geometry in LDS first - two 512-thread work-groups per CU (80 KiB each), else
+    // one 1024-thread work-group with the whole 160 KiB: a global load in the row loop has to wait for
     // every store queued before it (one vmcnt counter), which costs far more than anything else.
-    // Geometry in the workspace only when even a whole CU's LDS cannot hold it.
+    // Geometry in the workspace only when even a whole CU's LDS cannot hold it, and everything but
+    // the row tile there when the tables alone do not fit.
+    const size_t geom_bytes = ((size_t)(nM_max < 1 ? 1 : nM_max) * 32 + 255) / 256 * 256;
     for (int g = 1; g >= 0; --g) {
         for (int big = 0; big <= 1; ++big) {
             const size_t budget = big ? 160 * 1024 : 80 * 1024;
@@ -367,18 +378,20 @@ inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
             int WT = (int)((budget - fixed) / (TR * 8)) - 16;
             WT = WT / 16 * 16;
             if (WT > n_pad_max) WT = n_pad_max;
-            return AsmPlan{WT, g, big, asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, g, TR).total};
+            return AsmPlan{WT, g ? 0 : 1, big, asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, g, TR).total,
+                           geom_bytes};
         }
     }
-    return AsmPlan{0, 0, 0, 0};
+    const int TR = tile_rows(NT_DEFAULT);
+    const int WT = n_pad_max < 240 ? n_pad_max : 240;  // 64 KiB of tile: two work-groups per CU
+    const size_t tables = asm_lds_layout(nJ_max, nM_max, n_pad_max, -16, 1, TR).total;
+    return AsmPlan{WT, 2, 0, (size_t)TR * (WT + 16) * 8, (tables + 255) / 256 * 256};
 }
 
 }  // namespace
 
 extern "C" size_t trs_assemble_work_bytes(int nJ_max, int nM_max, int n_max) {
-    (void)nJ_max;
-    (void)n_max;
-    return ((size_t)(nM_max < 1 ? 1 : nM_max) * 32 + 255) / 256 * 256;  // member geometry fallback
+    return asm_plan(nJ_max, nM_max, trs_round_up(n_max < 1 ? 1 : n_max, TRS_NB)).work;
 }
 
 extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
@@ -387,27 +400,29 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
                                    const int* nM, int ld, size_t slab_stride, int n_pad_max,
                                    double* S, int flags, void* work, int* env, hipStream_t stream) {
     if (B <= 0 || n_pad_max <= 0) return 0;
-    if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;  // packed adjacency keys
+    // adjacency keys: other joint (16 bits) | member (16 bits)
+    if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;
     const AsmPlan plan = asm_plan(nJ_max, nM_max, n_pad_max);
-    if (plan.WT <= 0) return (int)hipErrorInvalidValue;
-#define TRS_LAUNCH_ASSEMBLE(GL, NTV)                                                                     \
+#define TRS_LAUNCH_ASSEMBLE(MODE, NTV)                                                                   \
     do {                                                                                                 \
         if (plan.lds > 48 * 1024)                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_assemble_kernel<GL, NTV>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_assemble_kernel<MODE, NTV>),     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);        \
-        hipLaunchKernelGGL((trs_assemble_kernel<GL, NTV>), dim3(B), dim3(NTV), plan.lds, stream, xyz,    \
+        hipLaunchKernelGGL((trs_assemble_kernel<MODE, NTV>), dim3(B), dim3(NTV), plan.lds, stream, xyz,  \
                            conn, E, A, loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max, ld, \
-                           slab_stride, S, flags, static_cast<unsigned char*>(work),                     \
-                           trs_assemble_work_bytes(nJ_max, nM_max, 0), env, plan.WT);                    \
+                           slab_stride, S, flags, static_cast<unsigned char*>(work), plan.work, env,     \
+                           plan.WT);                                                                     \
     } while (0)
-    if (plan.geom_in_lds && !plan.big)
-        TRS_LAUNCH_ASSEMBLE(true, NT_DEFAULT);
-    else if (plan.geom_in_lds)
-        TRS_LAUNCH_ASSEMBLE(true, NT_BIG);
+    if (plan.mode == 2)
+        TRS_LAUNCH_ASSEMBLE(2, NT_DEFAULT);
+    else if (plan.mode == 0 && !plan.big)
+        TRS_LAUNCH_ASSEMBLE(0, NT_DEFAULT);
+    else if (plan.mode == 0)
+        TRS_LAUNCH_ASSEMBLE(0, NT_BIG);
     else if (!plan.big)
-        TRS_LAUNCH_ASSEMBLE(false, NT_DEFAULT);
+        TRS_LAUNCH_ASSEMBLE(1, NT_DEFAULT);
     else
-        TRS_LAUNCH_ASSEMBLE(false, NT_BIG);
+        TRS_LAUNCH_ASSEMBLE(1, NT_BIG);
 #undef TRS_LAUNCH_ASSEMBLE
     return (int)hipGetLastError();
 }

@@ -134,3 +134,19 @@ def test_large_cube_trusses_on_gpu():
     nJ, nM = int(p.nJ[b]), int(p.nM[b])
     assert H.max_scaled_err(res.displace[b, :nJ], ref["u"]) <= 1e-7
     assert H.max_scaled_err(rcm.internal[b, :nM], ref["N"]) <= 1e-7
+
+
+@pytest.mark.gpu
+def test_truss_whose_assembly_tables_exceed_the_lds_on_gpu():
+    """~10 000 members / ~4 700 free DOFs: the adjacency and joint tables of the assembly no longer
+    fit a CU's LDS and live in the workspace (kernel MODE 2); generator and RCM order vs the oracle."""
+    p = gen.generate_cube_batch([950, 30], gridRange=(12, 12, 12), seed=3)
+    assert int(p.nM.max()) > 9000 and int(p.n_free.max()) > 4000
+    ref = orc.solve(gen.packed_to_json(p, 0))
+    nJ, nM = int(p.nJ[0]), int(p.nM[0])
+    for reorder in (False, True):
+        res = batch.solve_batch(p, reorder=reorder)
+        assert not res.info.any()
+        assert H.max_scaled_err(res.displace[0, :nJ], ref["u"]) <= 1e-8
+        assert H.max_scaled_err(res.internal[0, :nM], ref["N"]) <= 1e-8
+        assert H.max_scaled_err(res.external[0, :nJ], ref["f_ext"]) <= 1e-8
