@@ -5,6 +5,8 @@
 // (N c on joint1, -N c on joint0) instead of a dense K[~mask,:] @ u.
 //
 // Also the constraint reductions the GA fitness needs (truss.py:166-168,429-462; ga.py:139-149).
+#include <cstdlib>
+
 #include "trs_common.h"
 
 namespace {
@@ -27,6 +29,9 @@ __device__ __forceinline__ MemberGeom member_geom(const double* X, int j0, int j
     return g;
 }
 
+// STAGED: u and f_ext of the truss are staged in LDS (gathers and the reaction sums stay on chip);
+// for trusses with more than ~3400 joints they live directly in the output arrays instead.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void trs_recover_kernel(
     const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
     const double* __restrict__ A, const double* __restrict__ loads,
@@ -36,8 +41,14 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     extern __shared__ double sh[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int ndof = 3 * nJ[b], ndof_max = 3 * nJ_max;
-    double* u = sh;              // [ndof_max]
-    double* f = sh + ndof_max;   // [ndof_max]
+    double *u, *f;  // [ndof_max] each
+    if constexpr (STAGED) {
+        u = sh;
+        f = sh + ndof_max;
+    } else {
+        u = u_out + (size_t)b * ndof_max;
+        f = f_out + (size_t)b * ndof_max;
+    }
     const int* fi = free_index + (size_t)b * ndof_max;
     const double* F = loads + (size_t)b * ndof_max;
     const double* ufb = uf + (size_t)b * ld_uf;
@@ -46,6 +57,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         u[d] = r >= 0 ? ufb[r] : 0.0;
         f[d] = r >= 0 ? F[d] : 0.0;  // constrained: reaction accumulated below (load ignored)
     }
+    if constexpr (!STAGED) __threadfence_block();
     __syncthreads();
     const double* X = xyz + (size_t)b * ndof_max;
     const int members = nM[b];
@@ -68,10 +80,12 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         }
         N_out[mm] = axial;
     }
-    __syncthreads();
-    for (int d = tid; d < ndof_max; d += 256) {
-        u_out[(size_t)b * ndof_max + d] = u[d];
-        f_out[(size_t)b * ndof_max + d] = d < ndof ? f[d] : 0.0;
+    if constexpr (STAGED) {
+        __syncthreads();
+        for (int d = tid; d < ndof_max; d += 256) {
+            u_out[(size_t)b * ndof_max + d] = u[d];
+            f_out[(size_t)b * ndof_max + d] = d < ndof ? f[d] : 0.0;
+        }
     }
 }
 
@@ -133,11 +147,16 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
                                   hipStream_t stream) {
     if (B <= 0) return 0;
     const size_t lds = (size_t)6 * nJ_max * sizeof(double);
-    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    const char* force = getenv("TRS_DEBUG_RECOVER_UNSTAGED");  // tests: the large-truss path at any size
+    if (lds > 160 * 1024 || (force != nullptr && force[0] == '1')) {
+        hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), 0, stream, xyz, conn, E, A, loads,
+                           free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N);
+        return (int)hipGetLastError();
+    }
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_recover_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_recover_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(trs_recover_kernel, dim3(B), dim3(256), lds, stream, xyz, conn, E, A, loads,
+    hipLaunchKernelGGL(trs_recover_kernel<true>, dim3(B), dim3(256), lds, stream, xyz, conn, E, A, loads,
                        free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N);
     return (int)hipGetLastError();
 }

@@ -326,3 +326,19 @@ def test_every_system_size_around_the_tile_and_panel_boundaries(gpu):
             assert H.max_scaled_err(res.external[b, :nJ, :2], ref["f_ext"]) <= 1e-8, (b, reorder)
             assert H.max_scaled_err(res.internal[b, :nM], ref["N"]) <= 1e-8, (b, reorder)
             assert not res.displace[b, :nJ, 2].any()   # a 2D truss never moves in z
+
+
+def test_recover_without_lds_staging_matches(gpu, monkeypatch):
+    """The recovery kernel's path for trusses with more than ~3400 joints (u and f_ext live in the
+    output arrays instead of LDS), forced at bar-942 size: same displacements and member forces,
+    reactions equal up to the order of the atomic sums."""
+    data = H.load_json("bar-942_input_0")
+    dev = _device_batch(gpu, [data, data, data])
+    dev.solve()
+    ref = dev.result()
+    monkeypatch.setenv("TRS_DEBUG_RECOVER_UNSTAGED", "1")
+    dev.recover()
+    got = dev.result()
+    np.testing.assert_array_equal(got.displace, ref.displace)
+    np.testing.assert_array_equal(got.internal, ref.internal)
+    assert np.abs(got.external - ref.external).max() <= 1e-12 * np.abs(ref.external).max()

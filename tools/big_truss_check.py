@@ -1,14 +1,19 @@
+#!/usr/bin/env python3
+"""Very large single trusses (beyond the LDS tables of the assembly, beyond the LDS staging of the recovery)
+against the oracle: tools/big_truss_check.py [grid] [cubes...]."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from python_stable_3d_truss_analysis_amd import batch, generate as gen
 from oracle import truss_oracle as orc
-p = gen.generate_cube_batch([1200, 900, 40], gridRange=(12, 12, 12), seed=3)
+grid = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+cubes = [int(a) for a in sys.argv[2:]] or [1200, 900, 40]
+p = gen.generate_cube_batch(cubes, gridRange=(grid, grid, grid), seed=3)
 print("nJ", p.nJ, "nM", p.nM, "n_free", p.n_free)
 for reorder in (False, True):
     t0 = time.perf_counter(); res = batch.solve_batch(p, reorder=reorder); dt = time.perf_counter() - t0
     print("reorder", reorder, "info", res.info, "time", round(dt, 3))
-    for b in (0, 1, 2):
+    for b in range(p.B):
         ref = orc.solve(gen.packed_to_json(p, b))
         nJ, nM = int(p.nJ[b]), int(p.nM[b])
         eu = np.abs(res.displace[b, :nJ] - ref["u"]).max() / np.abs(ref["u"]).max()
