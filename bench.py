@@ -173,6 +173,22 @@ def cube_batch_rate(device, B, torch, batch):
             "note": "inputs resident, one launch pipeline per size bucket; informational, not the headline"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) with
+    torch.distributed.run as a CHILD process and pass its output and exit code through.  This process
+    has made no GPU call at this point (and never replaces itself with exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,7 +207,12 @@ def main():
                     help="treat every stiffness matrix as dense (no envelope tile skipping)")
     ap.add_argument("--no-dense-ref", action="store_true",
                     help="skip the dense-mode reference measurement of the factorisation (profiling runs)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than visible GPUs (ranks share devices round-robin; for testing "
+                         "the multi-rank path on a 1-GPU box - the line then reports the devices really used)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -210,12 +231,36 @@ def main():
             cpu_all = {"error": repr(exc)}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if world > ndev and not args.oversubscribe:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} visible GPU(s) (one process per GPU; "
+                         "--oversubscribe shares devices for testing)")
+    dev_index = local_rank % ndev
+    n_devices_used = min(world, ndev)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    timing_group = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        # The group carries ONLY the barrier around the timed region and the max-over-ranks of the
+        # elapsed time (no collective on the data path).  RCCL (backend "nccl") when every rank owns its
+        # GPU; gloo when ranks share a device (RCCL refuses duplicate devices) or RCCL cannot come up -
+        # a failure of the timing plumbing must not lose the measurement.
+        timing_group = "nccl" if world <= ndev else "gloo"
+        if timing_group == "nccl":
+            try:
+                dist.init_process_group("nccl", device_id=device)
+                probe = torch.zeros([1], device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(device)
+            except Exception as exc:  # pragma: no cover - needs a broken RCCL set-up
+                print(f"[bench rank {rank}] RCCL group failed ({exc!r}); timing over gloo", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                timing_group = "gloo"
+        if timing_group == "gloo":
+            dist.init_process_group("gloo")
 
     def barrier():
         if distributed:
@@ -249,7 +294,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device=device if timing_group == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -351,7 +397,9 @@ def main():
             "metric": "truss solves/sec (batched Solve)",
             "value": total_trusses / elapsed,
             "unit": "solves/s",
-            "n_gpus": world,
+            "n_gpus": n_devices_used,
+            "ranks": world,
+            "timing_group": timing_group,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

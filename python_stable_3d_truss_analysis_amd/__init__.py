@@ -12,7 +12,8 @@ from .utils import HipExtensionError, TrussNotStableError
 
 __all__ = ["Truss", "Member", "MemberType", "SupportType", "MetapathType", "TaskType",
            "LinkType", "GenerateMethod", "HipExtensionError", "TrussNotStableError",
-           "solve_batch", "pack_trusses", "PackedBatch", "BatchResult"]
+           "solve_batch", "pack_trusses", "PackedBatch", "BatchResult",
+           "ShardedSolver", "solve_batch_sharded", "solve_batch_distributed"]
 
 
 def __getattr__(name):
@@ -20,4 +21,7 @@ def __getattr__(name):
     if name in ("solve_batch", "pack_trusses", "PackedBatch", "BatchResult"):
         from . import batch
         return getattr(batch, name)
+    if name in ("ShardedSolver", "solve_batch_sharded", "solve_batch_distributed"):
+        from . import shard
+        return getattr(shard, name)
     raise AttributeError(name)

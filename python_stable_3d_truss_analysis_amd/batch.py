@@ -364,7 +364,7 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30):
     return groups
 
 
-def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False):
+def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False, sections=None):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
 
     The packed inputs go up once; a ragged batch is bucketed by padded system size
@@ -373,11 +373,17 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     down once.  `reorder=True` renumbers the joints of every truss by reverse Cuthill-McKee first
     (the order is found on the host, natively; inputs are permuted and results mapped back on the
     device): worth it when the trusses are not numbered along their long axis, e.g. generated cube
-    trusses."""
+    trusses.
+
+    `sections=[None, (a, e, density), ...]` solves the same trusses several times - `None` with their
+    own member sections, a triple with every member set to it (the "fixed member type" prior of the
+    reference's dataset path, `data.py:107-114`) - and returns a list of results: the geometry is
+    uploaded, reordered and bucketed once, only A and E change between the solves."""
     packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
         else pack_trusses(list(trusses_or_packed))
     torch, dev = _require_gpu(device)
     B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
+    variants = [None] if sections is None else list(sections)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
     full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS}
     perm = None
@@ -397,17 +403,20 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     # bucket's block instead of growing the pool bucket by bucket
     n_pad_of = lambda idx: (int(packed.n_free[idx].max()) + 63) // 64 * 64
     groups.sort(key=lambda idx: -len(idx) * n_pad_of(idx) * (n_pad_of(idx) + 16))
-    if len(groups) == 1 and len(groups[0]) == B:
-        bucket = DeviceBatch.from_device(full, packed.n_max)
-        bucket.solve()
-        u, f_ext, N, info = bucket.u, bucket.f_ext, bucket.N, bucket.info
-    else:
-        u = torch.zeros([B, nJ_max, 3], dtype=torch.float64, device=dev)
-        f_ext = torch.zeros_like(u)
-        N = torch.zeros([B, nM_max], dtype=torch.float64, device=dev)
-        info = torch.zeros([B], dtype=torch.int32, device=dev)
-        joint_fields = ("xyz", "cbits", "loads")
-        for idx in groups:
+    whole = len(groups) == 1 and len(groups[0]) == B
+    outs = []
+    for _ in variants:
+        z = torch.zeros if not whole else torch.empty
+        outs.append({"u": z([B, nJ_max, 3], dtype=torch.float64, device=dev),
+                     "f_ext": z([B, nJ_max, 3], dtype=torch.float64, device=dev),
+                     "N": z([B, nM_max], dtype=torch.float64, device=dev),
+                     "info": z([B], dtype=torch.int32, device=dev)})
+    joint_fields = ("xyz", "cbits", "loads")
+    for idx in groups:
+        if whole:
+            rows, nJ_b, nM_b = None, nJ_max, nM_max
+            sub = dict(full)
+        else:
             rows = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(dev)
             nJ_b = max(1, int(packed.nJ[idx].max()))
             nM_b = max(1, int(packed.nM[idx].max()))
@@ -418,16 +427,38 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
                     sub[f] = t
                 else:  # trimmed to the bucket's own maxima
                     sub[f] = t[:, :(nJ_b if f in joint_fields else nM_b)].contiguous()
-            bucket = DeviceBatch.from_device(sub, int(packed.n_free[idx].max()))
+        own = (sub["A"], sub["E"]) if len(variants) > 1 else None
+        if own is not None:   # the bucket's own sections survive the fixed-section solves
+            sub["A"], sub["E"] = own[0].clone(), own[1].clone()
+        bucket = DeviceBatch.from_device(sub, int(packed.n_free[idx].max()) if not whole else packed.n_max)
+        for slot, sec in enumerate(variants):
+            if sec is not None:
+                bucket.A.fill_(float(sec[0]))
+                bucket.E.fill_(float(sec[1]))
+            elif own is not None:
+                bucket.A.copy_(own[0])
+                bucket.E.copy_(own[1])
             bucket.solve()
-            u[:, :nJ_b].index_copy_(0, rows, bucket.u)
-            f_ext[:, :nJ_b].index_copy_(0, rows, bucket.f_ext)
-            N[:, :nM_b].index_copy_(0, rows, bucket.N)
-            info.index_copy_(0, rows, bucket.info)
-            del bucket
-    if perm is not None:  # back to the caller's joint numbering
-        by_joint = perm[:, :, None].expand(-1, -1, 3)
-        u = torch.zeros_like(u).scatter_(1, by_joint, u)
-        f_ext = torch.zeros_like(f_ext).scatter_(1, by_joint, f_ext)
+            o = outs[slot]
+            if whole:
+                o["u"].copy_(bucket.u); o["f_ext"].copy_(bucket.f_ext); o["N"].copy_(bucket.N)
+                o["info"].copy_(bucket.info)
+            else:
+                o["u"][:, :nJ_b].index_copy_(0, rows, bucket.u)
+                o["f_ext"][:, :nJ_b].index_copy_(0, rows, bucket.f_ext)
+                o["N"][:, :nM_b].index_copy_(0, rows, bucket.N)
+                o["info"].index_copy_(0, rows, bucket.info)
+        del bucket
+    results = []
+    for o in outs:
+        u, f_ext = o["u"], o["f_ext"]
+        if perm is not None:  # back to the caller's joint numbering
+            by_joint = perm[:, :, None].expand(-1, -1, 3)
+            u = torch.zeros_like(u).scatter_(1, by_joint, u)
+            f_ext = torch.zeros_like(f_ext).scatter_(1, by_joint, f_ext)
+        o["u"], o["f_ext"] = u, f_ext
     torch.cuda.synchronize(dev)
-    return BatchResult(u.cpu().numpy(), f_ext.cpu().numpy(), N.cpu().numpy(), info.cpu().numpy())
+    for o in outs:
+        results.append(BatchResult(o["u"].cpu().numpy(), o["f_ext"].cpu().numpy(), o["N"].cpu().numpy(),
+                                   o["info"].cpu().numpy()))
+    return results[0] if sections is None else results

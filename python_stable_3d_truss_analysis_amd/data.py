@@ -215,20 +215,50 @@ def hetero_tensors_batch(packed: PackedBatch, actual: BatchResult, prior: BatchR
     return graphs
 
 
-def solve_actual_and_prior(packed: PackedBatch, fixedMemberType=None, device=None, reorder=False):
+def solve_actual_and_prior(packed: PackedBatch, fixedMemberType=None, device=None, reorder=False,
+                           devices=None, pool=None, need_actual=True):
     """The two batched GPU solves behind a dataset: real sections, then every member set to
-    `fixedMemberType` (reference `data.py:107-114`).  Both go through `solve_batch`, i.e. ragged
-    batches are bucketed by size with bounded slab memory."""
-    import dataclasses
+    `fixedMemberType` (reference `data.py:107-114`).  The two solves differ only in A and E, so the
+    geometry is uploaded, RCM-reordered and bucketed ONCE (`solve_batch(..., sections=[...])`).
+
+    With more than one GPU (`devices` = list of device names, `pool` = a running
+    `shard.ShardedSolver`, or - when neither `device` nor `devices` is given - every visible GPU) the
+    batch is sharded over one worker process per GPU.
+    `need_actual=False` skips the solve with the real sections (the truss is already solved)."""
     from .batch import solve_batch
-    actual = solve_batch(packed, device, reorder=reorder)
-    prior = None
-    if fixedMemberType is not None:
-        ones = np.ones_like(packed.A)
-        fixed = dataclasses.replace(packed, A=ones * fixedMemberType.a, E=ones * fixedMemberType.e,
-                                    rho=ones * fixedMemberType.density)
-        prior = solve_batch(fixed, device, reorder=reorder)
+    sections = ([None] if need_actual else []) + \
+               ([(fixedMemberType.a, fixedMemberType.e, fixedMemberType.density)]
+                if fixedMemberType is not None else [])
+    if not sections:
+        return None, None
+    if pool is None and devices is None and device is None:
+        from .shard import visible_devices
+        seen = visible_devices()
+        devices = seen if len(seen) > 1 else None
+    if pool is not None:
+        out = pool.solve(packed, reorder=reorder, sections=sections)
+    elif devices is not None and len(devices) > 1:
+        from .shard import solve_batch_sharded
+        out = solve_batch_sharded(packed, devices, reorder=reorder, sections=sections)
+    else:
+        out = solve_batch(packed, devices[0] if devices else device, reorder=reorder, sections=sections)
+    actual = out[0] if need_actual else None
+    prior = out[-1] if fixedMemberType is not None else None
     return actual, prior
+
+
+def _dense_from_truss(truss):
+    """Dense (u [1,nJ,3], f_ext [1,nJ,3], N [1,nM]) of an already solved truss from its sparse result
+    dicts (absent = below 1e-10 = zero, truss.py:344-359)."""
+    nJ, nM, dim = truss.nJoint, truss.nMember, truss.dim
+    u, f, n = np.zeros([1, nJ, 3]), np.zeros([1, nJ, 3]), np.zeros([1, nM])
+    for j, v in truss.GetDisplacements(isProtect=False).items():
+        u[0, j, :dim] = v
+    for j, v in truss.GetExternalForces(isProtect=False).items():
+        f[0, j, :dim] = v
+    for m, v in truss.GetInternalForces(isProtect=False).items():
+        n[0, m] = v
+    return BatchResult(u, f, n, np.zeros([1], dtype=np.int32))
 
 
 class TrussHeteroDataCreator:
@@ -253,10 +283,19 @@ class TrussHeteroDataCreator:
         if _results is not None:
             actual, prior = _results
         else:
-            actual, prior = solve_actual_and_prior(packed, fixed)
-            if actual.info.any() or (prior is not None and prior.info.any()):
+            # as the reference (data.py:20-21,34-35): a truss that already carries results (solved, or
+            # loaded from an output file) is not solved again; an unstable one raises before any solve
+            solved = truss.isSolved
+            if not truss.isStable:
+                from .utils import TrussNotStableError
+                raise TrussNotStableError("The truss is not stable !")
+            actual, prior = solve_actual_and_prior(packed, fixed, need_actual=not solved)
+            if (actual is not None and actual.info.any()) or (prior is not None and prior.info.any()):
                 raise np.linalg.LinAlgError("Singular matrix")
-            truss.AdoptDenseResults(actual.displace[0], actual.external[0], actual.internal[0])
+            if solved:
+                actual = _dense_from_truss(truss)
+            else:
+                truss.AdoptDenseResults(actual.displace[0], actual.external[0], actual.internal[0])
         self.truss, self.source = truss, trussSrc
         self.jointIndexToID, self.memberIndexToID = truss.GetJointIDs(), truss.GetMemberIDs()
         dim, nJ, nM = truss.dim, truss.nJoint, truss.nMember

@@ -28,8 +28,14 @@ PENALTY = 1e5  # weight of the normalised violations in the fitness (ga.py:146-1
 class GA:
     def __init__(self, truss: Truss, memberTypeList, allowStress=30000., allowDisplace=10.,
                  nIteration=None, nPatience=50, nPop=200, nElite=50, pCrossover=0.7, pMutate=0.1,
-                 pOrigin=0.1, isCheckWorst=False):
+                 pOrigin=0.1, isCheckWorst=False, devices=None):
+        """Arguments as the reference (`ga.py:14-29`).  `devices` (not in the reference): a list of GPU
+        names - the population is then split over one worker process per GPU (128 per GPU for
+        nPop = 1024 on 8 GPUs), geometry resident on every GPU, the fitness
+        triples gathered on the host.  Default: the current device evaluates the whole population."""
         self.nPop, self.nElite = nPop, nElite
+        self._devices = list(devices) if devices else None
+        self._pool = None
         self.pCrossover, self.pMutate, self.pOrigin = pCrossover, pMutate, pOrigin
         self.pRandomGene = 1. - pCrossover - pMutate - pOrigin
         self.nIteration, self.nPatience = nIteration, nPatience
@@ -128,6 +134,11 @@ class GA:
         """[(fitness, isInternalAllowed, isDisplaceAllowed)] for a list of genes: one batched solve.
         Member sections are gathered on the device from the type table by the gene matrix."""
         import torch
+        if not self.truss.isStable:   # what Truss.Solve() raises per individual in the reference
+            from .utils import TrussNotStableError
+            raise TrussNotStableError("The truss is not stable !")
+        if self._devices is not None and len(self._devices) > 1:
+            return self._fitness_sharded(genes)
         dev = self._population_device(len(genes))
         count = len(genes)
         loci = torch.zeros([dev.B, dev.nM_max], dtype=torch.int64, device=dev.device)
@@ -141,6 +152,30 @@ class GA:
             raise np.linalg.LinAlgError("Singular matrix")
         w, s, d = (t[:count].cpu().numpy() for t in (weight, stressVio, dispVio))
         return [self._compose(float(w[i]), float(s[i]), float(d[i])) for i in range(count)]
+
+    def _fitness_sharded(self, genes):
+        """The population split over the GPUs of `devices` (`shard.ShardedSolver.fitness`)."""
+        from .batch import pack_trusses
+        from .shard import ShardedSolver
+        if self._pool is None:
+            self._pool = ShardedSolver(self._devices)
+            self._base = pack_trusses([self.truss])
+            self._table = np.array([[t.a, t.e, t.density] for t in self.typeList], dtype=np.float64)
+        count = len(genes)
+        pop = self._base.replicate(count)
+        sec = self._table[np.asarray(genes, dtype=np.int64)]          # [count, nMember, 3]
+        pop.A[:, :self.nMember], pop.E[:, :self.nMember] = sec[..., 0], sec[..., 1]
+        pop.rho[:, :self.nMember] = sec[..., 2]
+        fit, info = self._pool.fitness(pop, self.allowStress, self.allowDisplace, geometry_key=id(self))
+        if info.any():
+            raise np.linalg.LinAlgError("Singular matrix")
+        return [self._compose(float(fit[i, 0]), float(fit[i, 1]), float(fit[i, 2])) for i in range(count)]
+
+    def close(self):
+        """Stop the per-GPU worker processes of a multi-device GA (no-op otherwise)."""
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
 
     def _evaluate(self, pop):
         """Population -> list of fitness triples; batched unless GetFitness was overridden."""

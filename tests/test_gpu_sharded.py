@@ -1,0 +1,125 @@
+"""Multi-process / multi-GPU path with the REAL HIP solver, `-m gpu`.
+
+World size 2 everywhere: on a box with one GPU both ranks share cuda:0 (the processes, shards,
+shared-memory transport and gathers are the same as with one GPU per rank), on a box with more GPUs
+rank r takes cuda:r.  Sharded results are compared BITWISE with the single-process result: a truss's
+arithmetic does not depend on which batch or bucket it travels in.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _devices(n=2):
+    import torch
+    ndev = torch.cuda.device_count()
+    assert ndev >= 1
+    return [f"cuda:{i % ndev}" for i in range(n)]
+
+
+def _ragged_batch():
+    from python_stable_3d_truss_analysis_amd import batch
+    datas = [H.load_json(n) for n in H.data_case_names()]
+    datas += [d for _, d, _ in H.ragged_cube_cases()]
+    return batch.pack_json(datas)
+
+
+def _assert_same(a, b):
+    np.testing.assert_array_equal(a.displace, b.displace)
+    np.testing.assert_array_equal(a.external, b.external)
+    np.testing.assert_array_equal(a.internal, b.internal)
+    np.testing.assert_array_equal(a.info, b.info)
+
+
+def test_sharded_solver_matches_single_process_bitwise():
+    from python_stable_3d_truss_analysis_amd import batch, shard
+    packed = _ragged_batch()
+    single = batch.solve_batch(packed)
+    single_two = batch.solve_batch(packed, sections=[None, (1.0, 1e7, 0.1)], reorder=True)
+    with shard.ShardedSolver(_devices()) as pool:
+        _assert_same(pool.solve(packed), single)
+        both = pool.solve(packed, reorder=True, sections=[None, (1.0, 1e7, 0.1)])
+    assert not single.info.any()
+    for got, want in zip(both, single_two):
+        _assert_same(got, want)
+    # reordering changes the summation order, not the answer
+    assert H.max_scaled_err(single_two[0].displace, single.displace) < 1e-8
+
+
+def _spmd_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from python_stable_3d_truss_analysis_amd import shard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = shard.solve_batch_distributed(_ragged_batch())   # real HIP solver on cuda:(rank % ndev)
+    dist.barrier()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), u=full.displace, f=full.external, n=full.internal,
+             info=full.info)
+    dist.destroy_process_group()
+
+
+def test_spmd_two_ranks_real_solver(tmp_path):
+    import torch.multiprocessing as mp
+    from python_stable_3d_truss_analysis_amd import batch
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_spmd_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    single = batch.solve_batch(_ragged_batch())
+    for rank in range(2):
+        z = np.load(tmp_path / f"r{rank}.npz")
+        np.testing.assert_array_equal(z["u"], single.displace)
+        np.testing.assert_array_equal(z["f"], single.external)
+        np.testing.assert_array_equal(z["n"], single.internal)
+        assert not z["info"].any()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself and rank 0 prints
+    the one JSON line (n_gpus = the devices really used: 2 on a multi-GPU box, 1 when shared)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "256", "--no-cpu-baseline", "--no-pcie", "--cube-batch", "0", "--no-dense-ref"]
+    if ndev < 2:
+        cmd.append("--oversubscribe")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["ranks"] == 2 and line["n_gpus"] == min(2, ndev)
+    assert line["info_nonzero"] == 0 and line["value"] > 0
+    assert line["scaling"] == "weak" and line["config"]["batch_per_gpu"] == 256
+
+
+def test_ga_population_sharded_over_two_workers():
+    """Config 4 in its sharded form: the population split over two workers gives the same fitness
+    triples as the single-device evaluation."""
+    import random
+    from python_stable_3d_truss_analysis_amd import Truss, MemberType
+    from python_stable_3d_truss_analysis_amd.ga import GA
+    truss = Truss(3).LoadFromJSON(data=H.load_json("bar-120_input_0"))
+    types = [MemberType(0.5 + 0.5 * i, 1e7, 0.1) for i in range(6)]
+    random.seed(3)
+    one = GA(truss.Copy(), types, nPop=64, nElite=16)
+    genes = one.Initialize()
+    two = GA(truss.Copy(), types, nPop=64, nElite=16, devices=_devices())
+    try:
+        a, b = one.GetFitnessBatch(genes), two.GetFitnessBatch(genes)
+        b2 = two.GetFitnessBatch(genes[::-1])   # second generation: geometry already resident
+    finally:
+        two.close()
+    assert a == b and b2 == a[::-1]

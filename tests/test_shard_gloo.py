@@ -1,6 +1,12 @@
-"""Multi-rank path on CPU: two gloo processes shard a ragged batch, each 'solves' its shard with a
-stand-in (the oracle, test infrastructure) and the gathered result equals the single-process one.
-The GPU solver itself is covered by -m gpu; this test covers partitioning + gather (world size 2)."""
+"""Multi-rank path on CPU (world size 2).
+
+* SPMD: two gloo processes call `shard.solve_batch_distributed` on a ragged batch; the solver is a
+  stand-in (the oracle, test infrastructure) because there is no GPU here - partitioning, gather and
+  row order are what is covered.  The same entry point with the REAL HIP solver runs under `-m gpu`
+  (tests/test_gpu_sharded.py).
+* single controller: `ShardedSolver` with two worker processes, shards through shared memory, the
+  several-solves-per-geometry form (`sections=`) of the dataset path (reference data.py:107-114).
+"""
 import os
 import socket
 
@@ -16,42 +22,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _solve_with_oracle(packed, datas, idx):
-    from oracle import truss_oracle as orc
-    from python_stable_3d_truss_analysis_amd.batch import BatchResult
-    B = packed.B
-    res = BatchResult(np.zeros([B, packed.nJ_max, 3]), np.zeros([B, packed.nJ_max, 3]),
-                      np.zeros([B, packed.nM_max]), np.zeros([B], dtype=np.int32))
-    for b, g in enumerate(idx):
-        r = orc.solve(datas[g])
-        dim = r["u"].shape[1]
-        res.displace[b, :len(r["u"]), :dim] = r["u"]
-        res.external[b, :len(r["u"]), :dim] = r["f_ext"]
-        res.internal[b, :len(r["N"])] = r["N"]
-    return res
-
-
 def _worker(rank, world, port, names, out_dir):
     import torch.distributed as dist
     from python_stable_3d_truss_analysis_amd import batch, shard
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    datas = [H.load_json(n) for n in names]
-    packed = batch.pack_json(datas)
-    mine, idx = shard.shard_batch(packed, rank, world)
-    local = _solve_with_oracle(mine, datas, idx)
-    full = shard.gather_results(local, idx, packed.B)
+    packed = batch.pack_json([H.load_json(n) for n in names])
+    full = shard.solve_batch_distributed(packed, solver=H.oracle_batch_solver)
     dist.barrier()
-    if rank == 0:
-        np.savez(os.path.join(out_dir, "full.npz"), u=full.displace, n=full.internal, info=full.info)
+    np.savez(os.path.join(out_dir, f"full{rank}.npz"), u=full.displace, f=full.external, n=full.internal,
+             info=full.info)
     dist.destroy_process_group()
 
 
 def test_two_rank_shard_and_gather(tmp_path):
     from python_stable_3d_truss_analysis_amd import batch, shard
     names = H.data_case_names()[:8]           # ragged: 2D and 3D, 5 .. 111 free DOFs
-    datas = [H.load_json(n) for n in names]
-    packed = batch.pack_json(datas)
+    packed = batch.pack_json([H.load_json(n) for n in names])
     parts = shard.shard_indices(packed.n_free.astype(float) ** 3, 2)
     assert sorted(np.concatenate(parts).tolist()) == list(range(packed.B))
     assert abs(len(parts[0]) - len(parts[1])) <= 1
@@ -59,8 +46,42 @@ def test_two_rank_shard_and_gather(tmp_path):
     second = int(np.argsort(-packed.n_free)[1])
     assert (big in parts[0]) != (second in parts[0])
     mp.spawn(_worker, args=(2, _free_port(), names, str(tmp_path)), nprocs=2, join=True)
-    z = np.load(tmp_path / "full.npz")
-    single = _solve_with_oracle(packed, datas, np.arange(packed.B))
-    np.testing.assert_array_equal(z["u"], single.displace)
-    np.testing.assert_array_equal(z["n"], single.internal)
-    assert not z["info"].any()
+    single = H.oracle_batch_solver(packed)
+    for rank in range(2):                      # the gathered result is complete on every rank
+        z = np.load(tmp_path / f"full{rank}.npz")
+        np.testing.assert_array_equal(z["u"], single.displace)
+        np.testing.assert_array_equal(z["f"], single.external)
+        np.testing.assert_array_equal(z["n"], single.internal)
+        assert not z["info"].any()
+
+
+def test_sharded_solver_pool_two_workers():
+    import dataclasses
+    from python_stable_3d_truss_analysis_amd import batch, shard
+    names = [n for n in H.data_case_names() if "942" not in n]
+    packed = batch.pack_json([H.load_json(n) for n in names])
+    with shard.ShardedSolver(["cpu", "cpu"], _test_solver="tests.helpers:oracle_batch_solver") as pool:
+        assert pool.world_size == 2
+        one = pool.solve(packed)
+        two = pool.solve(packed, sections=[None, (1.0, 1e7, 0.1)])
+        again = pool.solve(packed.take(np.arange(3)))   # the pool outlives a batch; smaller than world*2
+    single = H.oracle_batch_solver(packed)
+    np.testing.assert_array_equal(one.displace, single.displace)
+    np.testing.assert_array_equal(one.internal, single.internal)
+    np.testing.assert_array_equal(two[0].external, single.external)
+    ones = np.ones_like(packed.A)
+    fixed = H.oracle_batch_solver(dataclasses.replace(packed, A=ones, E=ones * 1e7, rho=ones * 0.1))
+    np.testing.assert_array_equal(two[1].displace, fixed.displace)
+    np.testing.assert_array_equal(two[1].internal, fixed.internal)
+    np.testing.assert_array_equal(again.displace, single.displace[:3])
+    assert not os.path.exists("/dev/shm") or not [f for f in os.listdir("/dev/shm") if f.startswith("psm_")]
+
+
+def test_sharded_solver_reports_worker_errors():
+    import pytest
+    from python_stable_3d_truss_analysis_amd import batch, shard
+    from python_stable_3d_truss_analysis_amd.utils import HipExtensionError
+    packed = batch.pack_json([H.load_json("bar-6_input_0")])
+    with shard.ShardedSolver(["cpu"], _test_solver="tests.helpers:failing_solver") as pool:
+        with pytest.raises(HipExtensionError, match="stand-in failure"):
+            pool.solve(packed)
