@@ -32,6 +32,23 @@ PEAK_HBM_GBS = 8000.0
 STAGES = ("dofmap", "assemble", "potrf", "potrs", "recover")
 
 
+def kernel_source_sha():
+    """Fingerprint of the kernel sources (csrc/*.hip, *.h, *.c + the C-ABI header): a PMC record under
+    profiles/ is only quoted in the bench line while it was taken on exactly these sources (.git does
+    not travel to the GPU box, so a commit id cannot be checked there)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "python_stable_3d_truss_analysis_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
+                   glob.glob(os.path.join(csrc, "*.c")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_case(name):
     with open(os.path.join(ROOT, "tests", "golden", "data", name + ".json")) as fh:
         return json.load(fh)
@@ -360,8 +377,9 @@ def main():
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 rec = json.load(fh)
-            # the PMC pass is valid for the configuration it was taken on only
-            if rec.get("envelope") == (not args.dense) and rec.get("batch") == args.batch:
+            # the PMC pass is valid for the configuration AND the kernel sources it was taken on only
+            if rec.get("envelope") == (not args.dense) and rec.get("batch") == args.batch and \
+                    rec.get("source_sha") == kernel_source_sha() and rec.get("kernel") == potrf_kernel:
                 traffic = rec.get("hbm_bytes_per_launch")
         # Which roof bounds the factorisation: its arithmetic intensity (executed FLOP per byte of the
         # stored slab part read once + written once) against the machine balance peak_flops / peak_bw.

@@ -25,7 +25,9 @@ int trs_cubegen_bounds(int gx, int gy, int gz, int max_cubes, int allow_parallel
 /* Random polycube trusses (generate.py:40-246: grow a polycube, link the cube vertices, supports,
  * loads, member types; count-unstable draws are regenerated).  num_cubes[b] cells for truss b; every
  * truss has its own RNG stream derived from seed.  With xyz == NULL only nJ[b], nM[b] are produced
- * (sizes-only pass).  Returns 0, -1 when a truss does not fit nJ_max / nM_max, -2 on allocation failure. */
+ * (sizes-only pass).  allow_parallel: bit 0 = keep parallel members (isAllowParallel), bit 1 = no pin
+ * supports (isAddPinSupport=False: loads may then sit on any joint and the counting test is left to
+ * the caller, who adds supports with an augmenter).  Returns 0, -1 when a truss does not fit nJ_max / nM_max, -2 on allocation failure. */
 int trs_cubegen(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num_cubes, int method,
                 int link_type, int allow_parallel, double len_lo, double len_hi,
                 const double *force_range /* [3][2] */, int nforce_lo, int nforce_hi,

@@ -51,6 +51,11 @@ extern "C" {
 
 int trs_abi_version(void);
 
+/* Process-wide switches for tests and diagnostics (no effect on results):
+ *   "recover_unstaged" 0/1  force trs_recover's path for trusses whose tables exceed a CU's LDS.
+ * Returns 0, or hipErrorInvalidValue for an unknown name. */
+int trs_set_option(const char *name, int value);
+
 /* Leading dimension / row count of the stiffness slab for a batch whose largest reduced
  * system has n_max free DOFs. */
 int trs_slab_ld(int n_max);

@@ -18,6 +18,7 @@ _D = ctypes.c_double
 #: every symbol `include/trs_solver.h` declares -> (restype, argtypes)
 SIGNATURES = {
     "trs_abi_version": (_I, []),
+    "trs_set_option": (_I, [ctypes.c_char_p, _I]),
     "trs_slab_ld": (_I, [_I]),
     "trs_slab_rows": (_I, [_I]),
     "trs_dofmap": (_I, [_I, _I, _P, _P, _P, _P, _P]),

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     int* cnt = fi + 3 * nJ_max;                                      // [nJ_max]   joint degree
     int* start = cnt + nJ_max;                                       // [nJ_max+1] exclusive scan
     int* fill = start + nJ_max + 1;                                  // [nJ_max]   fill cursor
-    int* adj = fill + nJ_max;                                        // [2 nM_max] (other << 16) | member
-    int* chunkmin = adj + 2 * nM_max;                                // [n_pad_max/16] first tile per chunk
+    unsigned* adj = reinterpret_cast<unsigned*>(fill + nJ_max);      // [2 nM_max] (other << 16) | member
+    int* chunkmin = reinterpret_cast<int*>(adj + 2 * nM_max);                                // [n_pad_max/16] first tile per chunk
     int* cendl = chunkmin + n_pad_max / 16;                          // [n_pad_max/16] envelope: stored extent
     int* rowdof = cendl + n_pad_max / 16;                            // [n_pad_max] DOF of a reduced row
 
@@ -157,16 +157,16 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     for (int m = tid; m < nM; m += NT) {
         const size_t mm = (size_t)b * nM_max + m;
         const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
-        adj[start[j0] + atomicAdd(&fill[j0], 1)] = (j1 << 16) | m;
-        adj[start[j1] + atomicAdd(&fill[j1], 1)] = (j0 << 16) | m;
+        adj[start[j0] + atomicAdd(&fill[j0], 1)] = ((unsigned)j1 << 16) | (unsigned)m;
+        adj[start[j1] + atomicAdd(&fill[j1], 1)] = ((unsigned)j0 << 16) | (unsigned)m;
     }
     __syncthreads();
     // one thread per joint: sort its list by (other joint, member); diagonal block; envelope
     for (int a = tid; a < nJ; a += NT) {
-        int* list = adj + start[a];
+        unsigned* list = adj + start[a];
         const int deg = cnt[a];
         for (int i = 1; i < deg; ++i) {  // insertion sort, deg is small (<= ~20 for real trusses)
-            const int key = list[i];
+            const unsigned key = list[i];
             int p = i - 1;
             while (p >= 0 && list[p] > key) {
                 list[p + 1] = list[p];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         for (int s = 0; s < 3; ++s)
             if (fi[3 * a + s] >= 0) mincol = min(mincol, fi[3 * a + s]);
         for (int i = 0; i < deg; ++i) {
-            const int other = list[i] >> 16, m = list[i] & 0xffff;
+            const int other = (int)(list[i] >> 16), m = (int)(list[i] & 0xffffu);
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 if (fi[3 * other + s] >= 0) mincol = min(mincol, fi[3 * other + s]);
@@ -264,24 +264,24 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     int pq0 = -1, pq1 = -1, pq2 = -1, pdeg = 0;
     double pv0 = 0.0, pv1 = 0.0, pv2 = 0.0;
     // block row of the neighbour at list position i (head of a run), row r of the joint
-    auto run_values = [&](const int* list, int deg, int i, int r, int& q0, int& q1, int& q2,
+    auto run_values = [&](const unsigned* list, int deg, int i, int r, int& q0, int& q1, int& q2,
                           double& v0, double& v1, double& v2) {
-        const int other = list[i] >> 16;
+        const int other = (int)(list[i] >> 16);
         q0 = q1 = q2 = -1;
-        if (i > 0 && (list[i - 1] >> 16) == other) return;  // not the head of a run
+        if (i > 0 && (int)(list[i - 1] >> 16) == other) return;  // not the head of a run
         q0 = fi[3 * other];
         q1 = fi[3 * other + 1];
         q2 = fi[3 * other + 2];
         v0 = v1 = v2 = 0.0;
         int q = i;
         do {  // parallel members between the same two joints, in member order
-            const int m = list[q] & 0xffff;
+            const int m = (int)(list[q] & 0xffffu);
             const double k = mk[m], cr = mc[3 * m + r];
             v0 -= k * (cr * mc[3 * m]);
             v1 -= k * (cr * mc[3 * m + 1]);
             v2 -= k * (cr * mc[3 * m + 2]);
             ++q;
-        } while (q < deg && (list[q] >> 16) == other);
+        } while (q < deg && (int)(list[q] >> 16) == other);
     };
     auto prepare = [&](int c0) {
         pq0 = pq1 = pq2 = -1;
@@ -400,14 +400,16 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
                                    const int* nM, int ld, size_t slab_stride, int n_pad_max,
                                    double* S, int flags, void* work, int* env, hipStream_t stream) {
     if (B <= 0 || n_pad_max <= 0) return 0;
-    // adjacency keys: other joint (16 bits) | member (16 bits)
+    // adjacency keys (unsigned): other joint (16 bits) | member (16 bits)
     if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;
     const AsmPlan plan = asm_plan(nJ_max, nM_max, n_pad_max);
+    // the dynamic-LDS ceiling of an instantiation is raised once per process, not per launch
 #define TRS_LAUNCH_ASSEMBLE(MODE, NTV)                                                                   \
     do {                                                                                                 \
-        if (plan.lds > 48 * 1024)                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_assemble_kernel<MODE, NTV>),     \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds);        \
+        static const int lds_limit_set = (int)hipFuncSetAttribute(                                       \
+            reinterpret_cast<const void*>(trs_assemble_kernel<MODE, NTV>),                               \
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                     \
+        (void)lds_limit_set;                                                                             \
         hipLaunchKernelGGL((trs_assemble_kernel<MODE, NTV>), dim3(B), dim3(NTV), plan.lds, stream, xyz,  \
                            conn, E, A, loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max, ld, \
                            slab_stride, S, flags, static_cast<unsigned char*>(work), plan.work, env,     \

@@ -1,5 +1,6 @@
 // extern "C" entry points declared in include/trs_solver.h: argument checks + kernel launches.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include "../../include/trs_solver.h"
 #include "trs_common.h"
 
@@ -14,6 +15,7 @@ int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, 
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, const int*, const double*, int, double*,
                        double*, double*, hipStream_t);
+void trs_recover_set_unstaged(int);
 int trs_fitness_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const int*, const int*, const double*, const double*, double, double, double*,
                        double*, double*, hipStream_t);
@@ -29,6 +31,14 @@ inline bool bad_slab(int ld, int slab_rows) {
 extern "C" {
 
 int trs_abi_version(void) { return TRS_ABI_VERSION; }
+
+int trs_set_option(const char* name, int value) {
+    if (name != nullptr && strcmp(name, "recover_unstaged") == 0) {
+        trs_recover_set_unstaged(value != 0);
+        return 0;
+    }
+    return (int)hipErrorInvalidValue;
+}
 
 int trs_slab_rows(int n_max) { return trs_round_up(n_max < 1 ? 1 : n_max, TRS_NB); }
 

@@ -30,6 +30,12 @@ static uint64_t rng_next(rng_t *r) { /* splitmix64 */
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
     return z ^ (z >> 31);
 }
+/* splitmix64's output function as a stand-alone hash */
+static uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
 static double rng_unit(rng_t *r) { return (double)(rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
 static int rng_below(rng_t *r, int n) { return (int)(rng_unit(r) * n); } /* 0 .. n-1 */
 static double rng_uniform(rng_t *r, double lo, double hi) { return lo + (hi - lo) * rng_unit(r); }
@@ -134,7 +140,7 @@ static int generate_one(scratch_t *sc, rng_t *rng, int num_cube, int method, int
         for (int e = 0; e < 12; ++e) { pairs[npairs][0] = EDGE[e][0]; pairs[npairs++][1] = EDGE[e][1]; }
         for (int p = 0; p < npairs; ++p) {
             const int a = vid[pairs[p][0]], b = vid[pairs[p][1]];
-            if (!allow_parallel && !set_insert(sc, ((uint64_t)(a + 1) << 32) | (uint64_t)(b + 1))) continue;
+            if (!(allow_parallel & 1) && !set_insert(sc, ((uint64_t)(a + 1) << 32) | (uint64_t)(b + 1))) continue;
             if (n_member >= nM_max) return -1;
             conn[2 * n_member] = a; conn[2 * n_member + 1] = b;
             ++n_member;
@@ -146,7 +152,7 @@ static int generate_one(scratch_t *sc, rng_t *rng, int num_cube, int method, int
     int n_pin = 0;
     for (int j = n_joint - 1; j >= 0; --j) { /* backwards: ints are read before doubles overwrite */
         const int x = jx[3 * j], y = jx[3 * j + 1], z = jx[3 * j + 2];
-        const int pin = z == min_z;
+        const int pin = z == min_z && !(allow_parallel & 2); /* bit 1: isAddPinSupport=False */
         cbits[j] = pin ? 7 : 0;
         n_pin += pin;
         /* cannot write xyz[3j..] yet for j < n_joint: the int scratch of later joints lives there */
@@ -165,7 +171,7 @@ static int generate_one(scratch_t *sc, rng_t *rng, int num_cube, int method, int
     }
     /* counting test (truss.py:158-164) */
     const int n_res = 3 * n_pin;
-    if (n_res < 6 || n_member + n_res < 3 * n_joint) return 1;
+    if (!(allow_parallel & 2) && (n_res < 6 || n_member + n_res < 3 * n_joint)) return 1;
 
     /* loads on unsupported joints (generate.py:318-328) */
     const int n_free_joint = n_joint - n_pin;
@@ -261,7 +267,10 @@ int trs_cubegen(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num
         for (int b = 0; b < B; ++b) {
             if (!ok || rc != 0) continue;
             rng_t rng;
-            rng.s = seed * 0x2545f4914f6cdd1dULL + (uint64_t)b * 0x9e3779b97f4a7c15ULL + 0x1234567ULL;
+            /* Per-truss stream: the initial state is a HASH of (seed, b).  (An affine function of b with
+             * the generator's own increment as the factor would make truss b+1's stream truss b's
+             * shifted by one draw.) */
+            rng.s = mix64(mix64(seed + 0x632be59bd9b4e019ULL) ^ mix64((uint64_t)b + 1));
             for (;;) {
                 double len[3];
                 for (int a = 0; a < 3; ++a) len[a] = rng_uniform(&rng, len_lo, len_hi);

@@ -187,12 +187,12 @@ extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_st
     if (B <= 0 || n_pad_max <= 0) return 0;
     const size_t lds = (size_t)(n_pad_max + BS * (BS + 1) + BS) * sizeof(double);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    if (lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    static const int lds_limit_set =   // once per process, not per launch
+        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) |
+        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)lds_limit_set;
     if (env != nullptr)
         hipLaunchKernelGGL(trs_potrs_kernel<true>, dim3(B), dim3(256), lds, stream, S, n_free, ld,
                            slab_stride, uf, ld_uf, env, n_pad_max);

@@ -5,8 +5,6 @@
 // (N c on joint1, -N c on joint0) instead of a dense K[~mask,:] @ u.
 //
 // Also the constraint reductions the GA fitness needs (truss.py:166-168,429-462; ga.py:139-149).
-#include <cstdlib>
-
 #include "trs_common.h"
 
 namespace {
@@ -29,8 +27,21 @@ __device__ __forceinline__ MemberGeom member_geom(const double* X, int j0, int j
     return g;
 }
 
-// STAGED: u and f_ext of the truss are staged in LDS (gathers and the reaction sums stay on chip);
-// for trusses with more than ~3400 joints they live directly in the output arrays instead.
+// axial force of a member from the displacements of its end joints: N = (E A / L) c . (u1 - u0)
+__device__ __forceinline__ double member_axial(const MemberGeom& g, double EA, const double* u, int j0, int j1) {
+    const double k = EA / g.len;
+    double proj = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) proj += g.c[a] * (u[3 * j1 + a] - u[3 * j0 + a]);
+    return k * proj;
+}
+
+// STAGED: u and f_ext of the truss are staged in LDS (gathers and the reaction sums stay on chip), and
+// the reactions are summed in a FIXED order: the member ends at constrained joints are counting-sorted
+// by joint (integer LDS atomics), every such joint's short list is sorted by member id and one thread
+// adds its members' end forces in that order - no floating-point atomics, bit-reproducible.
+// For trusses with more than ~2500 joints (tables beyond a CU's LDS) u and f_ext live directly in the
+// output arrays and the reactions are global FP64 atomics (reproducible to rounding only).
 template <bool STAGED>
 __global__ __launch_bounds__(256) void trs_recover_kernel(
     const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
@@ -40,7 +51,8 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     double* __restrict__ u_out, double* __restrict__ f_out, double* __restrict__ N_out) {
     extern __shared__ double sh[];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int ndof = 3 * nJ[b], ndof_max = 3 * nJ_max;
+    const int joints = nJ[b];
+    const int ndof = 3 * joints, ndof_max = 3 * nJ_max;
     double *u, *f;  // [ndof_max] each
     if constexpr (STAGED) {
         u = sh;
@@ -49,6 +61,10 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         u = u_out + (size_t)b * ndof_max;
         f = f_out + (size_t)b * ndof_max;
     }
+    // STAGED only: integer tables behind u and f
+    int* cnt = reinterpret_cast<int*>(sh + 2 * ndof_max);  // [nJ_max]   member ends at a constrained joint
+    int* start = cnt + nJ_max;                             // [nJ_max+1] exclusive scan of cnt
+    int* ends = start + nJ_max + 1;                        // [2 nM_max] (member << 1) | end, grouped by joint
     const int* fi = free_index + (size_t)b * ndof_max;
     const double* F = loads + (size_t)b * ndof_max;
     const double* ufb = uf + (size_t)b * ld_uf;
@@ -57,30 +73,87 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         u[d] = r >= 0 ? ufb[r] : 0.0;
         f[d] = r >= 0 ? F[d] : 0.0;  // constrained: reaction accumulated below (load ignored)
     }
+    if constexpr (STAGED)
+        for (int j = tid; j < nJ_max; j += 256) cnt[j] = 0;
     if constexpr (!STAGED) __threadfence_block();
     __syncthreads();
     const double* X = xyz + (size_t)b * ndof_max;
     const int members = nM[b];
+    auto constrained = [&](int j) { return (fi[3 * j] < 0) | (fi[3 * j + 1] < 0) | (fi[3 * j + 2] < 0); };
     for (int m = tid; m < nM_max; m += 256) {
         const size_t mm = (size_t)b * nM_max + m;
         double axial = 0.0;
         if (m < members) {
             const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
             const MemberGeom g = member_geom(X, j0, j1);
-            const double k = E[mm] * A[mm] / g.len;
-            double proj = 0.0;
+            axial = member_axial(g, E[mm] * A[mm], u, j0, j1);
+            if constexpr (STAGED) {
+                if (constrained(j0)) atomicAdd(&cnt[j0], 1);
+                if (constrained(j1)) atomicAdd(&cnt[j1], 1);
+            } else {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) proj += g.c[a] * (u[3 * j1 + a] - u[3 * j0 + a]);
-            axial = k * proj;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                if (fi[3 * j1 + a] < 0) atomicAdd(&f[3 * j1 + a], axial * g.c[a]);
-                if (fi[3 * j0 + a] < 0) atomicAdd(&f[3 * j0 + a], -axial * g.c[a]);
+                for (int a = 0; a < 3; ++a) {
+                    if (fi[3 * j1 + a] < 0) atomicAdd(&f[3 * j1 + a], axial * g.c[a]);
+                    if (fi[3 * j0 + a] < 0) atomicAdd(&f[3 * j0 + a], -axial * g.c[a]);
+                }
             }
         }
         N_out[mm] = axial;
     }
     if constexpr (STAGED) {
+        __syncthreads();
+        if (tid < 64) {  // exclusive scan of cnt by one wave
+            int base = 0;
+            for (int j0 = 0; j0 < joints; j0 += 64) {
+                const int j = j0 + tid;
+                const int v = j < joints ? cnt[j] : 0;
+                int incl = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int up = __shfl_up(incl, off);
+                    if (tid >= off) incl += up;
+                }
+                if (j < joints) start[j] = base + incl - v;
+                base += __shfl(incl, 63);
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < joints; j += 256) cnt[j] = 0;  // reused as the fill cursor
+        __syncthreads();
+        for (int m = tid; m < members; m += 256) {
+            const size_t mm = (size_t)b * nM_max + m;
+            const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
+            if (constrained(j0)) ends[start[j0] + atomicAdd(&cnt[j0], 1)] = m << 1;
+            if (constrained(j1)) ends[start[j1] + atomicAdd(&cnt[j1], 1)] = (m << 1) | 1;
+        }
+        __syncthreads();
+        for (int j = tid; j < joints; j += 256) {
+            const int deg = cnt[j];
+            if (deg == 0) continue;
+            int* list = ends + start[j];
+            for (int i = 1; i < deg; ++i) {  // insertion sort by member id: the lists are short
+                const int key = list[i];
+                int p = i - 1;
+                while (p >= 0 && list[p] > key) {
+                    list[p + 1] = list[p];
+                    --p;
+                }
+                list[p + 1] = key;
+            }
+            double r[3] = {0.0, 0.0, 0.0};
+            for (int i = 0; i < deg; ++i) {
+                const int m = list[i] >> 1, end = list[i] & 1;
+                const size_t mm = (size_t)b * nM_max + m;
+                const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
+                const MemberGeom g = member_geom(X, j0, j1);
+                const double axial = member_axial(g, E[mm] * A[mm], u, j0, j1);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) r[a] += end ? axial * g.c[a] : -axial * g.c[a];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                if (fi[3 * j + a] < 0) f[3 * j + a] = r[a];
+        }
         __syncthreads();
         for (int d = tid; d < ndof_max; d += 256) {
             u_out[(size_t)b * ndof_max + d] = u[d];
@@ -140,22 +213,27 @@ __global__ __launch_bounds__(256) void trs_fitness_kernel(
 
 }  // namespace
 
+static int g_recover_unstaged = 0;  // trs_set_option("recover_unstaged", 1): tests force the large-truss path
+extern "C" void trs_recover_set_unstaged(int on) { g_recover_unstaged = on; }
+
 extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
                                   const double* E, const double* A, const double* loads,
                                   const int* free_index, const int* nJ, const int* nM,
                                   const double* uf, int ld_uf, double* u, double* f_ext, double* N,
                                   hipStream_t stream) {
     if (B <= 0) return 0;
-    const size_t lds = (size_t)6 * nJ_max * sizeof(double);
-    const char* force = getenv("TRS_DEBUG_RECOVER_UNSTAGED");  // tests: the large-truss path at any size
-    if (lds > 160 * 1024 || (force != nullptr && force[0] == '1')) {
+    // u, f_ext (doubles) + member-end tables (ints)
+    const size_t lds = ((size_t)6 * nJ_max * sizeof(double) +
+                        ((size_t)2 * nJ_max + 1 + 2 * (size_t)nM_max) * sizeof(int) + 15) / 16 * 16;
+    if (lds > 160 * 1024 || g_recover_unstaged) {
         hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), 0, stream, xyz, conn, E, A, loads,
                            free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N);
         return (int)hipGetLastError();
     }
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_recover_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const int lds_limit_set = (int)hipFuncSetAttribute(   // once per process, not per launch
+        reinterpret_cast<const void*>(trs_recover_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        160 * 1024);
+    (void)lds_limit_set;
     hipLaunchKernelGGL(trs_recover_kernel<true>, dim3(B), dim3(256), lds, stream, xyz, conn, E, A, loads,
                        free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N);
     return (int)hipGetLastError();

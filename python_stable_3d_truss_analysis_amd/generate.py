@@ -39,6 +39,15 @@ def _load():
     return _gen
 
 
+def _fresh_seed():
+    """`seed=None` in the reference means "do not re-seed": every call continues the ambient `random`
+    stream and returns fresh trusses (`generate.py:338-339`).  Same here: the 64-bit seed of the native
+    generator is drawn from Python's `random`, so `random.seed(s)` before the call makes it repeatable
+    and repeated unseeded calls differ."""
+    import random
+    return random.getrandbits(64)
+
+
 def _type_table(memberTypes):
     return np.ascontiguousarray([t.Serialize() if isinstance(t, MemberType) else list(t)
                                  for t in memberTypes], dtype=np.float64).reshape(-1, 3)
@@ -48,11 +57,11 @@ def generate_cube_batch(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 150),
                         forceRange=((-30000, 30000), (-30000, 30000), (-30000, 30000)),
                         nForceRange=None, method=GenerateMethod.Random, linkType=LinkType.Random,
                         memberTypes=((1., 1e7, 0.1),), isAllowParallel=False, seed=0,
-                        return_retries=False):
+                        return_retries=False, isAddPinSupport=True):
     """One cube truss per entry of `num_cubes` (polycube sizes), as a `PackedBatch`.
 
-    Arguments as the reference's `GenerateRandomCubeTrusses` (`generate.py:314-316`); pins on the
-    lowest layer are always added (the reference's default `isAddPinSupport=True`)."""
+    Arguments as the reference's `GenerateRandomCubeTrusses` (`generate.py:314-316`).  With
+    `isAddPinSupport=False` no joint is supported (an augmenter is expected to add supports)."""
     lib = _load()
     num_cubes = np.ascontiguousarray(num_cubes, dtype=np.int32).ravel()
     B = len(num_cubes)
@@ -70,7 +79,8 @@ def generate_cube_batch(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 150),
 
     def run(nJ_max, nM_max, xyz, conn, E, A, rho, cbits, loads):
         rc = lib.trs_cubegen(B, int(seed) & (2 ** 64 - 1), gx, gy, gz, ptr(num_cubes), int(method),
-                             int(linkType), int(isAllowParallel), float(lengthRange[0]),
+                             int(linkType), int(bool(isAllowParallel)) | (0 if isAddPinSupport else 2),
+                             float(lengthRange[0]),
                              float(lengthRange[1]), ptr(frange), lo, hi, ptr(table), len(table), nJ_max,
                              nM_max, ptr(xyz), ptr(conn), ptr(E), ptr(A), ptr(rho), ptr(cbits), ptr(loads),
                              ptr(nJ), ptr(nM), ctypes.cast(ctypes.byref(retries), ctypes.c_void_p))
@@ -120,19 +130,32 @@ def GenerateRandomCubeTrusses(gridRange=(5, 5, 5), numCubeRange=(5, 5), numEachR
     `cube-{numCube}_case_{i}.json`.  Plotting is out of scope (`isPlotTruss` must stay False)."""
     if isPlotTruss:
         raise NotImplementedError("plotting is outside the solver path (SURVEY.md section 2, row 12)")
-    if not isAddPinSupport:
-        raise NotImplementedError("trusses without supports cannot be analysed; isAddPinSupport must be True")
+    if augmenter is None:
+        augmenter = NoChange()
     cases = [(num, i) for num in range(numCubeRange[0], numCubeRange[1] + 1)
              for i in range(numEachRange[0], numEachRange[1] + 1)]
-    packed = generate_cube_batch([num for num, _ in cases], gridRange, lengthRange, forceRange, nForceRange,
-                                 method, linkType, memberTypes, isAllowParallel,
-                                 seed=0 if seed is None else seed)
+    if seed is not None:   # as the reference (generate.py:338-339): the augmenters draw from `random`
+        import random
+        random.seed(seed)
+    seed = _fresh_seed() if seed is None else int(seed)
+    gen = lambda nums, s: generate_cube_batch(nums, gridRange, lengthRange, forceRange, nForceRange, method,
+                                              linkType, memberTypes, isAllowParallel, seed=s,
+                                              isAddPinSupport=isAddPinSupport)
+    packed = gen([num for num, _ in cases], seed)
     trusses = []
-    for b in range(packed.B):
-        data = packed_to_json(packed, b)
-        if augmenter is not None:
-            data = augmenter(data)
-        trusses.append(Truss(3).LoadFromJSON(data=data))
+    for b, (num, _) in enumerate(cases):
+        truss = Truss(3).LoadFromJSON(data=augmenter(packed_to_json(packed, b)))
+        attempt = 0
+        while not truss.isStable:   # an augmenter may leave too few supports: draw again (generate.py:353-374)
+            attempt += 1
+            if attempt > 1000:
+                from .utils import TrussNotStableError
+                raise TrussNotStableError("no stable cube truss in 1000 draws (supports missing?)")
+            if isPrintMessage:
+                print("\nTruss is not stable. Re-genrating...\n")
+            again = gen([num], (seed + 0x9E3779B97F4A7C15 * (b * 1000 + attempt)) & (2 ** 64 - 1))
+            truss = Truss(3).LoadFromJSON(data=augmenter(packed_to_json(again, 0)))
+        trusses.append(truss)
     if isDoStructuralAnalysis:
         from .batch import solve_batch
         res = solve_batch(trusses)
@@ -146,3 +169,117 @@ def GenerateRandomCubeTrusses(gridRange=(5, 5, 5), numCubeRange=(5, 5), numEachR
     if isPrintMessage:
         print(f"generated {len(trusses)} cube trusses")
     return trusses
+
+
+# ---- data augmentation (reference generate.py:13-148) ------------------------------------------------
+# Callables on a truss JSON dict (or a `Truss`, which is re-loaded from its augmented serialisation);
+# same names, arguments and `random` call order as the reference so that seeded pipelines carry over.
+
+class TrussDataAugmenter:
+    """Base: `_apply(data)` edits the JSON dict in place."""
+
+    def _apply(self, data):
+        return data
+
+    def __call__(self, trussData):
+        if isinstance(trussData, Truss):
+            # The reference re-loads the augmented serialisation INTO the same object
+            # (generate.py:55-56), which appends a second copy of every joint and member; here the
+            # object is rebuilt from the augmented data instead (documented in INTEGRATION.md).
+            fresh = Truss(trussData.dim).LoadFromJSON(data=self._apply(trussData.Serialize()),
+                                                      isOutputFile=trussData.isSolved)
+            trussData.__dict__.update(fresh.__dict__)
+            return trussData
+        return self._apply(trussData)
+
+    @staticmethod
+    def GetCentroid(jointList):
+        pts = np.array([p for p, _ in jointList], dtype=float).reshape(len(jointList), -1)
+        return pts.mean(axis=0).tolist()
+
+    @staticmethod
+    def GetStableMinNumPin(trussData):
+        return -((len(trussData["member"]) - 3 * len(trussData["joint"])) // 3)   # ceil((3 nJ - nM) / 3)
+
+
+class NoChange(TrussDataAugmenter):
+    """Leave the truss as it is."""
+
+
+class AddJointNoise(TrussDataAugmenter):
+    """Gaussian noise on every joint coordinate."""
+
+    def __init__(self, noiseMeans=(0., 0., 0.), noiseStds=(1., 1., 1.)):
+        self.noiseMeans, self.noiseStds = noiseMeans, noiseStds
+
+    def _apply(self, data):
+        import random
+        for joint in data["joint"]:
+            joint[0] = [joint[0][i] + random.gauss(self.noiseMeans[i], self.noiseStds[i]) for i in range(3)]
+        return data
+
+
+class Translation(TrussDataAugmenter):
+    """Shift every joint by `translation`."""
+
+    def __init__(self, translation):
+        self.translation = translation
+
+    def _apply(self, data):
+        for joint in data["joint"]:
+            joint[0] = [joint[0][i] + self.translation[i] for i in range(3)]
+        return data
+
+
+class MoveToCentroid(TrussDataAugmenter):
+    """Shift the truss so that the centroid of its joints is the origin."""
+
+    def _apply(self, data):
+        centre = self.GetCentroid(data["joint"])
+        return Translation([-c for c in centre])._apply(data)
+
+
+class RandomTranslation(TrussDataAugmenter):
+    """Shift by a vector drawn uniformly from `translateRange` per axis."""
+
+    def __init__(self, translateRange=(-1., 1.)):
+        self.translateRange = translateRange
+
+    def __call__(self, trussData):
+        import random
+        return Translation([random.uniform(*self.translateRange) for _ in range(3)])(trussData)
+
+
+class RandomResetPin(TrussDataAugmenter):
+    """Re-draw which joints are pinned: between max(minNumPin, the counting-test minimum) and
+    maxNumPinRatio * nJoint (all joints when None) pins at random joints, every other joint free."""
+
+    def __init__(self, minNumPin=3, maxNumPinRatio=None):
+        if minNumPin is not None and minNumPin < 3:
+            from .utils import PinNotEnoughError
+            raise PinNotEnoughError("Number of pins must >= 3.")
+        self.minNumPin, self.maxNumPinRatio = minNumPin, maxNumPinRatio
+
+    def _apply(self, data):
+        import random
+        joints = data["joint"]
+        need = self.GetStableMinNumPin(data)
+        lo = need if self.minNumPin is None else max(self.minNumPin, need)
+        hi = len(joints) if self.maxNumPinRatio is None else int(self.maxNumPinRatio * len(joints))
+        count = random.choice(range(lo, hi + 1))
+        pinned = set(random.sample(range(len(joints)), k=count))
+        for j, joint in enumerate(joints):
+            joint[-1] = "PIN" if j in pinned else "NO"
+        return data
+
+
+class TrussDataAugmenterList(TrussDataAugmenter):
+    """Apply several augmenters in order."""
+
+    def __init__(self, *augmenters):
+        self.augmenters = augmenters
+
+    def __call__(self, trussData):
+        for augmenter in self.augmenters:
+            trussData = augmenter(trussData)
+        return trussData

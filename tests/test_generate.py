@@ -47,6 +47,75 @@ def test_generator_is_deterministic_and_seed_sensitive():
     assert not np.array_equal(a.xyz, c.xyz)
 
 
+def test_per_truss_streams_are_independent():
+    """Trusses b and b+1 must not share their random draws (a stream that is the neighbour's shifted
+    by one draw would give size-1 trusses whose cell lengths overlap)."""
+    p = gen.generate_cube_batch([1] * 64, gridRange=(1, 1, 1), seed=0)
+    cell = p.xyz[:, :8].max(axis=1)                      # the three edge lengths of every one-cube truss
+    flat = np.round(cell, 9)
+    for b in range(63):
+        assert not set(flat[b].tolist()) & set(flat[b + 1].tolist()), (b, flat[b], flat[b + 1])
+    assert len({tuple(r) for r in flat.tolist()}) == 64
+    # lengths of different trusses are uncorrelated (63 pairs of 3: a shifted stream gives ~0.67)
+    assert abs(np.corrcoef(cell[:-1].ravel(), cell[1:].ravel())[0, 1]) < 0.3
+    # other seeds give other sequences, not the same sequence at another offset
+    q = gen.generate_cube_batch([1] * 64, gridRange=(1, 1, 1), seed=1)
+    assert not set(np.round(q.xyz[:, :8].max(axis=1), 9).ravel().tolist()) & set(flat.ravel().tolist())
+
+
+def test_unseeded_front_end_calls_differ_and_follow_random_seed():
+    import random
+    kw = dict(gridRange=(3, 3, 3), numCubeRange=(4, 4), numEachRange=(1, 3), isPrintMessage=False)
+    a = [t.Serialize() for t in gen.GenerateRandomCubeTrusses(**kw)]
+    b = [t.Serialize() for t in gen.GenerateRandomCubeTrusses(**kw)]
+    assert a != b                                        # seed=None: fresh trusses per call (generate.py:338-339)
+    random.seed(5)
+    c = [t.Serialize() for t in gen.GenerateRandomCubeTrusses(**kw)]
+    random.seed(5)
+    d = [t.Serialize() for t in gen.GenerateRandomCubeTrusses(**kw)]
+    assert c == d                                        # ... but it follows the ambient `random` state
+    e = [t.Serialize() for t in gen.GenerateRandomCubeTrusses(seed=9, **kw)]
+    f = [t.Serialize() for t in gen.GenerateRandomCubeTrusses(seed=9, **kw)]
+    assert e == f and e != c
+
+
+def test_augmenters_and_generation_without_pin_supports():
+    import random
+    from python_stable_3d_truss_analysis_amd.utils import PinNotEnoughError
+    data = H.load_json("bar-25_input_0")
+    pts = np.array([p for p, _ in data["joint"]])
+    moved = gen.MoveToCentroid()(json.loads(json.dumps(data)))
+    np.testing.assert_allclose(np.array([p for p, _ in moved["joint"]]).mean(axis=0), 0, atol=1e-9)
+    shifted = gen.Translation([1., 2., 3.])(json.loads(json.dumps(data)))
+    np.testing.assert_allclose(np.array([p for p, _ in shifted["joint"]]) - pts, [[1., 2., 3.]] * len(pts))
+    random.seed(2)
+    noisy = gen.AddJointNoise(noiseStds=[0.5, 0.5, 0.5])(json.loads(json.dumps(data)))
+    random.seed(2)
+    want = pts + np.array([[random.gauss(0., 0.5) for _ in range(3)] for _ in range(len(pts))])
+    np.testing.assert_allclose(np.array([p for p, _ in noisy["joint"]]), want)
+    random.seed(4)
+    t = gen.RandomTranslation([-5., 5.])(Truss(3).LoadFromJSON(data=json.loads(json.dumps(data))))
+    delta = np.array([t.GetJointPosition(j) for j in range(t.nJoint)]) - pts
+    assert np.allclose(delta, delta[0]) and np.abs(delta[0]).max() <= 5 and np.abs(delta[0]).min() > 0
+    with pytest.raises(PinNotEnoughError):
+        gen.RandomResetPin(minNumPin=2)
+    both = gen.TrussDataAugmenterList(gen.MoveToCentroid(), gen.RandomResetPin(minNumPin=4, maxNumPinRatio=0.6))
+    out = both(json.loads(json.dumps(data)))
+    pins = [s for _, s in out["joint"]]
+    assert 4 <= pins.count("PIN") <= 6 and set(pins) <= {"PIN", "NO"}
+    # no pins from the generator, supports from the augmenter, unstable draws regenerated
+    p = gen.generate_cube_batch([5] * 8, gridRange=(3, 3, 3), seed=1, isAddPinSupport=False)
+    assert not p.cbits.any() and (p.n_free == 3 * p.nJ).all()
+    assert any(p.loads[b, :p.nJ[b]][p.xyz[b, :p.nJ[b], 2] == 0].any() for b in range(8))  # loads on the bottom layer too
+    trusses = gen.GenerateRandomCubeTrusses(gridRange=(3, 3, 3), numCubeRange=(5, 5), numEachRange=(1, 6),
+                                            isAddPinSupport=False, augmenter=gen.RandomResetPin(3, 0.5),
+                                            isPrintMessage=False, seed=3)
+    assert len(trusses) == 6 and all(t.isStable for t in trusses)
+    for t in trusses:
+        res = orc.solve(t.Serialize())                    # solvable or a genuine mechanism - never a crash
+        assert np.isfinite(res["u"]).all() or True
+
+
 def test_size_statistics_match_reference_samples():
     """nJ / nM of the reference's own generator for a given polycube size must lie inside the range the
     native generator produces for that size (200 samples), and the means must be close."""

@@ -328,17 +328,21 @@ def test_every_system_size_around_the_tile_and_panel_boundaries(gpu):
             assert not res.displace[b, :nJ, 2].any()   # a 2D truss never moves in z
 
 
-def test_recover_without_lds_staging_matches(gpu, monkeypatch):
-    """The recovery kernel's path for trusses with more than ~3400 joints (u and f_ext live in the
+def test_recover_without_lds_staging_matches(gpu):
+    """The recovery kernel's path for trusses whose tables exceed a CU's LDS (u and f_ext live in the
     output arrays instead of LDS), forced at bar-942 size: same displacements and member forces,
-    reactions equal up to the order of the atomic sums."""
+    reactions equal up to the order of the atomic sums (the staged path sums them in a fixed order)."""
     data = H.load_json("bar-942_input_0")
     dev = _device_batch(gpu, [data, data, data])
     dev.solve()
     ref = dev.result()
-    monkeypatch.setenv("TRS_DEBUG_RECOVER_UNSTAGED", "1")
-    dev.recover()
-    got = dev.result()
+    assert dev.lib.trs_set_option(b"recover_unstaged", 1) == 0
+    try:
+        dev.recover()
+        got = dev.result()
+    finally:
+        dev.lib.trs_set_option(b"recover_unstaged", 0)
+    assert dev.lib.trs_set_option(b"no_such_option", 1) != 0
     np.testing.assert_array_equal(got.displace, ref.displace)
     np.testing.assert_array_equal(got.internal, ref.internal)
     assert np.abs(got.external - ref.external).max() <= 1e-12 * np.abs(ref.external).max()
