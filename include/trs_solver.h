@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TRS_ABI_VERSION 3
+#define TRS_ABI_VERSION 4
 
 /* trs_assemble flags */
 #define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests) */
@@ -52,7 +52,8 @@ extern "C" {
 int trs_abi_version(void);
 
 /* Process-wide switches for tests and diagnostics (no effect on results):
- *   "recover_unstaged" 0/1  force trs_recover's path for trusses whose tables exceed a CU's LDS.
+ *   "recover_unstaged" 0/1  force trs_recover's path for trusses whose tables exceed a CU's LDS;
+ *   "small_path"       1/0  let trs_solve take the fused small-system kernel (default 1).
  * Returns 0, or hipErrorInvalidValue for an unknown name. */
 int trs_set_option(const char *name, int value);
 
@@ -129,7 +130,30 @@ int trs_fitness(int B, int nJ_max, int nM_max, const double *xyz, const int32_t 
                 double *weight /* [B] */, double *stress_vio /* [B] */, double *disp_vio /* [B] */,
                 void *stream);
 
-/* The whole Truss.Solve() pipeline (truss.py:329-364) on one stream:
+/* Fused path for SMALL trusses: the whole of Truss.Solve() (truss.py:329-364: dofmap, assembly,
+ * Cholesky with the load vector riding along, back substitution, recovery) in ONE kernel, one
+ * work-group per truss, the stiffness matrix resident in that work-group's LDS (it never reaches HBM).
+ * For batches whose largest reduced system has n_max_bound <= 128 free DOFs and whose tables fit a CU's
+ * LDS: trs_solve_small_fits() says whether a batch shape qualifies (1) or not (0); trs_solve_small
+ * returns hipErrorInvalidValue for a shape that does not.  Covers bar-6 ... bar-120, cube-7 and every
+ * individual of the reference's GA (ga.py:139-149).
+ *   free_index, n_free : optional outputs of the numbering stage (NULL = not wanted)
+ *   weight != NULL     : also the GA reductions of trs_fitness (rho, allow_* as there)
+ *   info[b]            : 0, k > 0 (pivot k not positive) or -1 (n_free[b] > n_max_bound: nothing solved)
+ * Bit-reproducible (fixed summation orders, no floating-point atomics). */
+int trs_solve_small_fits(int nJ_max, int nM_max, int n_max_bound);
+int trs_solve_small(int B, int nJ_max, int nM_max, int n_max_bound,
+                    const double *xyz, const int32_t *conn, const double *E, const double *A,
+                    const uint8_t *cbits, const double *loads, const int32_t *nJ, const int32_t *nM,
+                    double *u /* [B][nJ_max][3] */, double *f_ext /* [B][nJ_max][3] */,
+                    double *N /* [B][nM_max] */, int32_t *info /* [B] */,
+                    int32_t *free_index /* [B][nJ_max*3] or NULL */, int32_t *n_free /* [B] or NULL */,
+                    const double *rho /* [B][nM_max] or NULL */, double allow_stress, double allow_displace,
+                    double *weight /* [B] or NULL */, double *stress_vio /* [B] */, double *disp_vio /* [B] */,
+                    void *stream);
+
+/* The whole Truss.Solve() pipeline (truss.py:329-364) on one stream: trs_solve_small when the batch
+ * shape qualifies (the slab, uf, work and env arguments are then not touched), otherwise
  * dofmap -> assemble -> potrf -> potrs -> recover.  Workspace pointers as above. */
 int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound,
               const double *xyz, const int32_t *conn, const double *E, const double *A,

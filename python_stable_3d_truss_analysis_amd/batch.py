@@ -174,16 +174,18 @@ class DeviceBatch:
     """
     INPUT_FIELDS = ("xyz", "conn", "E", "A", "rho", "cbits", "loads", "nJ", "nM")
 
-    def __init__(self, packed: PackedBatch, device=None, use_envelope=True):
-        """`use_envelope=False` treats every reduced stiffness matrix as dense (no tile skipping)."""
+    def __init__(self, packed: PackedBatch, device=None, use_envelope=True, use_small=True):
+        """`use_envelope=False` treats every reduced stiffness matrix as dense (no tile skipping);
+        `use_small=False` keeps a batch of small trusses off the fused single-kernel path
+        (`trs_solve_small`) and sends it through the staged pipeline."""
         torch, dev = _require_gpu(device)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.packed = packed
         self._setup(torch, dev, {f: up(getattr(packed, f)) for f in self.INPUT_FIELDS},
-                    packed.B, packed.nJ_max, packed.nM_max, packed.n_max, use_envelope)
+                    packed.B, packed.nJ_max, packed.nM_max, packed.n_max, use_envelope, use_small)
 
     @classmethod
-    def from_device(cls, tensors, n_max, use_envelope=True):
+    def from_device(cls, tensors, n_max, use_envelope=True, use_small=True):
         """A batch whose inputs already live on the device: `tensors` maps INPUT_FIELDS to contiguous
         device tensors of the padded shapes (see PackedBatch); `n_max` bounds the free DOFs per truss
         (host-known, it sizes the slab)."""
@@ -191,10 +193,10 @@ class DeviceBatch:
         self = cls.__new__(cls)
         self.packed = None
         self._setup(torch, dev, tensors, int(tensors["xyz"].shape[0]), int(tensors["xyz"].shape[1]),
-                    int(tensors["conn"].shape[1]), int(n_max), use_envelope)
+                    int(tensors["conn"].shape[1]), int(n_max), use_envelope, use_small)
         return self
 
-    def _setup(self, torch, dev, tensors, B, nJ_max, nM_max, n_max, use_envelope):
+    def _setup(self, torch, dev, tensors, B, nJ_max, nM_max, n_max, use_envelope, use_small=True):
         self.torch, self.device = torch, dev
         self.lib = _capi.load()
         self.B, self.nJ_max, self.nM_max, self.n_max = B, nJ_max, nM_max, n_max
@@ -202,20 +204,37 @@ class DeviceBatch:
             setattr(self, f, tensors[f])
         self.ld = self.lib.trs_slab_ld(self.n_max)
         self.rows = self.lib.trs_slab_rows(self.n_max)
+        #: the whole batch goes through the fused small-system kernel (n_free <= 128, tables fit the LDS)
+        self.small = bool(use_small and self.lib.trs_solve_small_fits(nJ_max, nM_max, n_max))
+        self.use_envelope = use_envelope
         self.free_index = torch.empty([B, self.nJ_max * 3], dtype=torch.int32, device=dev)
         self.n_free = torch.empty([B], dtype=torch.int32, device=dev)
-        self.S = torch.empty([B, self.rows, self.ld], dtype=torch.float64, device=dev)
-        if os.environ.get("TRS_DEBUG_POISON"):   # tests: any read of a never-written slab entry shows
-            self.S.fill_(float("nan"))
-        self.uf = torch.empty([B, self.rows], dtype=torch.float64, device=dev)
         self.u = torch.empty([B, self.nJ_max, 3], dtype=torch.float64, device=dev)
         self.f_ext = torch.empty([B, self.nJ_max, 3], dtype=torch.float64, device=dev)
         self.N = torch.empty([B, self.nM_max], dtype=torch.float64, device=dev)
         self.info = torch.empty([B], dtype=torch.int32, device=dev)
-        work_bytes = self.lib.trs_assemble_work_bytes(self.nJ_max, self.nM_max, self.n_max)
-        self.work = torch.empty([B, work_bytes], dtype=torch.uint8, device=dev)
-        self.env = torch.zeros([B, self.lib.trs_env_ints(self.n_max)], dtype=torch.int32, device=dev) \
-            if use_envelope else None
+        self._slab = None   # (S, uf, work, env): the staged pipeline's workspace, allocated on first use
+
+    def _workspace(self):
+        """Stiffness slab, reduced solution, assembly workspace and envelope metadata of the staged
+        pipeline; a batch on the fused small path never allocates them."""
+        if self._slab is None:
+            torch, dev, B = self.torch, self.device, self.B
+            S = torch.empty([B, self.rows, self.ld], dtype=torch.float64, device=dev)
+            if os.environ.get("TRS_DEBUG_POISON"):   # tests: any read of a never-written slab entry shows
+                S.fill_(float("nan"))
+            uf = torch.empty([B, self.rows], dtype=torch.float64, device=dev)
+            work_bytes = self.lib.trs_assemble_work_bytes(self.nJ_max, self.nM_max, self.n_max)
+            work = torch.empty([B, work_bytes], dtype=torch.uint8, device=dev)
+            env = torch.zeros([B, self.lib.trs_env_ints(self.n_max)], dtype=torch.int32, device=dev) \
+                if self.use_envelope else None
+            self._slab = (S, uf, work, env)
+        return self._slab
+
+    S = property(lambda self: self._workspace()[0])
+    uf = property(lambda self: self._workspace()[1])
+    work = property(lambda self: self._workspace()[2])
+    env = property(lambda self: self._workspace()[3])
 
     # -- individual stages (used by the parity tests and the benchmark) ------------------
     def _stream(self):
@@ -254,8 +273,45 @@ class DeviceBatch:
             self.nJ.data_ptr(), self.nM.data_ptr(), self.uf.data_ptr(), self.rows, self.u.data_ptr(),
             self.f_ext.data_ptr(), self.N.data_ptr(), self._stream()), "trs_recover")
 
+    def _solve_small(self, fitness=None):
+        """`trs_solve_small`: the whole of `Truss.Solve()` in one kernel (optionally with the GA
+        reductions); returns the three reduction tensors or None."""
+        t = self.torch
+        out = [None, None, None]
+        if fitness is not None:
+            out = [t.empty([self.B], dtype=t.float64, device=self.device) for _ in range(3)]
+        ptr = lambda x: None if x is None else x.data_ptr()
+        with t.cuda.device(self.device):
+            _capi.check(self.lib.trs_solve_small(
+                self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), self.conn.data_ptr(),
+                self.E.data_ptr(), self.A.data_ptr(), self.cbits.data_ptr(), self.loads.data_ptr(),
+                self.nJ.data_ptr(), self.nM.data_ptr(), self.u.data_ptr(), self.f_ext.data_ptr(),
+                self.N.data_ptr(), self.info.data_ptr(), self.free_index.data_ptr(), self.n_free.data_ptr(),
+                self.rho.data_ptr() if fitness is not None else None,
+                float(fitness[0]) if fitness else 0.0, float(fitness[1]) if fitness else 0.0,
+                ptr(out[0]), ptr(out[1]), ptr(out[2]), self._stream()), "trs_solve_small")
+        return out if fitness is not None else None
+
+    def solve_fitness(self, allow_stress, allow_displace):
+        """Solve and reduce to (weight, stress_violation, displacement_violation) per truss - one kernel
+        on the fused small path, `solve()` + `fitness()` otherwise (GA generation, ga.py:139-160)."""
+        if self.small:
+            return self._solve_small((allow_stress, allow_displace))
+        self.solve()
+        return self.fitness(allow_stress, allow_displace)
+
     def solve(self):
-        """The whole pipeline, one C call, asynchronous on the current stream."""
+        """The whole pipeline, asynchronous on the current stream: one kernel for a batch of small
+        trusses (`trs_solve_small`), otherwise one C call that enqueues the five stages."""
+        if self.small:
+            self._solve_small()
+            return
+        if self.lib.trs_solve_small_fits(self.nJ_max, self.nM_max, self.n_max):
+            # small enough for the fused kernel but asked to stay off it: the stages one by one
+            # (trs_solve itself would pick the fused kernel)
+            with self.torch.cuda.device(self.device):
+                self.dofmap(); self.assemble(); self.potrf(); self.potrs(); self.recover()
+            return
         with self.torch.cuda.device(self.device):
             _capi.check(self.lib.trs_solve(
                 self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), self.conn.data_ptr(),
@@ -350,14 +406,33 @@ def permute_joints(packed: PackedBatch, perm):
                        packed.dim, packed.n_free)
 
 
+SMALL_N = 128  # largest reduced system of the fused small-system kernel (csrc/small.hip)
+
+
 def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30):
-    """Group the trusses of a ragged batch for launching: same padded system size n_pad per group
-    (the slab and every work-group of a launch are then uniform) and at most `max_slab_bytes` of
-    stiffness slab per launch.  Returns a list of index arrays (their union is range(B))."""
+    """Group the trusses of a ragged batch for launching.  Returns a list of index arrays (their union
+    is range(B)).
+
+    * Every truss with at most SMALL_N free DOFs goes into ONE group when that group qualifies for the
+      fused small-system kernel (`trs_solve_small_fits` on the group's own maxima): that kernel sizes
+      its work per truss, so nothing is gained by splitting it.
+    * The others are grouped by padded system size n_pad (the slab and every work-group of a launch
+      are then uniform), at most `max_slab_bytes` of stiffness slab per launch."""
     n_pad = (packed.n_free.astype(np.int64) + 63) // 64 * 64
     groups = []
-    for size in np.unique(n_pad):
-        idx = np.flatnonzero(n_pad == size)
+    small = np.flatnonzero(packed.n_free <= SMALL_N)
+    taken = np.zeros(packed.B, dtype=bool)
+    if len(small) and len(np.unique(n_pad[small])) > 1:
+        try:
+            fits = _capi.load().trs_solve_small_fits(int(packed.nJ[small].max()), int(packed.nM[small].max()),
+                                                     int(packed.n_free[small].max()))
+        except HipExtensionError:
+            fits = 0
+        if fits:
+            groups.append(small)
+            taken[small] = True
+    for size in np.unique(n_pad[~taken]):
+        idx = np.flatnonzero((n_pad == size) & ~taken)
         per_truss = max(1, int(size) * (int(size) + 16) * 8)
         step = max(1, max_slab_bytes // per_truss)
         groups.extend(idx[i: i + step] for i in range(0, len(idx), step))

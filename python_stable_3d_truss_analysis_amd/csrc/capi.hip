@@ -16,6 +16,11 @@ int trs_recover_launch(int, int, int, const double*, const int*, const double*, 
                        const double*, const int*, const int*, const int*, const double*, int, double*,
                        double*, double*, hipStream_t);
 void trs_recover_set_unstaged(int);
+int trs_solve_small_fits(int, int, int);
+int trs_solve_small_launch(int, int, int, int, const double*, const int*, const double*, const double*,
+                           const uint8_t*, const double*, const int*, const int*, double*, double*, double*,
+                           int*, int*, int*, const double*, double, double, double*, double*, double*,
+                           hipStream_t);
 int trs_fitness_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const int*, const int*, const double*, const double*, double, double, double*,
                        double*, double*, hipStream_t);
@@ -32,12 +37,30 @@ extern "C" {
 
 int trs_abi_version(void) { return TRS_ABI_VERSION; }
 
+static int g_small_path = 1;  // trs_set_option("small_path", 0): trs_solve never takes the fused kernel
+
 int trs_set_option(const char* name, int value) {
     if (name != nullptr && strcmp(name, "recover_unstaged") == 0) {
         trs_recover_set_unstaged(value != 0);
         return 0;
     }
+    if (name != nullptr && strcmp(name, "small_path") == 0) {
+        g_small_path = value != 0;
+        return 0;
+    }
     return (int)hipErrorInvalidValue;
+}
+
+int trs_solve_small(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz, const int32_t* conn,
+                    const double* E, const double* A, const uint8_t* cbits, const double* loads,
+                    const int32_t* nJ, const int32_t* nM, double* u, double* f_ext, double* N, int32_t* info,
+                    int32_t* free_index, int32_t* n_free, const double* rho, double allow_stress,
+                    double allow_displace, double* weight, double* stress_vio, double* disp_vio,
+                    void* stream) {
+    if (B < 0) return (int)hipErrorInvalidValue;
+    return trs_solve_small_launch(B, nJ_max, nM_max, n_max_bound, xyz, conn, E, A, cbits, loads, nJ, nM, u,
+                                  f_ext, N, info, free_index, n_free, rho, allow_stress, allow_displace,
+                                  weight, stress_vio, disp_vio, (hipStream_t)stream);
 }
 
 int trs_slab_rows(int n_max) { return trs_round_up(n_max < 1 ? 1 : n_max, TRS_NB); }
@@ -100,6 +123,10 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
               const int32_t* nJ, const int32_t* nM, int32_t* free_index, int32_t* n_free, int ld,
               int slab_rows, double* S, double* uf, int ld_uf, double* u, double* f_ext, double* N,
               int32_t* info, void* work, int32_t* env, void* stream) {
+    if (g_small_path && trs_solve_small_fits(nJ_max, nM_max, n_max_bound))  // everything in one kernel
+        return trs_solve_small(B, nJ_max, nM_max, n_max_bound, xyz, conn, E, A, cbits, loads, nJ, nM, u,
+                               f_ext, N, info, free_index, n_free, nullptr, 0.0, 0.0, nullptr, nullptr,
+                               nullptr, stream);
     if (n_max_bound > slab_rows) return (int)hipErrorInvalidValue;
     int rc = trs_dofmap(B, nJ_max, cbits, nJ, free_index, n_free, stream);
     if (rc) return rc;

@@ -145,8 +145,7 @@ class GA:
         loci[:count, :self.nMember] = torch.tensor(genes, dtype=torch.int64, device=dev.device)
         sections = self._typeTable[loci]                    # [B, nM, 3] = (a, e, density)
         dev.A.copy_(sections[..., 0]); dev.E.copy_(sections[..., 1]); dev.rho.copy_(sections[..., 2])
-        dev.solve()
-        weight, stressVio, dispVio = dev.fitness(self.allowStress, self.allowDisplace)
+        weight, stressVio, dispVio = dev.solve_fitness(self.allowStress, self.allowDisplace)
         info = dev.info[:count].cpu().numpy()
         if info.any():
             raise np.linalg.LinAlgError("Singular matrix")

@@ -164,8 +164,7 @@ def _worker_main(device, conn, test_solver):
                     dev.packed = None  # the host arrays are views of shared memory that goes away
                 else:
                     dev.set_sections(shard.A, shard.E, shard.rho)
-                dev.solve()
-                w, sv, dv = dev.fitness(*opts["fitness"])
+                w, sv, dv = dev.solve_fitness(*opts["fitness"])
                 outs["fit"][idx, 0] = w.cpu().numpy()
                 outs["fit"][idx, 1] = sv.cpu().numpy()
                 outs["fit"][idx, 2] = dv.cpu().numpy()

@@ -184,9 +184,14 @@ def test_size_buckets_and_trimmed_cover_a_ragged_batch():
     p = batch.pack_json(datas).replicate(3)
     groups = batch.size_buckets(p)
     assert sorted(np.concatenate(groups).tolist()) == list(range(p.B))
+    merged = 0
     for idx in groups:
         pads = (p.n_free[idx] + 63) // 64 * 64
-        assert len(set(pads.tolist())) == 1                  # one padded size per launch
+        if p.n_free[idx].max() <= batch.SMALL_N:             # the fused small-system kernel: one group
+            merged += 1
+        else:
+            assert len(set(pads.tolist())) == 1              # otherwise one padded size per launch
+    assert merged == 1 and sum(int(p.n_free[i].max() <= batch.SMALL_N) for i in groups) == 1
     small = batch.size_buckets(p, max_slab_bytes=1 << 20)     # memory bound splits a bucket
     assert len(small) > len(groups) and sum(len(i) for i in small) == p.B
     sub = p.take(groups[0]).trimmed()
