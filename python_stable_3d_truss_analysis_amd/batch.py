@@ -439,6 +439,63 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30):
     return groups
 
 
+def _solve_small_host(packed: PackedBatch, torch, dev, variants):
+    """Host arrays in -> host results out for a batch that qualifies for the fused small-system kernel
+    as a whole: ONE upload (every input packed into one byte buffer), one `trs_solve_small` launch per
+    section variant, ONE download.  This is what `Truss.Solve()` of a small truss costs: two copies and
+    a kernel.  Returns a list of `BatchResult`, one per variant."""
+    lib = _capi.load()
+    B, nJm, nMm = packed.B, packed.nJ_max, packed.nM_max
+    ins = [("xyz", packed.xyz, np.float64), ("loads", packed.loads, np.float64), ("E", packed.E, np.float64),
+           ("A", packed.A, np.float64), ("conn", packed.conn, np.int32), ("nJ", packed.nJ, np.int32),
+           ("nM", packed.nM, np.int32), ("cbits", packed.cbits, np.uint8)]
+    off, total = {}, 0
+    for name, arr, dt in ins:
+        off[name] = total
+        total += (arr.size * np.dtype(dt).itemsize + 15) // 16 * 16
+    own = len(variants) > 1 or variants[0] is not None
+    if own:   # the solves read A_var / E_var; the batch's own sections stay in A / E
+        off["A_var"], off["E_var"] = total, total + (packed.A.size * 8 + 15) // 16 * 16
+        total = off["E_var"] + (packed.A.size * 8 + 15) // 16 * 16
+    host = np.empty([total], dtype=np.uint8)
+    for name, arr, dt in ins:
+        host[off[name]: off[name] + arr.size * np.dtype(dt).itemsize].view(dt)[:] = arr.reshape(-1)
+    din = torch.from_numpy(host).to(dev)
+    nu, nn = B * nJm * 3 * 8, B * nMm * 8
+    per = 2 * nu + nn + (B * 4 + 15) // 16 * 16
+    dout = torch.empty([len(variants) * per], dtype=torch.uint8, device=dev)
+    pin, pout = din.data_ptr(), dout.data_ptr()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    nsec = B * nMm * 8
+    with torch.cuda.device(dev):
+        for slot, sec in enumerate(variants):
+            a_ptr, e_ptr = pin + off["A"], pin + off["E"]
+            if own:
+                va = din[off["A_var"]: off["A_var"] + nsec].view(torch.float64)
+                ve = din[off["E_var"]: off["E_var"] + nsec].view(torch.float64)
+                if sec is None:
+                    va.copy_(din[off["A"]: off["A"] + nsec].view(torch.float64))
+                    ve.copy_(din[off["E"]: off["E"] + nsec].view(torch.float64))
+                else:
+                    va.fill_(float(sec[0])); ve.fill_(float(sec[1]))
+                a_ptr, e_ptr = pin + off["A_var"], pin + off["E_var"]
+            o = pout + slot * per
+            _capi.check(lib.trs_solve_small(
+                B, nJm, nMm, packed.n_max, pin + off["xyz"], pin + off["conn"], e_ptr, a_ptr,
+                pin + off["cbits"], pin + off["loads"], pin + off["nJ"], pin + off["nM"], o, o + nu,
+                o + 2 * nu, o + 2 * nu + nn, None, None, None, 0.0, 0.0, None, None, None, stream),
+                "trs_solve_small")
+    hout = dout.cpu().numpy()
+    results = []
+    for slot in range(len(variants)):
+        h = hout[slot * per: (slot + 1) * per]
+        results.append(BatchResult(h[:nu].view(np.float64).reshape(B, nJm, 3),
+                                   h[nu: 2 * nu].view(np.float64).reshape(B, nJm, 3),
+                                   h[2 * nu: 2 * nu + nn].view(np.float64).reshape(B, nMm),
+                                   h[2 * nu + nn: 2 * nu + nn + 4 * B].view(np.int32).copy()))
+    return results
+
+
 def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False, sections=None):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
 
@@ -459,6 +516,10 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     torch, dev = _require_gpu(device)
     B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
     variants = [None] if sections is None else list(sections)
+    if B and _capi.load().trs_solve_small_fits(nJ_max, nM_max, packed.n_max):
+        # every truss is small: the fused kernel, no bucketing, no reordering (nothing to gain from it)
+        out = _solve_small_host(packed, torch, dev, variants)
+        return out[0] if sections is None else out
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
     full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS}
     perm = None

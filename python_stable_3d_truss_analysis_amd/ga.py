@@ -142,15 +142,23 @@ class GA:
         dev = self._population_device(len(genes))
         count = len(genes)
         loci = torch.zeros([dev.B, dev.nM_max], dtype=torch.int64, device=dev.device)
-        loci[:count, :self.nMember] = torch.tensor(genes, dtype=torch.int64, device=dev.device)
+        loci[:count, :self.nMember] = torch.from_numpy(np.asarray(genes, dtype=np.int64)).to(dev.device)
         sections = self._typeTable[loci]                    # [B, nM, 3] = (a, e, density)
         dev.A.copy_(sections[..., 0]); dev.E.copy_(sections[..., 1]); dev.rho.copy_(sections[..., 2])
-        weight, stressVio, dispVio = dev.solve_fitness(self.allowStress, self.allowDisplace)
-        info = dev.info[:count].cpu().numpy()
-        if info.any():
+        # one kernel for solve + reductions on the fused small path; one download for everything
+        terms = torch.stack(dev.solve_fitness(self.allowStress, self.allowDisplace) +
+                            [dev.info.to(torch.float64)])[:, :count].cpu().numpy()
+        if terms[3].any():
             raise np.linalg.LinAlgError("Singular matrix")
-        w, s, d = (t[:count].cpu().numpy() for t in (weight, stressVio, dispVio))
-        return [self._compose(float(w[i]), float(s[i]), float(d[i])) for i in range(count)]
+        return self._compose_many(terms[0], terms[1], terms[2])
+
+    def _compose_many(self, weight, stressViolation, displaceViolation):
+        """`_compose` over arrays (same arithmetic, element by element)."""
+        okStress = np.abs(stressViolation) < ZERO_EPS
+        okDisplace = np.abs(displaceViolation) < ZERO_EPS
+        fitness = weight + np.where(okStress, 0.0, stressViolation / self.allowStress * PENALTY)
+        fitness = fitness + np.where(okDisplace, 0.0, displaceViolation / self.allowDisplace * PENALTY)
+        return list(zip(fitness.tolist(), okStress.tolist(), okDisplace.tolist()))
 
     def _fitness_sharded(self, genes):
         """The population split over the GPUs of `devices` (`shard.ShardedSolver.fitness`)."""
@@ -168,7 +176,7 @@ class GA:
         fit, info = self._pool.fitness(pop, self.allowStress, self.allowDisplace, geometry_key=id(self))
         if info.any():
             raise np.linalg.LinAlgError("Singular matrix")
-        return [self._compose(float(fit[i, 0]), float(fit[i, 1]), float(fit[i, 2])) for i in range(count)]
+        return self._compose_many(fit[:, 0], fit[:, 1], fit[:, 2])
 
     def close(self):
         """Stop the per-GPU worker processes of a multi-device GA (no-op otherwise)."""
