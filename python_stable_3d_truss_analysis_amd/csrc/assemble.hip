@@ -19,6 +19,13 @@
 //     (row, column) is written by exactly one thread), then each row goes to HBM exactly once with
 //     16-byte coalesced stores, the tile being zeroed behind the reads.  Rows wider than the tile
 //     are written in column segments.
+//
+//  phase 1c (narrow envelopes, the default for them): instead of slab rows the matrix leaves the kernel
+//     as compact per-tile entry lists (trs_common.h, TrsCompactLayout) and the load vector goes to `uf`:
+//     two threads per joint walk its adjacency list once to count and once to emit the joint's 3x3
+//     blocks (the values and their summation order are those of phase 1, bit for bit), entries
+//     counting-sorted by tile through LDS counters.  The fused factorisation (trs_potrf_fused_kernel)
+//     forms the tiles from these lists where it consumes them: K_ff never exists densely in HBM.
 #include "trs_common.h"
 #include "../../include/trs_solver.h"
 
@@ -48,9 +55,15 @@ __host__ __device__ inline AsmLds asm_lds_layout(int nJ_max, int nM_max, int n_p
     l.rhs = l.diag + (size_t)nJ_max * 48;                        // double[n_pad_max]
     l.tile = l.rhs + (size_t)n_pad_max * 8;                      // double[TR][WT + 16]
     l.ints = l.tile + (size_t)TR * (WT + 16) * 8;
-    const size_t nints = (size_t)6 * nJ_max + 1 + 2 * (size_t)nM_max + 2 * (n_pad_max / 16) + n_pad_max;
+    const size_t nints = (size_t)6 * nJ_max + 1 + 2 * (size_t)nM_max + 2 * (n_pad_max / 16) + n_pad_max + 4;
     l.total = (l.ints + nints * 4 + 15) / 16 * 16;
     return l;
+}
+// LDS tables of the compact path (ints: tile begin, tile fill cursor, tbase); they alias the row tile,
+// which that path does not use
+__host__ __device__ inline size_t asm_compact_tab_bytes(int n_pad_max) {
+    const int nch = n_pad_max / 16;
+    return ((size_t)2 * nch * (TRS_NARROW_MAX_BELOW + 4) + nch + 1) * 4;
 }
 
 // MODE fixes, at compile time, the address space of the per-truss tables (LDS loads, not flat ones):
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     const int* __restrict__ nM_arr, const int nJ_max, const int nM_max, const int n_pad_max,
     const int ld, const size_t slab_stride, double* __restrict__ S_all, const int flags,
     unsigned char* __restrict__ work_all, const size_t work_stride, int* __restrict__ env_all,
-    const int WT) {
+    const int WT, double* __restrict__ uf_all, const int ld_uf, const size_t ck_off, const int compact_ok) {
     extern __shared__ unsigned char lds_raw[];
     constexpr int TR = tile_rows(NT);
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -102,6 +115,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     int* chunkmin = reinterpret_cast<int*>(adj + 2 * nM_max);                                // [n_pad_max/16] first tile per chunk
     int* cendl = chunkmin + n_pad_max / 16;                          // [n_pad_max/16] envelope: stored extent
     int* rowdof = cendl + n_pad_max / 16;                            // [n_pad_max] DOF of a reduced row
+    int* wgflag = rowdof + n_pad_max;                                // [4] [0]: this matrix leaves as entry lists
 
     // ---- phase 0 ---------------------------------------------------------------------------------------
     const double* X = xyz + (size_t)b * 3 * nJ_max;
@@ -243,7 +257,23 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             for (int off = 32; off > 0; off >>= 1) widest = max(widest, __shfl_xor(widest, off));
             // which factorisation kernel will take this matrix decides the shape of the stored part
             const bool narrow = widest <= TRS_NARROW_MAX_BELOW;
-            if (tid == 0) env[n_pad_max / 16 + n_pad_max / 64] = (narrow ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1;
+            // narrow envelopes leave as compact entry lists (phase 1c) unless the caller asked for the
+            // slab (tests, A/B runs) or the list tables do not fit next to this batch's other tables
+            const bool compact = narrow && compact_ok != 0 && !full && uf_all != nullptr &&
+                                 (flags & TRS_ASM_NO_COMPACT) == 0;
+            if (tid == 0) {
+                int* meta = env + n_pad_max / 16 + n_pad_max / 64;
+                meta[0] = ((narrow ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1) | (compact ? TRS_ENV_COMPACT : 0);
+                if (compact) {  // where the factorisation finds the lists: byte offsets / 16 from `work`
+                    const TrsCompactLayout ck = trs_compact_layout(nJ_max, nM_max, n_pad_max);
+                    const size_t base = (size_t)b * work_stride + ck_off;
+                    meta[1] = (int)((base + ck.tdesc) >> 4);
+                    meta[2] = (int)((base + ck.tbase) >> 4);
+                    meta[3] = (int)((base + ck.epos) >> 4);
+                    meta[4] = (int)((base + ck.eval) >> 4);
+                }
+                wgflag[0] = compact ? 1 : 0;
+            }
             for (int t = tid; t < nch; t += 64) {  // t | 3 lies in the same step: reads precede the writes
                 const int e = narrow ? max(cendl[t] + 1, (t | 3) + 1) : cendl[t | 3] + 1 + (TRS_WIDE_ITEM - 1);
                 __builtin_amdgcn_wave_barrier();
@@ -252,6 +282,140 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             }
         }
         __syncthreads();
+    }
+
+    // ---- phase 1c: compact per-tile entry lists (narrow envelopes) -----------------------------------------
+    if (has_env && wgflag[0] != 0) {
+        const TrsCompactLayout ck = trs_compact_layout(nJ_max, nM_max, n_pad_max);
+        unsigned char* cbase = work_all + (size_t)b * work_stride + ck_off;
+        int* tdesc = reinterpret_cast<int*>(cbase + ck.tdesc);
+        int* tbase_g = reinterpret_cast<int*>(cbase + ck.tbase);
+        unsigned short* epos = reinterpret_cast<unsigned short*>(cbase + ck.epos);
+        double* eval = reinterpret_cast<double*>(cbase + ck.eval);
+        int* tbeg = reinterpret_cast<int*>(lds_raw + lay.tile);  // [ntile] first entry of a tile (after the scan)
+        int* tfill = tbeg + ck.ntile_cap;                        // [ntile] entries counted / emitted so far
+        int* tbase = tfill + ck.ntile_cap;                       // [nch + 1] first tile id of chunk t
+        if (tid < 64) {  // tbase = exclusive scan of the stored extent per chunk
+            int base = 0;
+            for (int t0 = 0; t0 < nch; t0 += 64) {
+                const int t = t0 + tid;
+                const int v = t < nch ? cendl[t] - t : 0;
+                int incl = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int up = __shfl_up(incl, off);
+                    if (tid >= off) incl += up;
+                }
+                if (t < nch) {
+                    tbase[t] = base + incl - v;
+                    tbase_g[t] = base + incl - v;
+                }
+                base += __shfl(incl, 63);
+            }
+            if (tid == 0) {
+                tbase[nch] = base;
+                tbase_g[nch] = base;
+            }
+        }
+        __syncthreads();
+        const int ntile = tbase[nch];
+        for (int x = tid; x < ntile; x += NT) tfill[x] = 0;
+        // load vector: f at the free rows, zero on the padding
+        double* ufb = uf_all + (size_t)b * ld_uf;
+        for (int c = tid; c < npad; c += NT) ufb[c] = c < n ? rhs[c] : 0.0;
+        __syncthreads();
+        // Two threads per joint walk its sorted adjacency list (positions h, h + 2, ...); thread h = 0 also
+        // takes the joint's own block.  PASS 0 counts the entries per tile, PASS 1 emits them.
+        // An entry (row c, column q) is stored when q >= 16 floor(c / 16): the upper part by 16-row tiles,
+        // diagonal tiles whole - exactly the slab entries of phase 1.
+        auto tile_of = [&](int c, int q) { return tbase[c >> 4] + ((q >> 4) - (c >> 4)); };
+        auto slot_of = [&](int c, int q) { return ((c & 15) >> 2) * 64 + (c & 3) * 16 + (q & 15); };
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int w = tid; w < 2 * nJ; w += NT) {
+                const int a = w >> 1, h = w & 1;
+                const int ca[3] = {fi[3 * a], fi[3 * a + 1], fi[3 * a + 2]};
+                if ((ca[0] & ca[1] & ca[2]) < 0) continue;  // all three constrained: no rows
+                auto emit = [&](int c, int q, double v) {
+                    if (c < 0 || q < 0 || q < (c & ~15)) return;
+                    const int tl = tile_of(c, q);
+                    if (pass == 0) {
+                        atomicAdd(&tfill[tl], 1);
+                    } else {
+                        const int e = tbeg[tl] + atomicAdd(&tfill[tl], 1);
+                        eval[e] = v;
+                        epos[e] = (unsigned short)slot_of(c, q);
+                    }
+                };
+                if (h == 0) {  // the joint's own 3x3 block [xx xy xz; xy yy yz; xz yz zz]
+                    const double* dg = diag + 6 * a;
+                    const double d[3][3] = {{dg[0], dg[1], dg[2]}, {dg[1], dg[3], dg[4]}, {dg[2], dg[4], dg[5]}};
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int sI = 0; sI < 3; ++sI) emit(ca[r], ca[sI], d[r][sI]);
+                }
+                const unsigned* list = adj + start[a];
+                const int deg = cnt[a];
+                for (int i = h; i < deg; i += 2) {
+                    const int other = (int)(list[i] >> 16);
+                    if (i > 0 && (int)(list[i - 1] >> 16) == other) continue;  // not the head of a run
+                    const int co[3] = {fi[3 * other], fi[3 * other + 1], fi[3 * other + 2]};
+                    double v[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+                    if (pass == 1) {
+                        int q = i;
+                        do {  // parallel members between the same two joints, in member order (as phase 1)
+                            const int m = (int)(list[q] & 0xffffu);
+                            const double k = mk[m];
+                            const double c3[3] = {mc[3 * m], mc[3 * m + 1], mc[3 * m + 2]};
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                for (int sI = 0; sI < 3; ++sI) v[r][sI] -= k * (c3[r] * c3[sI]);
+                            ++q;
+                        } while (q < deg && (int)(list[q] >> 16) == other);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int sI = 0; sI < 3; ++sI) emit(ca[r], co[sI], v[r][sI]);
+                }
+            }
+            for (int c = n + tid; c < npad; c += NT) {  // identity padding
+                const int tl = tile_of(c, c);
+                if (pass == 0) {
+                    atomicAdd(&tfill[tl], 1);
+                } else {
+                    const int e = tbeg[tl] + atomicAdd(&tfill[tl], 1);
+                    eval[e] = 1.0;
+                    epos[e] = (unsigned short)slot_of(c, c);
+                }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                if (tid < 64) {  // exclusive scan of the counts; descriptors to memory
+                    int base = 0;
+                    for (int x0 = 0; x0 < ntile; x0 += 64) {
+                        const int x = x0 + tid;
+                        const int v = x < ntile ? tfill[x] : 0;
+                        int incl = v;
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const int up = __shfl_up(incl, off);
+                            if (tid >= off) incl += up;
+                        }
+                        if (x < ntile) {
+                            tbeg[x] = base + incl - v;
+                            tdesc[2 * x] = base + incl - v;
+                            tdesc[2 * x + 1] = v;
+                            tfill[x] = 0;
+                        }
+                        base += __shfl(incl, 63);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        return;
     }
 
     // ---- phase 1 ---------------------------------------------------------------------------------------
@@ -360,8 +524,16 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
 // tile width, table placement (kernel MODE) and work-group size for a batch shape
 struct AsmPlan {
     int WT, mode, big;
-    size_t lds, work;  // LDS per work-group, workspace bytes per truss
+    size_t lds, work;  // LDS per work-group, workspace bytes per truss (tables/geometry + compact lists)
+    int compact_ok;    // the tables of the compact path fit (they alias the row tile)
+    size_t ck_off;     // offset of the compact-list region inside a truss's workspace
 };
+inline AsmPlan asm_finish(AsmPlan p, int nJ_max, int nM_max, int n_pad_max, size_t tile_bytes) {
+    p.ck_off = p.work;
+    p.compact_ok = p.mode != 2 && tile_bytes >= asm_compact_tab_bytes(n_pad_max);
+    p.work += trs_compact_layout(nJ_max, nM_max < 1 ? 1 : nM_max, n_pad_max).total;
+    return p;
+}
 inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
     // Tables and member geometry in LDS first - two 512-thread work-groups per CU (80 KiB each), else
     // one 1024-thread work-group with the whole 160 KiB: a global load in the row loop has to wait for
@@ -378,14 +550,16 @@ inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
             int WT = (int)((budget - fixed) / (TR * 8)) - 16;
             WT = WT / 16 * 16;
             if (WT > n_pad_max) WT = n_pad_max;
-            return AsmPlan{WT, g ? 0 : 1, big, asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, g, TR).total,
-                           geom_bytes};
+            return asm_finish(AsmPlan{WT, g ? 0 : 1, big, asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, g, TR).total,
+                                      geom_bytes, 0, 0},
+                              nJ_max, nM_max, n_pad_max, (size_t)TR * (WT + 16) * 8);
         }
     }
     const int TR = tile_rows(NT_DEFAULT);
     const int WT = n_pad_max < 240 ? n_pad_max : 240;  // 64 KiB of tile: two work-groups per CU
     const size_t tables = asm_lds_layout(nJ_max, nM_max, n_pad_max, -16, 1, TR).total;
-    return AsmPlan{WT, 2, 0, (size_t)TR * (WT + 16) * 8, (tables + 255) / 256 * 256};
+    return asm_finish(AsmPlan{WT, 2, 0, (size_t)TR * (WT + 16) * 8, (tables + 255) / 256 * 256, 0, 0}, nJ_max,
+                      nM_max, n_pad_max, 0);
 }
 
 }  // namespace
@@ -403,6 +577,9 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
     // adjacency keys (unsigned): other joint (16 bits) | member (16 bits)
     if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;
     const AsmPlan plan = asm_plan(nJ_max, nM_max, n_pad_max);
+    // compact-list offsets travel as (byte offset / 16) in 32-bit metadata fields
+    const int compact_ok = plan.compact_ok && uf != nullptr && ld_uf >= n_pad_max &&
+                           (((size_t)B * plan.work) >> 4) < ((size_t)1 << 31);
     // the dynamic-LDS ceiling of an instantiation is raised once per process, not per launch
 #define TRS_LAUNCH_ASSEMBLE(MODE, NTV)                                                                   \
     do {                                                                                                 \
@@ -413,7 +590,7 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
         hipLaunchKernelGGL((trs_assemble_kernel<MODE, NTV>), dim3(B), dim3(NTV), plan.lds, stream, xyz,  \
                            conn, E, A, loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max, ld, \
                            slab_stride, S, flags, static_cast<unsigned char*>(work), plan.work, env,     \
-                           plan.WT);                                                                     \
+                           plan.WT, uf, ld_uf, plan.ck_off, compact_ok);                                 \
     } while (0)
     if (plan.mode == 2)
         TRS_LAUNCH_ASSEMBLE(2, NT_DEFAULT);

@@ -68,6 +68,39 @@ __host__ __device__ static inline TrsEnv trs_env_of(const int* env, int b, int n
     return TrsEnv{base, base + n_pad_max / 16, base + trs_env_cend_offset(n_pad_max),
                   base[n_pad_max / 16 + n_pad_max / 64]};
 }
-// the matrix goes to the wave-per-matrix kernel (slack == TRS_NARROW_ITEM - 1) or to the
-// work-group kernel
-__host__ __device__ static inline bool trs_env_is_narrow(const TrsEnv& e) { return e.slack == TRS_NARROW_ITEM - 1; }
+// Routing code in `slack`: low byte = chunks an item may overhang (TRS_NARROW_ITEM - 1: the matrix goes
+// to a wave-per-matrix kernel, TRS_WIDE_ITEM - 1: to the work-group kernel); bit 8 set = the stiffness
+// matrix was NOT written to the slab but as compact per-tile entry lists (below) for the fused
+// wave-per-matrix kernel, which forms the tiles where it consumes them.
+#define TRS_ENV_COMPACT 0x100
+__host__ __device__ static inline bool trs_env_is_narrow(const TrsEnv& e) { return (e.slack & 0xff) == TRS_NARROW_ITEM - 1; }
+__host__ __device__ static inline bool trs_env_is_compact(const TrsEnv& e) { return (e.slack & TRS_ENV_COMPACT) != 0; }
+
+// ---- compact stiffness matrix of a narrow-envelope truss (per truss, in the assembly workspace) --------
+// K_ff as per-TILE entry lists instead of slab tiles: the factorisation reads ~10 bytes per non-zero
+// instead of 2 KB per 16 x 16 tile, and the stiffness matrix never exists in HBM in dense form.
+//   tile (t, q), t <= q < cend[t]  = slab rows 16 t .. 16 t + 15 (columns of L), matrix rows 16 q .. 16 q + 15
+//   tile id                        = tbase[t] + (q - t)
+//   tdesc[id]                      = (first entry, number of entries)
+//   entry e                        = value eval[e] at D-form slot epos[e] = r * 64 + lq * 16 + li of the
+//                                    tile: slab row 16 t + lq + 4 r, column 16 q + li  (the register
+//                                    layout tile_load() produces; potrf.hip)
+// At most TRS_NARROW_MAX_BELOW + 4 tiles per chunk (the narrow condition); entries: every member gives
+// one 3 x 3 block in the upper part (9) and possibly its mirror inside a diagonal tile (9), every joint
+// one diagonal block (9), plus the identity padding.
+struct TrsCompactLayout {
+    size_t tdesc, tbase, epos, eval, total;  // byte offsets inside the truss's compact region
+    int ntile_cap, ecap;
+};
+__host__ __device__ static inline TrsCompactLayout trs_compact_layout(int nJ_max, int nM_max, int n_pad_max) {
+    TrsCompactLayout l;
+    const int nch = n_pad_max / 16;
+    l.ntile_cap = nch * (TRS_NARROW_MAX_BELOW + 4);
+    l.ecap = 18 * nM_max + 9 * nJ_max + 64;
+    l.tdesc = 0;                                                    // int2[ntile_cap]
+    l.tbase = l.tdesc + (size_t)l.ntile_cap * 8;                    // int[nch + 1]
+    l.epos = (l.tbase + (size_t)(nch + 1) * 4 + 15) / 16 * 16;      // unsigned short[ecap]
+    l.eval = (l.epos + (size_t)l.ecap * 2 + 15) / 16 * 16;          // double[ecap]
+    l.total = (l.eval + (size_t)l.ecap * 8 + 255) / 256 * 256;
+    return l;
+}

@@ -95,10 +95,15 @@ def test_small_kernel_fitness_reductions_match_trs_fitness():
     packed.A[:] = rng.uniform(0.5, 8.0, size=packed.A.shape)
     packed.rho[:] = rng.uniform(0.1, 1.0, size=packed.rho.shape)
     dev = batch.DeviceBatch(packed)
-    w, sv, dv = (t.cpu().numpy() for t in dev.solve_fitness(20000.0, 2.0))
+    dev.solve()
+    first = dev.result()
+    stress = np.abs(first.internal[:, :120]) / packed.A[:, :120]
+    allow_s = float(np.median(stress.max(axis=1)))                       # about half the trusses violate
+    allow_d = float(np.median(np.linalg.norm(first.displace, axis=2).max(axis=1)))
+    w, sv, dv = (t.cpu().numpy() for t in dev.solve_fitness(allow_s, allow_d))
     res = dev.result()
-    assert not res.info.any() and (sv > 0).any() and (dv > 0).any()
-    w2, sv2, dv2 = (t.cpu().numpy() for t in dev.fitness(20000.0, 2.0))   # trs_fitness on the same u, N
+    assert not res.info.any() and (sv > 0).any() and (dv > 0).any() and (sv == 0).any() and (dv == 0).any()
+    w2, sv2, dv2 = (t.cpu().numpy() for t in dev.fitness(allow_s, allow_d))   # trs_fitness on the same u, N
     np.testing.assert_array_equal(w, w2)
     np.testing.assert_allclose(sv, sv2, rtol=1e-13, atol=0)
     np.testing.assert_allclose(dv, dv2, rtol=1e-13, atol=0)
@@ -107,8 +112,8 @@ def test_small_kernel_fitness_reductions_match_trs_fitness():
         for m, mem in enumerate(d["member"]):
             mem[1] = [float(packed.A[b, m]), float(packed.E[b, m]), float(packed.rho[b, m])]
         ref = orc.solve(d)
-        fit, ok_s, ok_d = orc.fitness_terms(d, ref, 20000.0, 2.0)
-        mine = w[b] + sv[b] / 20000.0 * 1e5 + dv[b] / 2.0 * 1e5
+        fit, ok_s, ok_d = orc.fitness_terms(d, ref, allow_s, allow_d)
+        mine = w[b] + sv[b] / allow_s * 1e5 + dv[b] / allow_d * 1e5
         assert mine == pytest.approx(fit, rel=1e-9)
 
 
