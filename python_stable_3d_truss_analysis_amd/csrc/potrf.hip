@@ -268,13 +268,38 @@ __device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelL
     lds_signal_add(&sm.f_done);
 }
 
+// ---- the load vector / forward-substituted load vector as a plain array ---------------------------------
+// uf[c] holds f[c] before and y[c] after the factorisation of column c's panel.  As an MFMA operand the
+// load vector is a 16-wide chunk of which only column 0 is not zero: lane (lq, li) of a fragment is
+// uf[c0 + lq] for li == 0 and zero otherwise - one 8-byte load for four lanes, the rest goes through the
+// out-of-range lane offset (no memory traffic).
+struct LoadVec {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff;  // (lane >> 4) * 8 for the lanes li == 0, out of range for the others
+    __device__ __forceinline__ double load(int soff) const {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+    }
+    __device__ __forceinline__ void store(int soff, double v) const {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
+    }
+};
+// D-form tile of the load vector for the 16 columns c0 .. c0+15: comp r of lane (lq, 0) <-> uf[c0 + lq + 4 r]
+__device__ __forceinline__ void ytile_load(d4& acc, const LoadVec& Y, int c0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Y.load((c0 + 4 * r) * 8);
+}
+__device__ __forceinline__ void ytile_store(const d4& acc, const LoadVec& Y, int c0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Y.store((c0 + 4 * r) * 8, acc[r]);
+}
+
 // ---- I: one work item = NV consecutive 16-row chunks below the diagonal block ---------------------
 // Update (streams L from HBM, B-side fragments shared through L1/L2), wait for the factor wave,
 // solve against the diagonal block with the fragments it left in LDS, store.
 template <int NV>
 __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const int rowbase,
                                            const int kstart, PanelLds& sm, const int f_target,
-                                           Stamps& st) {
+                                           Stamps& st, const LoadVec* Y = nullptr) {
     const int lane = threadIdx.x & 63;
     d4 acc[NV][CT];
 #pragma unroll
@@ -345,6 +370,10 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int s = 0; s < CT; ++s) tile_store(acc[v][s], S, r0 + 16 * s, rowbase + 16 * v);
+    if (Y != nullptr) {  // the load column's item: y also goes to uf, where trs_potrs reads it
+#pragma unroll
+        for (int s = 0; s < CT; ++s) ytile_store(acc[0][s], *Y, r0 + 16 * s);
+    }
     st.mark(4);
 }
 
@@ -359,7 +388,8 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
 
 __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_kernel(
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
-    int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max) {
+    int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max,
+    double* __restrict__ uf_all, const int ld_uf) {
     __shared__ PanelLds sm;
     const int b = blockIdx.x;
     const int npad = trs_round_up(n_free[b], TRS_NB);
@@ -385,6 +415,9 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
     const bool has_env = env_all != nullptr;
     const TrsEnv env = has_env ? trs_env_of(env_all, b, n_pad_max) : TrsEnv{nullptr, nullptr, nullptr, 0};
     if (has_env && trs_env_is_narrow(env)) return;  // trs_potrf_narrow_kernel's matrix
+    LoadVec Y;
+    Y.rs = __builtin_amdgcn_make_buffer_rsrc(uf_all + (size_t)b * ld_uf, 0, ld_uf * (int)sizeof(double), 0x00020000);
+    Y.voff = (lane & 15) == 0 ? (unsigned)(lane >> 4) * 8u : Slab::gone;
 
     Stamps st;
     st.start();
@@ -425,7 +458,7 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
             if (item == nmain) {
                 // L y = f rides along as the row n_pad.  Its own envelope is dense, but the panel's
                 // rows are zero (and unwritten) left of their envelope: start there.
-                panel_item<1>(S, r0, npad, has_env ? 16 * env.ft[4 * panel] : 0, sm, panel + 1, st);
+                panel_item<1>(S, r0, npad, has_env ? 16 * env.ft[4 * panel] : 0, sm, panel + 1, st, &Y);
                 continue;
             }
             const int c0 = 4 * panel + CT + item * RS;  // first chunk of the item
@@ -456,6 +489,57 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
     if (threadIdx.x == 0) info[b] = sm.info;
 }
 
+// ---- stiffness tiles formed from the compact per-tile entry lists (trs_common.h, TrsCompactLayout) ------
+// The wave scatters a tile's entries into a zeroed 2 KB LDS image in D-form order (ds_write_b64 at the
+// slot the assembly recorded), reads the image back as the four accumulator registers and re-zeroes it.
+// LDS operations of one wave complete in order, so no barrier is needed between the steps.
+struct KLists {
+    const int* tdesc;              // (first entry, count) per tile
+    const int* tbase;              // first tile id per slab chunk
+    __amdgpu_buffer_rsrc_t vals;   // double[]
+    __amdgpu_buffer_rsrc_t slots;  // unsigned short[]
+    lds_f64* img;                  // this wave's tile image, 256 doubles, all zero between tiles
+};
+struct TileFetch {  // round 0 of a tile's entries, in flight
+    double v;
+    unsigned p;
+    int beg, cnt;
+};
+__device__ __forceinline__ TileFetch ktile_issue(const KLists& K, const int id, const bool exists = true) {
+    TileFetch f;
+    f.beg = 0;
+    f.cnt = 0;
+    f.v = 0.0;
+    f.p = 0;
+    if (!exists) return f;  // wave-uniform: a tile outside the envelope costs nothing
+    f.beg = K.tdesc[2 * id];
+    f.cnt = K.tdesc[2 * id + 1];
+    const int lane = threadIdx.x & 63;
+    const unsigned e = (unsigned)(f.beg + lane);
+    const unsigned gone = lane < f.cnt ? 0u : 0x80000000u;
+    f.v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(K.vals, (e * 8u) | gone, 0, 0));
+    f.p = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(K.slots, (e * 2u) | gone, 0, 0);
+    return f;
+}
+__device__ __forceinline__ void ktile_finish(d4& acc, const KLists& K, const TileFetch& f) {
+    const int lane = threadIdx.x & 63;
+    if (lane < f.cnt) K.img[f.p] = f.v;
+    for (int e0 = 64; e0 < f.cnt; e0 += 64) {  // dense tiles: further rounds of 64 entries
+        const unsigned e = (unsigned)(f.beg + e0 + lane);
+        if (e0 + lane < f.cnt) {
+            const double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(K.vals, e * 8u, 0, 0));
+            const unsigned p = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(K.slots, e * 2u, 0, 0);
+            K.img[p] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = K.img[r * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) K.img[r * 64 + lane] = 0.0;
+}
+
 // ======================================================================================================
 // Narrow-envelope variant: one WAVE per matrix, four matrices per work-group, no barriers, no
 // hand-offs between waves.  The wave keeps the panel's ten diagonal-block tiles (the six L_{u,s}
@@ -481,10 +565,11 @@ constexpr int DEPTHN = TRS_NARROW_DEPTH;  // k-steps of fragments in flight (div
 // Tile (chunk q, column tile tt) is stored iff q < cend[tt] (trs_common.h); what is not stored is an
 // exact zero of L: its loads return 0 and its stores are dropped through the lane offset.
 //   kstart = 16 ft[c0]: first column of chunk c0's envelope; the chunks after it may start later.
-template <int NV>
+template <int NV, bool FUSED>
 __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const int c0, const int kstart,
                                             const int* __restrict__ ft, const int* __restrict__ cend,
-                                            const double* Wl, const d4 (&t)[CT][CT]) {
+                                            const double* Wl, const d4 (&t)[CT][CT], const KLists& K,
+                                            const int (&tb)[CT]) {
     const int rowbase = 16 * c0, lane = threadIdx.x & 63;
     d4 acc[NV][CT];
     // cend is non-decreasing: chunk c0+v is stored in the panel's tiles smin[v] .. 3 (one scalar
@@ -498,15 +583,33 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
 #pragma unroll
         for (int v = 0; v < NV; ++v) smin[v] += c0 + v >= ce ? 1 : 0;
     }
+    if constexpr (FUSED) {
+        // the stiffness tiles of the item come from the entry lists; the next tile's entries are
+        // requested while the current tile's image is formed
+        auto fetch = [&](int i) {  // i = v * CT + s
+            const int v = i / CT, s = i % CT;
+            return ktile_issue(K, tb[s] + (c0 + v) - (r0 / 16 + s), s >= smin[v]);
+        };
+        TileFetch cur = fetch(0);
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int s = 0; s < CT; ++s) {
-            const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
-            const unsigned vo = S.lane_off(s >= smin[v]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[v][s][r] = S.load_at(vo, o + r * (S.ld * 32));
+        for (int i = 0; i < NV * CT; ++i) {
+            TileFetch nxt = cur;
+            if (i + 1 < NV * CT) nxt = fetch(i + 1);
+            if (i % CT >= smin[i / CT]) ktile_finish(acc[i / CT][i % CT], K, cur);
+            else acc[i / CT][i % CT] = d4{0.0, 0.0, 0.0, 0.0};
+            cur = nxt;
         }
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int s = 0; s < CT; ++s) {
+                const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
+                const unsigned vo = S.lane_off(s >= smin[v]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[v][s][r] = S.load_at(vo, o + r * (S.ld * 32));
+            }
+    }
     if (r0 > kstart) {
         int ob = S.at(kstart, r0);
         int oa = S.at(kstart, rowbase);
@@ -577,13 +680,22 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
 #define TRS_NARROW_MATRICES_PER_WG 4
 #endif
 constexpr int MPW = TRS_NARROW_MATRICES_PER_WG;  // waves (= matrices) per work-group of the narrow kernel
-__global__ __launch_bounds__(64 * MPW, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narrow_kernel(
+#ifndef TRS_FUSED_WAVES_PER_SIMD
+#define TRS_FUSED_WAVES_PER_SIMD 2
+#endif
+// FUSED = false: the stiffness matrix and the load column are read from the slab (trs_assemble wrote them);
+// FUSED = true : the stiffness tiles are formed from the compact entry lists and the load vector is read
+//                from uf - K_ff never existed in HBM in dense form.  Both leave L in the slab and y in uf.
+template <bool FUSED>
+__global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narrow_kernel(
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
-    int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max, const int B) {
+    int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max, const int B,
+    const unsigned char* __restrict__ work, double* __restrict__ uf_all, const int ld_uf) {
     __shared__ ChScratch scratch[MPW];
     __shared__ double wlds[MPW][CT][256];  // per wave: inv(L_ss), s = 0..3, as A-fragments (PanelLds::W layout)
     __shared__ double ylds[MPW][CT][4][4];  // per wave: the load column (lanes li == 0 of its tiles), parked
                                           // during the factorisation
+    __shared__ double kimg[FUSED ? MPW : 1][256];  // per wave: image of the stiffness tile being formed
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * MPW + wave;
@@ -594,12 +706,28 @@ __global__ __launch_bounds__(64 * MPW, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf
         return;
     }
     const TrsEnv env = trs_env_of(env_all, b, n_pad_max);
-    if (!trs_env_is_narrow(env)) return;  // trs_potrf_kernel's matrix
+    if (!trs_env_is_narrow(env) || trs_env_is_compact(env) != FUSED) return;  // another kernel's matrix
     Slab S;
     S.rs = __builtin_amdgcn_make_buffer_rsrc(S_all + (size_t)b * slab_stride, 0,
                                              (int)(slab_stride * sizeof(double)), 0x00020000);
     S.ld = ld;
     S.loff = ((unsigned)(lane >> 4) * (unsigned)ld + (unsigned)(lane & 15)) * 8u;
+    LoadVec Y;
+    Y.rs = __builtin_amdgcn_make_buffer_rsrc(uf_all + (size_t)b * ld_uf, 0, ld_uf * (int)sizeof(double), 0x00020000);
+    Y.voff = (lane & 15) == 0 ? (unsigned)(lane >> 4) * 8u : Slab::gone;
+    KLists K{};
+    if constexpr (FUSED) {
+        const int* meta = env.last + n_pad_max / 64;  // slack | list offsets / 16 (written by trs_assemble)
+        K.tdesc = reinterpret_cast<const int*>(work + ((size_t)(unsigned)meta[1] << 4));
+        K.tbase = reinterpret_cast<const int*>(work + ((size_t)(unsigned)meta[2] << 4));
+        K.slots = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(work) + ((size_t)(unsigned)meta[3] << 4),
+                                                    0, 0x7fffffff, 0x00020000);
+        K.vals = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(work) + ((size_t)(unsigned)meta[4] << 4),
+                                                   0, 0x7fffffff, 0x00020000);
+        K.img = (lds_f64*)&kimg[wave][0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) K.img[r * 64 + lane] = 0.0;
+    }
     ChScratch& sc = scratch[wave];
     double* Wl = &wlds[wave][0][0];
     int bad_col = 0;
@@ -614,18 +742,38 @@ __global__ __launch_bounds__(64 * MPW, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf
         // D: the ten lower tiles of the diagonal block, and the load column's four tiles (L y = f rides
         // along as row n_pad: same k range and B-side fragments as the block, which are read once)
         d4 t[CT][CT], y[CT];
+        int tb[CT] = {0, 0, 0, 0};  // first tile id of the panel's four slab chunks (FUSED)
+        if constexpr (FUSED) {
 #pragma unroll
-        for (int u = 0; u < CT; ++u)
+            for (int s = 0; s < CT; ++s) tb[s] = K.tbase[4 * panel + s];
 #pragma unroll
-            for (int s = 0; s <= u; ++s) tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+            for (int s = 0; s < CT; ++s) ytile_load(y[s], Y, r0 + 16 * s);
+            // tile (slab chunk 4 panel + s, matrix rows chunk 4 panel + u) has id tb[s] + u - s
+            constexpr int TU[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, TS[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+            TileFetch cur = ktile_issue(K, tb[0]);
 #pragma unroll
-        for (int s = 0; s < CT; ++s) tile_load(y[s], S, r0 + 16 * s, npad);
+            for (int q = 0; q < 10; ++q) {  // the next tile's entries are in flight while this image is formed
+                TileFetch nxt = cur;
+                if (q + 1 < 10) nxt = ktile_issue(K, tb[TS[q + 1]] + TU[q + 1] - TS[q + 1]);
+                ktile_finish(t[TU[q]][TS[q]], K, cur);
+                cur = nxt;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < CT; ++u)
+#pragma unroll
+                for (int s = 0; s <= u; ++s) tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+#pragma unroll
+            for (int s = 0; s < CT; ++s) tile_load(y[s], S, r0 + 16 * s, npad);
+        }
         st.drain();
         st.mark(0);
         if (r0 > kd) {
             const int step = S.ld * 32;
             int ok = S.at(kd, r0);
-            int oy = S.at(kd, npad);
+            int oy = FUSED ? kd * 8 : S.at(kd, npad);   // FUSED: rows kd .. of uf (32 bytes per k-step)
+            const int ystep = FUSED ? 32 : step;
+            auto yload = [&](int off) { return FUSED ? Y.load(off) : S.load(off); };
             double fb[DEPTHN][CT], fy[DEPTHN];
             auto bload = [&](int off, int c, int k) {  // zero where chunk c is left of its envelope
                 return S.load_at(S.lane_off(k >= bks[c]), off + 128 * c);
@@ -634,7 +782,7 @@ __global__ __launch_bounds__(64 * MPW, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf
             for (int d = 0; d < DEPTHN - 1; ++d) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c) fb[d][c] = bload(ok + d * step, c, kd + 4 * d);
-                fy[d] = S.load(oy + d * step);
+                fy[d] = yload(oy + d * ystep);
             }
             for (int k0 = kd; k0 < r0; k0 += 4 * DEPTHN) {
 #pragma unroll
@@ -643,7 +791,7 @@ __global__ __launch_bounds__(64 * MPW, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf
 #pragma unroll
                     for (int c = 0; c < CT; ++c)
                         fb[nd][c] = bload(ok + (d + DEPTHN - 1) * step, c, k0 + 4 * (d + DEPTHN - 1));
-                    fy[nd] = S.load(oy + (d + DEPTHN - 1) * step);
+                    fy[nd] = yload(oy + (d + DEPTHN - 1) * ystep);
                     // chunk u of the block has non-zeros in these four columns only from bks[u] on
                     // (non-decreasing in u): products with an all-zero operand are not issued
                     const int kk = k0 + 4 * d;
@@ -656,7 +804,7 @@ __global__ __launch_bounds__(64 * MPW, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf
                         }
                 }
                 ok += DEPTHN * step;
-                oy += DEPTHN * step;
+                oy += DEPTHN * ystep;
             }
         }
         st.mark(1);
@@ -717,7 +865,8 @@ __global__ __launch_bounds__(64 * MPW, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf
             for (int s2 = s + 1; s2 < CT; ++s2)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[s2] = mfma_f64_negA(t[s2][s][r], y[s][r], y[s2]);
-            tile_store(y[s], S, r0 + 16 * s, npad);
+            if constexpr (!FUSED) tile_store(y[s], S, r0 + 16 * s, npad);  // later panels read it from the slab
+            ytile_store(y[s], Y, r0 + 16 * s);                             // trs_potrs reads y from uf
         }
         st.mark(3);
         // items: the chunks below the block that reach into this panel
@@ -726,13 +875,13 @@ __global__ __launch_bounds__(64 * MPW, TRS_NARROW_WAVES_PER_SIMD) void trs_potrf
             const int ks = 16 * env.ft[c0];
             const int left = lastq - c0 + 1;
             if (RSN >= 4 && left >= 4) {
-                narrow_item<(RSN >= 4 ? 4 : 1)>(S, r0, c0, ks, env.ft, env.cend, Wl, t);
+                narrow_item<(RSN >= 4 ? 4 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
                 c0 += 4;
             } else if (RSN >= 2 && left >= 2) {
-                narrow_item<(RSN >= 2 ? 2 : 1)>(S, r0, c0, ks, env.ft, env.cend, Wl, t);
+                narrow_item<(RSN >= 2 ? 2 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
                 c0 += 2;
             } else {
-                narrow_item<1>(S, r0, c0, ks, env.ft, env.cend, Wl, t);
+                narrow_item<1, FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
                 c0 += 1;
             }
         }
@@ -759,18 +908,27 @@ extern "C" int trs_debug_stamps(unsigned long long* host_out, int reset) {
 #endif
 
 extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
-                                double* S, int* info, const int* env, hipStream_t stream) {
+                                double* S, int* info, const int* env, const void* work, double* uf,
+                                int ld_uf, hipStream_t stream) {
     if (B <= 0) return 0;
     // a slab is addressed through one buffer descriptor with 32-bit byte offsets, the upper half of
     // the offset range being the "tile not stored" marker (Slab::gone)
     if (slab_stride * sizeof(double) >= (size_t)1 << 31) return (int)hipErrorInvalidValue;
+    if (uf == nullptr || ld_uf < n_pad_max) return (int)hipErrorInvalidValue;
     if (env != nullptr) {
-        hipLaunchKernelGGL(trs_potrf_narrow_kernel, dim3((B + MPW - 1) / MPW), dim3(64 * MPW), 0, stream, S, n_free, ld,
-                           slab_stride, info, env, n_pad_max, B);
-        const int rc = (int)hipGetLastError();
+        // both wave-per-matrix kernels are launched; each takes the matrices trs_assemble routed to it
+        hipLaunchKernelGGL(trs_potrf_narrow_kernel<true>, dim3((B + MPW - 1) / MPW), dim3(64 * MPW), 0, stream, S,
+                           n_free, ld, slab_stride, info, env, n_pad_max, B,
+                           static_cast<const unsigned char*>(work), uf, ld_uf);
+        int rc = (int)hipGetLastError();
+        if (rc) return rc;
+        hipLaunchKernelGGL(trs_potrf_narrow_kernel<false>, dim3((B + MPW - 1) / MPW), dim3(64 * MPW), 0, stream, S,
+                           n_free, ld, slab_stride, info, env, n_pad_max, B,
+                           static_cast<const unsigned char*>(work), uf, ld_uf);
+        rc = (int)hipGetLastError();
         if (rc) return rc;
     }
     hipLaunchKernelGGL(trs_potrf_kernel, dim3(B), dim3(NW * 64), 0, stream, S, n_free, ld,
-                       slab_stride, info, env, n_pad_max);
+                       slab_stride, info, env, n_pad_max, uf, ld_uf);
     return (int)hipGetLastError();
 }
