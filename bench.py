@@ -361,8 +361,10 @@ def main():
             nchm = dev.rows // 16
             env_ft, env_last = env[:nchm], env[nchm:nchm + dev.rows // 64]
             slack = int(env[nchm + dev.rows // 64])
-            narrow = slack == 1   # the kernel choice recorded by trs_assemble (csrc/trs_common.h)
-            potrf_kernel = "trs_potrf_narrow_kernel" if narrow else "trs_potrf_kernel"
+            narrow = (slack & 0xff) == 1   # the kernel choice recorded by trs_assemble (csrc/trs_common.h)
+            compact = bool(slack & 0x100)  # K_ff as compact entry lists, tiles formed in the factorisation
+            potrf_kernel = ("trs_potrf_narrow_kernel<true>" if compact else "trs_potrf_narrow_kernel<false>") \
+                if narrow else "trs_potrf_kernel"
             env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nchm]
             tile_flops = potrf_tile_flops(n, env_ft, env_last, env_cend, narrow)
             counts = algorithmic_counts(n, nJ, nM, env_cend)

@@ -30,9 +30,17 @@
  *      other entries with i >= 16*floor(c/16), i < n_pad + 16 are 0; entries left of the
  *      diagonal tile are never read or written unless TRS_ASM_FULL_SYMMETRIC is given.
  *    After trs_potrf_batched:  S[c][i] = U[c][i] (i >= c) with K_ff = U^T U (U = L^T), and
- *    S[c][n_pad] = y[c], the forward-substituted right-hand side (L y = f_f).  Inside every
+ *    uf[c] = y[c], the forward-substituted right-hand side (L y = f_f).  Inside every
  *    16 x 16 diagonal tile the entries below the diagonal (c > i, same tile) hold the strictly
  *    lower part of inv(L_tile) (its diagonal is 1 / U[c][c]); trs_potrs_batched uses it.
+ *
+ * Compact form (narrow envelopes, the default with envelope metadata): trusses whose envelope is
+ *    narrow enough for the wave-per-matrix factorisation do NOT get their stiffness matrix written to
+ *    the slab at all.  trs_assemble leaves it in the truss's share of `work` as per-tile entry lists
+ *    (value + position, ~10 bytes per non-zero instead of 2 KB per 16 x 16 tile; layout
+ *    TrsCompactLayout in csrc/trs_common.h) and the load vector in uf; trs_potrf_batched forms the
+ *    tiles from the lists where it consumes them and writes only the factor to the slab.  K_ff then
+ *    never exists in dense form in HBM.  TRS_ASM_NO_COMPACT keeps the slab form for such trusses.
  */
 #ifndef TRS_SOLVER_H
 #define TRS_SOLVER_H
@@ -47,7 +55,8 @@ extern "C" {
 #define TRS_ABI_VERSION 4
 
 /* trs_assemble flags */
-#define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests) */
+#define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests); implies the slab form */
+#define TRS_ASM_NO_COMPACT 2     /* narrow-envelope matrices too are written to the slab (tests, A/B runs) */
 
 int trs_abi_version(void);
 
@@ -76,9 +85,10 @@ int trs_dofmap(int B, int nJ_max, const uint8_t *cbits, const int32_t *nJ,
  * `env` is an int32 array of B * trs_env_ints(n_max) entries. */
 int trs_env_ints(int n_max);
 
-/* Bytes of assembly workspace PER TRUSS for a batch with these maxima (member stiffness and
- * direction cosines, used only when they do not fit the CU's LDS); the caller passes B times this
- * many bytes as `work`. */
+/* Bytes of assembly workspace PER TRUSS for a batch with these maxima: member stiffness and
+ * direction cosines when they do not fit the CU's LDS, and the compact entry lists of the stiffness
+ * matrix (see "Compact form" above), which trs_potrf_batched reads back.  The caller passes B times
+ * this many bytes as `work` to both. */
 size_t trs_assemble_work_bytes(int nJ_max, int nM_max, int n_max);
 
 /* Assembly of the reduced stiffness matrix and load vector.  Replaces Member.k/cosines/matK
@@ -93,7 +103,9 @@ int trs_assemble(int B, int nJ_max, int nM_max,
                  const int32_t *n_free, const int32_t *nJ, const int32_t *nM,
                  int ld, int slab_rows, double *S /* [B][slab_rows][ld] */, int flags,
                  void *work /* B * trs_assemble_work_bytes(...) */,
-                 int32_t *env /* out, B * trs_env_ints(...), or NULL */, void *stream);
+                 int32_t *env /* out, B * trs_env_ints(...), or NULL */,
+                 double *uf /* out [B][ld_uf]: the load vector of the trusses in compact form; NULL = slab form only */,
+                 int ld_uf, void *stream);
 
 /* Batched Cholesky factorisation with fused forward substitution of the right-hand-side
  * column.  Replaces the factorisation half of np.linalg.solve (truss.py:343; LAPACK dgesv in
@@ -101,12 +113,16 @@ int trs_assemble(int B, int nJ_max, int nM_max,
  * info[b] = 0 on success, k > 0 when the pivot of column k (1-based) is not positive
  * (the reference raises numpy.linalg.LinAlgError for an exactly singular matrix). */
 int trs_potrf_batched(int B, const int32_t *n_free, int ld, int slab_rows, double *S,
-                      int32_t *info /* [B] */, const int32_t *env /* or NULL */, void *stream);
+                      int32_t *info /* [B] */, const int32_t *env /* or NULL */,
+                      const void *work /* the buffer trs_assemble filled */,
+                      double *uf /* [B][ld_uf]: out y = L^-1 f (in: f, for the trusses in compact form) */,
+                      int ld_uf, void *stream);
 
-/* Back substitution U u_f = y.  Replaces the solve half of np.linalg.solve (truss.py:343).
- * uf[b][c] = reduced displacement c (c < n_free[b]); entries up to n_pad are written. */
+/* Back substitution U u_f = y, in place on uf.  Replaces the solve half of np.linalg.solve
+ * (truss.py:343).  In: uf[b][c] = y[c] (from trs_potrf_batched); out: uf[b][c] = reduced displacement c
+ * (c < n_free[b]); entries up to n_pad are written. */
 int trs_potrs_batched(int B, const int32_t *n_free, int ld, int slab_rows, const double *S,
-                      double *uf /* [B][ld_uf] */, int ld_uf, const int32_t *env /* or NULL */,
+                      double *uf /* inout [B][ld_uf] */, int ld_uf, const int32_t *env /* or NULL */,
                       void *stream);
 
 /* Result recovery.  Replaces the displacement scatter (truss.py:342), the reactions

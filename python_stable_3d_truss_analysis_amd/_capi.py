@@ -24,8 +24,8 @@ SIGNATURES = {
     "trs_dofmap": (_I, [_I, _I, _P, _P, _P, _P, _P]),
     "trs_env_ints": (_I, [_I]),
     "trs_assemble_work_bytes": (ctypes.c_size_t, [_I, _I, _I]),
-    "trs_assemble": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P]),
-    "trs_potrf_batched": (_I, [_I, _P, _I, _I, _P, _P, _P, _P]),
+    "trs_assemble": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "trs_potrf_batched": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "trs_potrs_batched": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
     "trs_recover": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "trs_fitness": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _P, _P, _P, _P]),

@@ -253,12 +253,13 @@ class DeviceBatch:
             self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
             self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
             self.n_free.data_ptr(), self.nJ.data_ptr(), self.nM.data_ptr(), self.ld, self.rows,
-            self.S.data_ptr(), flags, self.work.data_ptr(), self._env_ptr(), self._stream()),
-            "trs_assemble")
+            self.S.data_ptr(), flags, self.work.data_ptr(), self._env_ptr(), self.uf.data_ptr(), self.rows,
+            self._stream()), "trs_assemble")
 
     def potrf(self):
         _capi.check(self.lib.trs_potrf_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
                                                self.S.data_ptr(), self.info.data_ptr(), self._env_ptr(),
+                                               self.work.data_ptr(), self.uf.data_ptr(), self.rows,
                                                self._stream()), "trs_potrf_batched")
 
     def potrs(self):

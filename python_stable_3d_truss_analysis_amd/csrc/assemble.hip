@@ -572,7 +572,8 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
                                    const double* E, const double* A, const double* loads,
                                    const int* free_index, const int* n_free, const int* nJ,
                                    const int* nM, int ld, size_t slab_stride, int n_pad_max,
-                                   double* S, int flags, void* work, int* env, hipStream_t stream) {
+                                   double* S, int flags, void* work, int* env, double* uf, int ld_uf,
+                                   hipStream_t stream) {
     if (B <= 0 || n_pad_max <= 0) return 0;
     // adjacency keys (unsigned): other joint (16 bits) | member (16 bits)
     if (nJ_max >= 65536 || nM_max >= 65536) return (int)hipErrorInvalidValue;

@@ -8,9 +8,10 @@ extern "C" {
 int trs_dofmap_launch(int, int, const uint8_t*, const int*, int*, int*, hipStream_t);
 int trs_assemble_launch(int, int, int, const double*, const int*, const double*, const double*,
                         const double*, const int*, const int*, const int*, const int*, int, size_t,
-                        int, double*, int, void*, int*, hipStream_t);
+                        int, double*, int, void*, int*, double*, int, hipStream_t);
 size_t trs_assemble_work_bytes(int, int, int);
-int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int*, hipStream_t);
+int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int*, const void*, double*, int,
+                     hipStream_t);
 int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, const int*, hipStream_t);
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, const int*, const double*, int, double*,
@@ -78,18 +79,20 @@ int trs_dofmap(int B, int nJ_max, const uint8_t* cbits, const int32_t* nJ, int32
 int trs_assemble(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn,
                  const double* E, const double* A, const double* loads, const int32_t* free_index,
                  const int32_t* n_free, const int32_t* nJ, const int32_t* nM, int ld, int slab_rows,
-                 double* S, int flags, void* work, int32_t* env, void* stream) {
+                 double* S, int flags, void* work, int32_t* env, double* uf, int ld_uf, void* stream) {
     if (B < 0 || nJ_max <= 0 || nM_max < 0 || bad_slab(ld, slab_rows) || (B > 0 && !work))
         return (int)hipErrorInvalidValue;
+    if (uf != nullptr && ld_uf < slab_rows) return (int)hipErrorInvalidValue;
     return trs_assemble_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM,
-                               ld, (size_t)slab_rows * ld, slab_rows, S, flags, work, env,
+                               ld, (size_t)slab_rows * ld, slab_rows, S, flags, work, env, uf, ld_uf,
                                (hipStream_t)stream);
 }
 
 int trs_potrf_batched(int B, const int32_t* n_free, int ld, int slab_rows, double* S, int32_t* info,
-                      const int32_t* env, void* stream) {
-    if (B < 0 || bad_slab(ld, slab_rows)) return (int)hipErrorInvalidValue;
-    return trs_potrf_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, info, env,
+                      const int32_t* env, const void* work, double* uf, int ld_uf, void* stream) {
+    if (B < 0 || bad_slab(ld, slab_rows) || (B > 0 && (uf == nullptr || ld_uf < slab_rows)))
+        return (int)hipErrorInvalidValue;
+    return trs_potrf_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, info, env, work, uf, ld_uf,
                             (hipStream_t)stream);
 }
 
@@ -131,9 +134,9 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
     int rc = trs_dofmap(B, nJ_max, cbits, nJ, free_index, n_free, stream);
     if (rc) return rc;
     rc = trs_assemble(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM, ld,
-                      slab_rows, S, 0, work, env, stream);
+                      slab_rows, S, 0, work, env, uf, ld_uf, stream);
     if (rc) return rc;
-    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, env, stream);
+    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, env, work, uf, ld_uf, stream);
     if (rc) return rc;
     rc = trs_potrs_batched(B, n_free, ld, slab_rows, S, uf, ld_uf, env, stream);
     if (rc) return rc;

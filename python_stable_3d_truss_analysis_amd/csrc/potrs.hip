@@ -1,5 +1,5 @@
-// Back substitution U u = y for a batch of factored slabs (U = L^T in the upper part of S, y in
-// the column n_pad; see include/trs_solver.h).  Replaces the solve half of np.linalg.solve
+// Back substitution U u = y for a batch of factored slabs (U = L^T in the upper part of S; y in uf,
+// which the solution overwrites; see include/trs_solver.h).  Replaces the solve half of np.linalg.solve
 // (slientruss3d/truss.py:343).  HBM-bound: U is streamed once, row by row (contiguous rows).
 //
 // One work-group per truss.  Blocks of 64 rows from the bottom up: all four waves form
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
     double* Ub = sh + npad;           // [64][65] diagonal block
     double* tb = Ub + BS * (BS + 1);  // [64] right-hand side of the block
     const double* S = S_all + (size_t)b * slab_stride;
+    const double* yb = uf + (size_t)b * ld_uf;  // y = L^-1 f, left there by trs_potrf_batched
     // lane (g, l): rows 4 g .. 4 g + 3 of the wave's 16 rows, columns l + 16 k of a 64-column chunk.
     // Every load instruction covers four rows x 128 contiguous bytes; 16 independent loads per chunk.
     const int g = lane >> 4, l = lane & 15;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
 #pragma unroll
             for (int k = 0; k < 4; ++k)  // tiles left of the wave's diagonal tile: never written, never used
                 if (k >= wave) dv[4 * q + k] = rows[(size_t)q * ld + cb + 16 * k + l];
-            yv[q] = rows[(size_t)q * ld + npad];
+            yv[q] = yb[cb + wrow + q];
         }
 #pragma unroll
         for (int p = 0; p < PF; ++p)

@@ -32,7 +32,7 @@ def test_host_side_helpers_of_the_abi():
     assert lib.trs_slab_rows(696) == 704 and lib.trs_slab_ld(696) == 720
     assert lib.trs_slab_rows(64) == 64 and lib.trs_slab_rows(65) == 128 and lib.trs_slab_rows(0) == 64
     # argument validation happens before any launch: bad leading dimension is refused
-    assert lib.trs_potrf_batched(1, None, 100, 64, None, None, None, None) != 0
+    assert lib.trs_potrf_batched(1, None, 100, 64, None, None, None, None, None, 64, None) != 0
     assert lib.trs_env_ints(696) == 2 * (704 // 16) + 704 // 64 + 8
 
 

@@ -85,7 +85,9 @@ def test_stages_against_oracle(gpu, name):
     # stored extent per 16-row chunk (csrc/trs_common.h): exact at tile granularity for the
     # wave-per-matrix kernel (slack 1), rectangular per panel for the work-group kernel (slack 3)
     nchm = dev.rows // 16
-    slack = int(env[nchm + dev.rows // 64])
+    meta = env[nchm + dev.rows // 64: nchm + dev.rows // 64 + 8]
+    slack, compact = int(meta[0]) & 0xff, bool(int(meta[0]) & 0x100)
+    assert compact == (slack == 1)       # narrow envelopes leave the assembly as compact entry lists
     env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nch]
     lastc = [max(q for q in range(nch) if env_ft[q] <= t) for t in range(nch)]
     if slack == 1:
@@ -93,22 +95,65 @@ def test_stages_against_oracle(gpu, name):
     else:
         assert env_cend.tolist() == [min(nch, int(env_last[t // 4]) + 1 + 3) for t in range(nch)]
 
-    # --- assemble (production layout: upper part by 16-tiles) -----------------------------------
+    # --- assemble (production layout) ------------------------------------------------------------
     dev.S.fill_(float("nan"))
+    dev.uf.fill_(float("nan"))
     dev.assemble(flags=0)
     S = dev.S.cpu().numpy()[0]
-    for c in (0, n // 2, n - 1):
-        lo = c // 16 * 16
-        hi = 16 * int(env_cend[c // 16])                        # end of the written part of the row
-        assert H.max_scaled_err(S[c, lo:min(hi, n)], ref["K_ff"][c, lo:min(hi, n)]) <= 1e-14
-        assert not ref["K_ff"][c, min(hi, n):].any()            # beyond it K is structurally zero
-        assert np.isnan(S[c, hi:npad]).all() or hi >= npad      # ... and nothing was written there
+    if compact:
+        # compact form: nothing in the slab; K_ff as per-tile entry lists in `work`, f in uf
+        assert np.isnan(S).all()
+        work = dev.work.cpu().numpy().reshape(-1)
+        off = [int(v) * 16 for v in meta[1:5]]
+        tbase = work[off[1]: off[1] + 4 * (nch + 1)].view(np.int32)
+        ntile = int(tbase[nch])
+        assert tbase.tolist() == np.concatenate([[0], np.cumsum(env_cend - np.arange(nch))]).tolist()
+        tdesc = work[off[0]: off[0] + 8 * ntile].view(np.int32).reshape(ntile, 2)
+        assert tdesc[0, 0] == 0 and (tdesc[1:, 0] == np.cumsum(tdesc[:-1, 1])).all()   # lists back to back
+        total = int(tdesc[-1, 0] + tdesc[-1, 1])
+        slots = work[off[2]: off[2] + 2 * total].view(np.uint16).astype(np.int64)
+        vals = work[off[3]: off[3] + 8 * total].view(np.float64)
+        K = np.zeros([npad, npad])
+        seen = np.zeros([npad, npad], dtype=np.int32)
+        for t in range(nch):
+            for q in range(t, int(env_cend[t])):
+                beg, cnt = tdesc[tbase[t] + q - t]
+                p = slots[beg: beg + cnt]
+                rows = 16 * t + ((p >> 4) & 3) + 4 * (p >> 6)      # D-form slot: r * 64 + lq * 16 + li
+                cols = 16 * q + (p & 15)
+                K[rows, cols] = vals[beg: beg + cnt]
+                np.add.at(seen, (rows, cols), 1)
+        assert seen.max() == 1                                       # every entry exactly once
+        want = np.zeros([npad, npad])
+        want[:n, :n] = ref["K_ff"]
+        want[np.arange(n, npad), np.arange(n, npad)] = 1.0           # identity padding
+        stored = np.arange(npad)[None, :] >= (np.arange(npad)[:, None] // 16 * 16)
+        assert H.max_scaled_err(K[stored], want[stored]) <= 1e-14
+        assert not K[~stored].any()
+        uf0 = dev.uf.cpu().numpy()[0]
+        np.testing.assert_array_equal(uf0[:n], f_free)
+        assert not uf0[n:npad].any()
+        # bit-identical to the slab form of the same matrix (same sums in the same order)
+        dev.assemble(flags=2)                                        # TRS_ASM_NO_COMPACT
+        S2 = dev.S.cpu().numpy()[0]
+        inside = stored & (np.arange(npad)[None, :] < 16 * env_cend[np.arange(npad) // 16][:, None])
+        assert np.array_equal(S2[:npad, :npad][inside], K[inside])
+        dev.S.fill_(float("nan"))
+        dev.assemble(flags=0)
+    else:
+        for c in (0, n // 2, n - 1):
+            lo = c // 16 * 16
+            hi = 16 * int(env_cend[c // 16])                        # end of the written part of the row
+            assert H.max_scaled_err(S[c, lo:min(hi, n)], ref["K_ff"][c, lo:min(hi, n)]) <= 1e-14
+            assert not ref["K_ff"][c, min(hi, n):].any()            # beyond it K is structurally zero
+            assert np.isnan(S[c, hi:npad]).all() or hi >= npad      # ... and nothing was written there
 
     # --- potrf: U^T U = K_ff, y = L^-1 f ------------------------------------------------------
     dev.potrf()
     assert int(dev.info.cpu()[0]) == 0
     S = dev.S.cpu().numpy()[0]
-    U, y = _upper_from_slab(S, npad)
+    U, _ = _upper_from_slab(S, npad)
+    y = dev.uf.cpu().numpy()[0][:npad]           # y = L^-1 f is left in uf for trs_potrs
     Lref = np.linalg.cholesky(ref["K_ff"])
     # tiles outside the envelope are never written (NaN poison of the test slab): there the factor
     # must be structurally zero
@@ -258,11 +303,12 @@ def test_replicated_batch_is_identical_and_deterministic(gpu):
         assert np.array_equal(first.internal[b], first.internal[0])
     # potrf on identical input is bitwise reproducible (fixed summation order)
     dev.dofmap(); dev.assemble()
-    S0 = dev.S.clone()
+    S0, f0 = dev.S.clone(), dev.uf.clone()      # (compact form: the matrix sits in `work`, f in uf)
     dev.potrf()
-    U1 = dev.S.clone()
-    dev.S.copy_(S0)
+    U1, y1 = dev.S.clone(), dev.uf.clone()
+    dev.S.copy_(S0); dev.uf.copy_(f0)
     dev.potrf()
+    assert bool((y1.view(dev.torch.int64) == dev.uf.view(dev.torch.int64)).all())
     same = U1[:, :704, :720].triu().view(dev.torch.int64) == dev.S[:, :704, :720].triu().view(dev.torch.int64)
     assert bool(same.all())   # bitwise (NaN poison outside the envelope compares equal as bits)
 
