@@ -62,7 +62,9 @@ int trs_abi_version(void);
 
 /* Process-wide switches for tests and diagnostics (no effect on results):
  *   "recover_unstaged" 0/1  force trs_recover's path for trusses whose tables exceed a CU's LDS;
- *   "small_path"       1/0  let trs_solve take the fused small-system kernel (default 1).
+ *   "small_path"       1/0  let trs_solve take the fused small-system kernel (default 1);
+ *   "compact"          1/0  let trs_assemble leave narrow-envelope matrices as compact entry lists
+ *                           (default 1; 0 = TRS_ASM_NO_COMPACT on every call).
  * Returns 0, or hipErrorInvalidValue for an unknown name. */
 int trs_set_option(const char *name, int value);
 

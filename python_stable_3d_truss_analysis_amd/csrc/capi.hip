@@ -39,6 +39,7 @@ extern "C" {
 int trs_abi_version(void) { return TRS_ABI_VERSION; }
 
 static int g_small_path = 1;  // trs_set_option("small_path", 0): trs_solve never takes the fused kernel
+static int g_compact = 1;     // trs_set_option("compact", 0): trs_assemble writes every matrix to the slab
 
 int trs_set_option(const char* name, int value) {
     if (name != nullptr && strcmp(name, "recover_unstaged") == 0) {
@@ -47,6 +48,10 @@ int trs_set_option(const char* name, int value) {
     }
     if (name != nullptr && strcmp(name, "small_path") == 0) {
         g_small_path = value != 0;
+        return 0;
+    }
+    if (name != nullptr && strcmp(name, "compact") == 0) {
+        g_compact = value != 0;
         return 0;
     }
     return (int)hipErrorInvalidValue;
@@ -83,6 +88,7 @@ int trs_assemble(int B, int nJ_max, int nM_max, const double* xyz, const int32_t
     if (B < 0 || nJ_max <= 0 || nM_max < 0 || bad_slab(ld, slab_rows) || (B > 0 && !work))
         return (int)hipErrorInvalidValue;
     if (uf != nullptr && ld_uf < slab_rows) return (int)hipErrorInvalidValue;
+    if (!g_compact) flags |= TRS_ASM_NO_COMPACT;
     return trs_assemble_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM,
                                ld, (size_t)slab_rows * ld, slab_rows, S, flags, work, env, uf, ld_uf,
                                (hipStream_t)stream);

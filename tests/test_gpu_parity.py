@@ -85,9 +85,8 @@ def test_stages_against_oracle(gpu, name):
     # stored extent per 16-row chunk (csrc/trs_common.h): exact at tile granularity for the
     # wave-per-matrix kernel (slack 1), rectangular per panel for the work-group kernel (slack 3)
     nchm = dev.rows // 16
-    meta = env[nchm + dev.rows // 64: nchm + dev.rows // 64 + 8]
-    slack, compact = int(meta[0]) & 0xff, bool(int(meta[0]) & 0x100)
-    assert compact == (slack == 1)       # narrow envelopes leave the assembly as compact entry lists
+    slack = int(env[nchm + dev.rows // 64]) & 0xff
+    assert not int(env[nchm + dev.rows // 64]) & 0x100     # TRS_ASM_FULL_SYMMETRIC implies the slab form
     env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nch]
     lastc = [max(q for q in range(nch) if env_ft[q] <= t) for t in range(nch)]
     if slack == 1:
@@ -100,6 +99,9 @@ def test_stages_against_oracle(gpu, name):
     dev.uf.fill_(float("nan"))
     dev.assemble(flags=0)
     S = dev.S.cpu().numpy()[0]
+    meta = dev.env.cpu().numpy()[0][nchm + dev.rows // 64: nchm + dev.rows // 64 + 8]
+    compact = bool(int(meta[0]) & 0x100)
+    assert compact == (slack == 1) and int(meta[0]) & 0xff == slack   # narrow envelopes leave as entry lists
     if compact:
         # compact form: nothing in the slab; K_ff as per-tile entry lists in `work`, f in uf
         assert np.isnan(S).all()
