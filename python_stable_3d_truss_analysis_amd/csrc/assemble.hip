@@ -273,6 +273,8 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                     meta[4] = (int)((base + ck.eval) >> 4);
                 }
                 wgflag[0] = compact ? 1 : 0;
+                // wave-per-matrix kernels read the load vector from uf: no load column in the slab
+                wgflag[1] = (narrow && uf_all != nullptr) ? 1 : 0;
             }
             for (int t = tid; t < nch; t += 64) {  // t | 3 lies in the same step: reads precede the writes
                 const int e = narrow ? max(cendl[t] + 1, (t | 3) + 1) : cendl[t | 3] + 1 + (TRS_WIDE_ITEM - 1);
@@ -419,6 +421,11 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     }
 
     // ---- phase 1 ---------------------------------------------------------------------------------------
+    const bool with_col = !(has_env && wgflag[1] != 0);  // the 16-wide load-column chunk rides in the slab
+    if (!with_col) {
+        double* ufb = uf_all + (size_t)b * ld_uf;
+        for (int c = tid; c < npad; c += NT) ufb[c] = c < n ? rhs[c] : 0.0;
+    }
     double* S = S_all + (size_t)b * slab_stride;
     const int rr = tid / TPR, e_first = tid % TPR;
     const int Wstride = WT + 16;
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             const int seg_hi = min(i_hi, seg_lo + WT);
             const int Ws = seg_hi - seg_lo;  // multiple of 16
             const bool is_last = seg_hi == i_hi;
-            const int W = Ws + (is_last ? 16 : 0);
+            const int W = Ws + (is_last && with_col ? 16 : 0);
             {   // scatter: every (row, column) of the tile is written by exactly one thread
                 double* row = T + (size_t)rr * Wstride - seg_lo;
                 if (pq0 >= seg_lo && pq0 < seg_hi) row[pq0] = pv0;
@@ -498,7 +505,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 }
                 if (e_first == TPR - 1) {
                     const int cc = c0 + rr;
-                    if (is_last) row[seg_lo + Ws] = cc < n ? rhs[cc] : 0.0;      // load column
+                    if (is_last && with_col) row[seg_lo + Ws] = cc < n ? rhs[cc] : 0.0;  // load column
                     if (cc >= n && cc >= seg_lo && cc < seg_hi) row[cc] = 1.0;   // identity padding
                 }
             }

@@ -683,9 +683,9 @@ constexpr int MPW = TRS_NARROW_MATRICES_PER_WG;  // waves (= matrices) per work-
 #ifndef TRS_FUSED_WAVES_PER_SIMD
 #define TRS_FUSED_WAVES_PER_SIMD 2
 #endif
-// FUSED = false: the stiffness matrix and the load column are read from the slab (trs_assemble wrote them);
-// FUSED = true : the stiffness tiles are formed from the compact entry lists and the load vector is read
-//                from uf - K_ff never existed in HBM in dense form.  Both leave L in the slab and y in uf.
+// FUSED = false: the stiffness tiles are read from the slab (trs_assemble wrote them);
+// FUSED = true : the stiffness tiles are formed from the compact entry lists - K_ff never existed in HBM in
+//                dense form.  Both read the load vector from uf, leave y there and L in the slab.
 template <bool FUSED>
 __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narrow_kernel(
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
@@ -764,16 +764,16 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
 #pragma unroll
                 for (int s = 0; s <= u; ++s) tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
 #pragma unroll
-            for (int s = 0; s < CT; ++s) tile_load(y[s], S, r0 + 16 * s, npad);
+            for (int s = 0; s < CT; ++s) ytile_load(y[s], Y, r0 + 16 * s);
         }
         st.drain();
         st.mark(0);
         if (r0 > kd) {
             const int step = S.ld * 32;
             int ok = S.at(kd, r0);
-            int oy = FUSED ? kd * 8 : S.at(kd, npad);   // FUSED: rows kd .. of uf (32 bytes per k-step)
-            const int ystep = FUSED ? 32 : step;
-            auto yload = [&](int off) { return FUSED ? Y.load(off) : S.load(off); };
+            int oy = kd * 8;   // rows kd .. of uf (32 bytes per k-step)
+            const int ystep = 32;
+            auto yload = [&](int off) { return Y.load(off); };
             double fb[DEPTHN][CT], fy[DEPTHN];
             auto bload = [&](int off, int c, int k) {  // zero where chunk c is left of its envelope
                 return S.load_at(S.lane_off(k >= bks[c]), off + 128 * c);
@@ -865,8 +865,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
             for (int s2 = s + 1; s2 < CT; ++s2)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[s2] = mfma_f64_negA(t[s2][s][r], y[s][r], y[s2]);
-            if constexpr (!FUSED) tile_store(y[s], S, r0 + 16 * s, npad);  // later panels read it from the slab
-            ytile_store(y[s], Y, r0 + 16 * s);                             // trs_potrs reads y from uf
+            ytile_store(y[s], Y, r0 + 16 * s);  // later panels and trs_potrs read y from uf
         }
         st.mark(3);
         // items: the chunks below the block that reach into this panel
