@@ -331,7 +331,10 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         // An entry (row c, column q) is stored when q >= 16 floor(c / 16): the upper part by 16-row tiles,
         // diagonal tiles whole - exactly the slab entries of phase 1.
         auto tile_of = [&](int c, int q) { return tbase[c >> 4] + ((q >> 4) - (c >> 4)); };
-        auto slot_of = [&](int c, int q) { return ((c & 15) >> 2) * 64 + (c & 3) * 16 + (q & 15); };
+        // position inside the chunk's run of tiles: (tile - first tile of the chunk) << 8 | D-form slot
+        auto slot_of = [&](int c, int q) {
+            return ((((q >> 4) - (c >> 4)) << 8) | (((c & 15) >> 2) * 64 + (c & 3) * 16 + (q & 15)));
+        };
         for (int pass = 0; pass < 2; ++pass) {
             for (int w = tid; w < 2 * nJ; w += NT) {
                 const int a = w >> 1, h = w & 1;

@@ -490,54 +490,71 @@ __global__ __launch_bounds__(NW * 64, TRS_POTRF_WAVES_PER_SIMD) void trs_potrf_k
 }
 
 // ---- stiffness tiles formed from the compact per-tile entry lists (trs_common.h, TrsCompactLayout) ------
-// The wave scatters a tile's entries into a zeroed 2 KB LDS image in D-form order (ds_write_b64 at the
-// slot the assembly recorded), reads the image back as the four accumulator registers and re-zeroes it.
-// LDS operations of one wave complete in order, so no barrier is needed between the steps.
+// The tiles of one slab chunk are numbered consecutively and their entries lie back to back, so the
+// tiles a panel needs from a chunk (the diagonal block's column of tiles; an item's one or two tiles)
+// are ONE contiguous entry range.  The wave requests a range's entries in rounds of 64 (all rounds in
+// flight together), scatters them into a zeroed LDS image of up to four tiles in D-form order
+// (ds_write_b64 at the slot the assembly recorded: (tile - first tile) * 256 + r * 64 + lq * 16 + li),
+// reads the tiles back as accumulator registers and re-zeroes the image behind the reads.  LDS
+// operations of one wave complete in order, so no barrier is needed between the steps.
 struct KLists {
     const int* tdesc;              // (first entry, count) per tile
     const int* tbase;              // first tile id per slab chunk
     __amdgpu_buffer_rsrc_t vals;   // double[]
-    __amdgpu_buffer_rsrc_t slots;  // unsigned short[]
-    lds_f64* img;                  // this wave's tile image, 256 doubles, all zero between tiles
+    __amdgpu_buffer_rsrc_t slots;  // unsigned short[]: (tile - chunk) << 8 | D-form slot
+    lds_f64* img;                  // this wave's image, 4 tiles = 1024 doubles, all zero between ranges
 };
-struct TileFetch {  // round 0 of a tile's entries, in flight
-    double v;
-    unsigned p;
+template <int RPF>
+struct RangeFetch {  // the first RPF rounds of a range's entries, in flight
+    double v[RPF];
+    unsigned p[RPF];
     int beg, cnt;
 };
-__device__ __forceinline__ TileFetch ktile_issue(const KLists& K, const int id, const bool exists = true) {
-    TileFetch f;
+template <int RPF>
+__device__ __forceinline__ RangeFetch<RPF> krange_issue(const KLists& K, const int first, const int last,
+                                                        const bool exists = true) {
+    RangeFetch<RPF> f;
     f.beg = 0;
     f.cnt = 0;
-    f.v = 0.0;
-    f.p = 0;
-    if (!exists) return f;  // wave-uniform: a tile outside the envelope costs nothing
-    f.beg = K.tdesc[2 * id];
-    f.cnt = K.tdesc[2 * id + 1];
+    if (exists) {  // wave-uniform
+        f.beg = K.tdesc[2 * first];
+        f.cnt = K.tdesc[2 * last] + K.tdesc[2 * last + 1] - f.beg;
+    }
     const int lane = threadIdx.x & 63;
-    const unsigned e = (unsigned)(f.beg + lane);
-    const unsigned gone = lane < f.cnt ? 0u : 0x80000000u;
-    f.v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(K.vals, (e * 8u) | gone, 0, 0));
-    f.p = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(K.slots, (e * 2u) | gone, 0, 0);
+#pragma unroll
+    for (int j = 0; j < RPF; ++j) {
+        const unsigned e = (unsigned)(f.beg + 64 * j + lane);
+        const unsigned gone = 64 * j + lane < f.cnt ? 0u : 0x80000000u;  // past the range: no memory traffic
+        f.v[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(K.vals, (e * 8u) | gone, 0, 0));
+        f.p[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(K.slots, (e * 2u) | gone, 0, 0);
+    }
     return f;
 }
-__device__ __forceinline__ void ktile_finish(d4& acc, const KLists& K, const TileFetch& f) {
+// `sub` = (first tile - chunk) << 8: the image starts at the range's first tile
+template <int RPF>
+__device__ __forceinline__ void krange_scatter(const KLists& K, const RangeFetch<RPF>& f, const int sub) {
     const int lane = threadIdx.x & 63;
-    if (lane < f.cnt) K.img[f.p] = f.v;
-    for (int e0 = 64; e0 < f.cnt; e0 += 64) {  // dense tiles: further rounds of 64 entries
+#pragma unroll
+    for (int j = 0; j < RPF; ++j)
+        if (64 * j + lane < f.cnt) K.img[(int)f.p[j] - sub] = f.v[j];
+    for (int e0 = 64 * RPF; e0 < f.cnt; e0 += 64) {  // denser than expected: further rounds, one at a time
         const unsigned e = (unsigned)(f.beg + e0 + lane);
         if (e0 + lane < f.cnt) {
             const double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(K.vals, e * 8u, 0, 0));
-            const unsigned p = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(K.slots, e * 2u, 0, 0);
-            K.img[p] = v;
+            const int pp = (int)__builtin_amdgcn_raw_buffer_load_b16(K.slots, e * 2u, 0, 0);
+            K.img[pp - sub] = v;
         }
     }
     __builtin_amdgcn_wave_barrier();
+}
+// tile k of the image -> accumulator registers; the image is zero again afterwards
+__device__ __forceinline__ void ktile_take(d4& acc, const KLists& K, const int k) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = K.img[r * 64 + lane];
+    for (int r = 0; r < 4; ++r) acc[r] = K.img[k * 256 + r * 64 + lane];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) K.img[r * 64 + lane] = 0.0;
+    for (int r = 0; r < 4; ++r) K.img[k * 256 + r * 64 + lane] = 0.0;
 }
 
 // ======================================================================================================
@@ -584,20 +601,28 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
         for (int v = 0; v < NV; ++v) smin[v] += c0 + v >= ce ? 1 : 0;
     }
     if constexpr (FUSED) {
-        // the stiffness tiles of the item come from the entry lists; the next tile's entries are
-        // requested while the current tile's image is formed
-        auto fetch = [&](int i) {  // i = v * CT + s
-            const int v = i / CT, s = i % CT;
-            return ktile_issue(K, tb[s] + (c0 + v) - (r0 / 16 + s), s >= smin[v]);
-        };
-        TileFetch cur = fetch(0);
+        // The stiffness tiles of the item come from the entry lists: per slab chunk s the item's tiles
+        // (chunk c0 and, if stored, c0 + 1: cend is non-decreasing) are one entry range.  All four ranges
+        // are requested first, then each is scattered into the image and taken tile by tile.
+        static_assert(NV <= 2, "an item's tiles of one slab chunk must fit the image");
+        RangeFetch<1> rf[CT];
+        int nvs[CT];
 #pragma unroll
-        for (int i = 0; i < NV * CT; ++i) {
-            TileFetch nxt = cur;
-            if (i + 1 < NV * CT) nxt = fetch(i + 1);
-            if (i % CT >= smin[i / CT]) ktile_finish(acc[i / CT][i % CT], K, cur);
-            else acc[i / CT][i % CT] = d4{0.0, 0.0, 0.0, 0.0};
-            cur = nxt;
+        for (int s = 0; s < CT; ++s) {
+            nvs[s] = 0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) nvs[s] += s >= smin[v] ? 1 : 0;
+            const int first = tb[s] + c0 - (r0 / 16 + s);
+            rf[s] = krange_issue<1>(K, first, first + nvs[s] - 1, nvs[s] > 0);
+        }
+#pragma unroll
+        for (int s = 0; s < CT; ++s) {
+            if (nvs[s] > 0) krange_scatter<1>(K, rf[s], (c0 - (r0 / 16 + s)) << 8);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (s >= smin[v]) ktile_take(acc[v][s], K, v);
+                else acc[v][s] = d4{0.0, 0.0, 0.0, 0.0};
+            }
         }
     } else {
 #pragma unroll
@@ -695,7 +720,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
     __shared__ double wlds[MPW][CT][256];  // per wave: inv(L_ss), s = 0..3, as A-fragments (PanelLds::W layout)
     __shared__ double ylds[MPW][CT][4][4];  // per wave: the load column (lanes li == 0 of its tiles), parked
                                           // during the factorisation
-    __shared__ double kimg[FUSED ? MPW : 1][256];  // per wave: image of the stiffness tile being formed
+    __shared__ double kimg[FUSED ? MPW : 1][FUSED ? 1024 : 1];  // per wave: image of up to four stiffness tiles
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * MPW + wave;
@@ -726,7 +751,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
                                                    0, 0x7fffffff, 0x00020000);
         K.img = (lds_f64*)&kimg[wave][0];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) K.img[r * 64 + lane] = 0.0;
+        for (int r = 0; r < 16; ++r) K.img[r * 64 + lane] = 0.0;
     }
     ChScratch& sc = scratch[wave];
     double* Wl = &wlds[wave][0][0];
@@ -748,16 +773,24 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
             for (int s = 0; s < CT; ++s) tb[s] = K.tbase[4 * panel + s];
 #pragma unroll
             for (int s = 0; s < CT; ++s) ytile_load(y[s], Y, r0 + 16 * s);
-            // tile (slab chunk 4 panel + s, matrix rows chunk 4 panel + u) has id tb[s] + u - s
-            constexpr int TU[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, TS[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
-            TileFetch cur = ktile_issue(K, tb[0]);
+            // Column s of the diagonal block = tiles (slab chunk 4 panel + s, matrix rows chunk 4 panel + u),
+            // u = s .. 3: ids tb[s] .. tb[s] + 3 - s, one entry range.  All four ranges are in flight before
+            // the first image is formed.
+            const RangeFetch<4> f0 = krange_issue<4>(K, tb[0], tb[0] + 3);
+            const RangeFetch<3> f1 = krange_issue<3>(K, tb[1], tb[1] + 2);
+            const RangeFetch<3> f2 = krange_issue<3>(K, tb[2], tb[2] + 1);
+            const RangeFetch<2> f3 = krange_issue<2>(K, tb[3], tb[3]);
+            krange_scatter<4>(K, f0, 0);
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {  // the next tile's entries are in flight while this image is formed
-                TileFetch nxt = cur;
-                if (q + 1 < 10) nxt = ktile_issue(K, tb[TS[q + 1]] + TU[q + 1] - TS[q + 1]);
-                ktile_finish(t[TU[q]][TS[q]], K, cur);
-                cur = nxt;
-            }
+            for (int u = 0; u < CT; ++u) ktile_take(t[u][0], K, u);
+            krange_scatter<3>(K, f1, 0);
+#pragma unroll
+            for (int u = 1; u < CT; ++u) ktile_take(t[u][1], K, u - 1);
+            krange_scatter<3>(K, f2, 0);
+#pragma unroll
+            for (int u = 2; u < CT; ++u) ktile_take(t[u][2], K, u - 2);
+            krange_scatter<2>(K, f3, 0);
+            ktile_take(t[3][3], K, 0);
         } else {
 #pragma unroll
             for (int u = 0; u < CT; ++u)

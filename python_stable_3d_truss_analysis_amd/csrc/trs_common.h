@@ -82,9 +82,11 @@ __host__ __device__ static inline bool trs_env_is_compact(const TrsEnv& e) { ret
 //   tile (t, q), t <= q < cend[t]  = slab rows 16 t .. 16 t + 15 (columns of L), matrix rows 16 q .. 16 q + 15
 //   tile id                        = tbase[t] + (q - t)
 //   tdesc[id]                      = (first entry, number of entries)
-//   entry e                        = value eval[e] at D-form slot epos[e] = r * 64 + lq * 16 + li of the
-//                                    tile: slab row 16 t + lq + 4 r, column 16 q + li  (the register
-//                                    layout tile_load() produces; potrf.hip)
+//   entry e                        = value eval[e] at epos[e] = (q - t) << 8 | slot, slot = r * 64 + lq * 16 + li
+//                                    the D-form position inside the tile: slab row 16 t + lq + 4 r, column
+//                                    16 q + li (the register layout tile_load() produces; potrf.hip).  The
+//                                    tiles of a chunk are consecutive, so several of them scatter into one
+//                                    LDS image with one subtraction.
 // At most TRS_NARROW_MAX_BELOW + 4 tiles per chunk (the narrow condition); entries: every member gives
 // one 3 x 3 block in the upper part (9) and possibly its mirror inside a diagonal tile (9), every joint
 // one diagonal block (9), plus the identity padding.

@@ -126,7 +126,9 @@ def test_stages_against_oracle(gpu, name):
             for q in range(t, int(env_cend[t])):
                 beg, cnt = tdesc[tbase[t] + q - t]
                 p = slots[beg: beg + cnt]
-                rows = 16 * t + ((p >> 4) & 3) + 4 * (p >> 6)      # D-form slot: r * 64 + lq * 16 + li
+                assert ((p >> 8) == q - t).all()                   # (tile - chunk) << 8 | D-form slot
+                p = p & 255
+                rows = 16 * t + ((p >> 4) & 3) + 4 * (p >> 6)      # slot: r * 64 + lq * 16 + li
                 cols = 16 * q + (p & 15)
                 K[rows, cols] = vals[beg: beg + cnt]
                 np.add.at(seen, (rows, cols), 1)
