@@ -756,6 +756,19 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
     ChScratch& sc = scratch[wave];
     double* Wl = &wlds[wave][0][0];
     int bad_col = 0;
+    // FUSED: the entry ranges of the diagonal block's four tile columns, requested one panel ahead
+    RangeFetch<4> f0{};
+    RangeFetch<3> f1{}, f2{};
+    RangeFetch<2> f3{};
+    int tbn[CT] = {0, 0, 0, 0};
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int s = 0; s < CT; ++s) tbn[s] = K.tbase[s];
+        f0 = krange_issue<4>(K, tbn[0], tbn[0] + 3);
+        f1 = krange_issue<3>(K, tbn[1], tbn[1] + 2);
+        f2 = krange_issue<3>(K, tbn[2], tbn[2] + 1);
+        f3 = krange_issue<2>(K, tbn[3], tbn[3]);
+    }
     Stamps st;  // 0 tile loads, 1 block update, 2 factorisation, 3 load column + block stores, 4 items, 5 fence
     st.start();
 
@@ -770,16 +783,11 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
         int tb[CT] = {0, 0, 0, 0};  // first tile id of the panel's four slab chunks (FUSED)
         if constexpr (FUSED) {
 #pragma unroll
-            for (int s = 0; s < CT; ++s) tb[s] = K.tbase[4 * panel + s];
+            for (int s = 0; s < CT; ++s) tb[s] = tbn[s];
 #pragma unroll
             for (int s = 0; s < CT; ++s) ytile_load(y[s], Y, r0 + 16 * s);
             // Column s of the diagonal block = tiles (slab chunk 4 panel + s, matrix rows chunk 4 panel + u),
-            // u = s .. 3: ids tb[s] .. tb[s] + 3 - s, one entry range.  All four ranges are in flight before
-            // the first image is formed.
-            const RangeFetch<4> f0 = krange_issue<4>(K, tb[0], tb[0] + 3);
-            const RangeFetch<3> f1 = krange_issue<3>(K, tb[1], tb[1] + 2);
-            const RangeFetch<3> f2 = krange_issue<3>(K, tb[2], tb[2] + 1);
-            const RangeFetch<2> f3 = krange_issue<2>(K, tb[3], tb[3]);
+            // u = s .. 3: ids tb[s] .. tb[s] + 3 - s, one entry range (requested a panel ahead).
             krange_scatter<4>(K, f0, 0);
 #pragma unroll
             for (int u = 0; u < CT; ++u) ktile_take(t[u][0], K, u);
@@ -791,6 +799,15 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
             for (int u = 2; u < CT; ++u) ktile_take(t[u][2], K, u - 2);
             krange_scatter<2>(K, f3, 0);
             ktile_take(t[3][3], K, 0);
+            // the next panel's ranges are in flight during this panel's update, factorisation and items
+            if (r0 + TRS_NB < npad) {
+#pragma unroll
+                for (int s = 0; s < CT; ++s) tbn[s] = K.tbase[4 * (panel + 1) + s];
+                f0 = krange_issue<4>(K, tbn[0], tbn[0] + 3);
+                f1 = krange_issue<3>(K, tbn[1], tbn[1] + 2);
+                f2 = krange_issue<3>(K, tbn[2], tbn[2] + 1);
+                f3 = krange_issue<2>(K, tbn[3], tbn[3]);
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < CT; ++u)
