@@ -502,7 +502,7 @@ struct KLists {
     const int* tbase;              // first tile id per slab chunk
     __amdgpu_buffer_rsrc_t vals;   // double[]
     __amdgpu_buffer_rsrc_t slots;  // unsigned short[]: (tile - chunk) << 8 | D-form slot
-    lds_f64* img;                  // this wave's image, 4 tiles = 1024 doubles, all zero between ranges
+    lds_f64* img;                  // the image being formed (all zero before a range is scattered)
 };
 template <int RPF>
 struct RangeFetch {  // the first RPF rounds of a range's entries, in flight
@@ -547,14 +547,31 @@ __device__ __forceinline__ void krange_scatter(const KLists& K, const RangeFetch
     }
     __builtin_amdgcn_wave_barrier();
 }
-// tile k of the image -> accumulator registers; the image is zero again afterwards
+// tile k of the image -> accumulator registers; REZERO: the tile is zero again afterwards
+template <bool REZERO>
 __device__ __forceinline__ void ktile_take(d4& acc, const KLists& K, const int k) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = K.img[k * 256 + r * 64 + lane];
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (REZERO) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) K.img[k * 256 + r * 64 + lane] = 0.0;
+        for (int r = 0; r < 4; ++r) K.img[k * 256 + r * 64 + lane] = 0.0;
+    }
+}
+// zero what krange_scatter<RPF> wrote (ranges that fit their prefetched rounds; otherwise whole tiles)
+template <int RPF>
+__device__ __forceinline__ void krange_unscatter(const KLists& K, const RangeFetch<RPF>& f, const int sub,
+                                                 const int ntile) {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_wave_barrier();
+    if (f.cnt <= 64 * RPF) {
+#pragma unroll
+        for (int j = 0; j < RPF; ++j)
+            if (64 * j + lane < f.cnt) K.img[(int)f.p[j] - sub] = 0.0;
+    } else {
+        for (int x = lane; x < 256 * ntile; x += 64) K.img[x] = 0.0;
+    }
 }
 
 // ======================================================================================================
@@ -620,9 +637,10 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
             if (nvs[s] > 0) krange_scatter<1>(K, rf[s], (c0 - (r0 / 16 + s)) << 8);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                if (s >= smin[v]) ktile_take(acc[v][s], K, v);
+                if (s >= smin[v]) ktile_take<false>(acc[v][s], K, v);
                 else acc[v][s] = d4{0.0, 0.0, 0.0, 0.0};
             }
+            if (nvs[s] > 0) krange_unscatter<1>(K, rf[s], (c0 - (r0 / 16 + s)) << 8, NV);
         }
     } else {
 #pragma unroll
@@ -720,7 +738,8 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
     __shared__ double wlds[MPW][CT][256];  // per wave: inv(L_ss), s = 0..3, as A-fragments (PanelLds::W layout)
     __shared__ double ylds[MPW][CT][4][4];  // per wave: the load column (lanes li == 0 of its tiles), parked
                                           // during the factorisation
-    __shared__ double kimg[FUSED ? MPW : 1][FUSED ? 1024 : 1];  // per wave: image of up to four stiffness tiles
+    __shared__ double kimg[FUSED ? MPW : 1][FUSED ? 512 : 1];  // per wave: image of an item's (up to two) stiffness
+                                                               // tiles; the diagonal block's images use wlds
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * MPW + wave;
@@ -751,24 +770,11 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
                                                    0, 0x7fffffff, 0x00020000);
         K.img = (lds_f64*)&kimg[wave][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) K.img[r * 64 + lane] = 0.0;
+        for (int r = 0; r < 8; ++r) K.img[r * 64 + lane] = 0.0;
     }
     ChScratch& sc = scratch[wave];
     double* Wl = &wlds[wave][0][0];
     int bad_col = 0;
-    // FUSED: the entry ranges of the diagonal block's four tile columns, requested one panel ahead
-    RangeFetch<4> f0{};
-    RangeFetch<3> f1{}, f2{};
-    RangeFetch<2> f3{};
-    int tbn[CT] = {0, 0, 0, 0};
-    if constexpr (FUSED) {
-#pragma unroll
-        for (int s = 0; s < CT; ++s) tbn[s] = K.tbase[s];
-        f0 = krange_issue<4>(K, tbn[0], tbn[0] + 3);
-        f1 = krange_issue<3>(K, tbn[1], tbn[1] + 2);
-        f2 = krange_issue<3>(K, tbn[2], tbn[2] + 1);
-        f3 = krange_issue<2>(K, tbn[3], tbn[3]);
-    }
     Stamps st;  // 0 tile loads, 1 block update, 2 factorisation, 3 load column + block stores, 4 items, 5 fence
     st.start();
 
@@ -783,31 +789,33 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
         int tb[CT] = {0, 0, 0, 0};  // first tile id of the panel's four slab chunks (FUSED)
         if constexpr (FUSED) {
 #pragma unroll
-            for (int s = 0; s < CT; ++s) tb[s] = tbn[s];
+            for (int s = 0; s < CT; ++s) tb[s] = K.tbase[4 * panel + s];
 #pragma unroll
             for (int s = 0; s < CT; ++s) ytile_load(y[s], Y, r0 + 16 * s);
             // Column s of the diagonal block = tiles (slab chunk 4 panel + s, matrix rows chunk 4 panel + u),
-            // u = s .. 3: ids tb[s] .. tb[s] + 3 - s, one entry range (requested a panel ahead).
-            krange_scatter<4>(K, f0, 0);
+            // u = s .. 3: ids tb[s] .. tb[s] + 3 - s, one entry range.  All four ranges are in flight before
+            // the first image is formed.  (Requesting them a whole panel ahead was measured: no gain, 38
+            // registers.)  The images are formed in the inv(L_ss) buffer, which is dead until the block is
+            // factored and is overwritten then: it is zeroed before, not after, its use.
+            const RangeFetch<4> f0 = krange_issue<4>(K, tb[0], tb[0] + 3);
+            const RangeFetch<3> f1 = krange_issue<3>(K, tb[1], tb[1] + 2);
+            const RangeFetch<3> f2 = krange_issue<3>(K, tb[2], tb[2] + 1);
+            const RangeFetch<2> f3 = krange_issue<2>(K, tb[3], tb[3]);
+            KLists Kd = K;
+            Kd.img = (lds_f64*)Wl;
 #pragma unroll
-            for (int u = 0; u < CT; ++u) ktile_take(t[u][0], K, u);
-            krange_scatter<3>(K, f1, 0);
+            for (int r = 0; r < 16; ++r) Kd.img[r * 64 + lane] = 0.0;
+            krange_scatter<4>(Kd, f0, 0);
 #pragma unroll
-            for (int u = 1; u < CT; ++u) ktile_take(t[u][1], K, u - 1);
-            krange_scatter<3>(K, f2, 0);
+            for (int u = 0; u < CT; ++u) ktile_take<true>(t[u][0], Kd, u);
+            krange_scatter<3>(Kd, f1, 0);
 #pragma unroll
-            for (int u = 2; u < CT; ++u) ktile_take(t[u][2], K, u - 2);
-            krange_scatter<2>(K, f3, 0);
-            ktile_take(t[3][3], K, 0);
-            // the next panel's ranges are in flight during this panel's update, factorisation and items
-            if (r0 + TRS_NB < npad) {
+            for (int u = 1; u < CT; ++u) ktile_take<true>(t[u][1], Kd, u - 1);
+            krange_scatter<3>(Kd, f2, 0);
 #pragma unroll
-                for (int s = 0; s < CT; ++s) tbn[s] = K.tbase[4 * (panel + 1) + s];
-                f0 = krange_issue<4>(K, tbn[0], tbn[0] + 3);
-                f1 = krange_issue<3>(K, tbn[1], tbn[1] + 2);
-                f2 = krange_issue<3>(K, tbn[2], tbn[2] + 1);
-                f3 = krange_issue<2>(K, tbn[3], tbn[3]);
-            }
+            for (int u = 2; u < CT; ++u) ktile_take<true>(t[u][2], Kd, u - 2);
+            krange_scatter<2>(Kd, f3, 0);
+            ktile_take<false>(t[3][3], Kd, 0);
         } else {
 #pragma unroll
             for (int u = 0; u < CT; ++u)
