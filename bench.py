@@ -224,9 +224,9 @@ def main():
                     help="treat every stiffness matrix as dense (no envelope tile skipping)")
     ap.add_argument("--no-dense-ref", action="store_true",
                     help="skip the dense-mode reference measurement of the factorisation (profiling runs)")
-    ap.add_argument("--no-compact", action="store_true",
-                    help="A/B: the stiffness matrix goes through the slab (round-1 path) instead of the compact "
-                         "entry lists consumed by the fused factorisation")
+    ap.add_argument("--compact", action="store_true",
+                    help="A/B: the stiffness matrix leaves the assembly as compact entry lists and the fused "
+                         "factorisation forms the tiles from them (K_ff never dense in HBM) instead of the slab")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than visible GPUs (ranks share devices round-robin; for testing "
                          "the multi-rank path on a 1-GPU box - the line then reports the devices really used)")
@@ -288,9 +288,9 @@ def main():
         torch.cuda.synchronize(device)
 
     packed = batch.pack_json([data]).replicate(args.batch)
-    if args.no_compact:
+    if args.compact:
         from python_stable_3d_truss_analysis_amd import _capi
-        _capi.check(_capi.load().trs_set_option(b"compact", 0), "trs_set_option")
+        _capi.check(_capi.load().trs_set_option(b"compact", 1), "trs_set_option")
     dev = batch.DeviceBatch(packed, device, use_envelope=not args.dense)
     n, nJ, nM = int(packed.n_free[0]), int(packed.nJ[0]), int(packed.nM[0])
 

@@ -34,7 +34,7 @@
  *    16 x 16 diagonal tile the entries below the diagonal (c > i, same tile) hold the strictly
  *    lower part of inv(L_tile) (its diagonal is 1 / U[c][c]); trs_potrs_batched uses it.
  *
- * Compact form (narrow envelopes, the default with envelope metadata): trusses whose envelope is
+ * Compact form (narrow envelopes; opt-in, trs_set_option("compact", 1)): trusses whose envelope is
  *    narrow enough for the wave-per-matrix factorisation do NOT get their stiffness matrix written to
  *    the slab at all.  trs_assemble leaves it in the truss's share of `work` as per-tile entry lists
  *    (value + position, ~10 bytes per non-zero instead of 2 KB per 16 x 16 tile; layout
@@ -63,8 +63,9 @@ int trs_abi_version(void);
 /* Process-wide switches for tests and diagnostics (no effect on results):
  *   "recover_unstaged" 0/1  force trs_recover's path for trusses whose tables exceed a CU's LDS;
  *   "small_path"       1/0  let trs_solve take the fused small-system kernel (default 1);
- *   "compact"          1/0  let trs_assemble leave narrow-envelope matrices as compact entry lists
- *                           (default 1; 0 = TRS_ASM_NO_COMPACT on every call).
+ *   "compact"          0/1  1: trs_assemble leaves narrow-envelope matrices as compact entry lists and
+ *                           trs_potrf_batched forms the tiles from them (see "Compact form" above);
+ *                           0 (default): TRS_ASM_NO_COMPACT on every call, the matrix goes through the slab.
  * Returns 0, or hipErrorInvalidValue for an unknown name. */
 int trs_set_option(const char *name, int value);
 

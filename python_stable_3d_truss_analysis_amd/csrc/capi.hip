@@ -39,7 +39,10 @@ extern "C" {
 int trs_abi_version(void) { return TRS_ABI_VERSION; }
 
 static int g_small_path = 1;  // trs_set_option("small_path", 0): trs_solve never takes the fused kernel
-static int g_compact = 1;     // trs_set_option("compact", 0): trs_assemble writes every matrix to the slab
+// trs_set_option("compact", 1): trs_assemble leaves narrow-envelope matrices as compact entry lists and the
+// fused wave-per-matrix factorisation forms the tiles from them.  Off by default: on bar-942 x 4096 the
+// fused factorisation pays for the bytes it saves with LDS and issue slots.
+static int g_compact = 0;
 
 int trs_set_option(const char* name, int value) {
     if (name != nullptr && strcmp(name, "recover_unstaged") == 0) {

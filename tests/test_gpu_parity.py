@@ -38,9 +38,20 @@ def _upper_from_slab(S, npad):
     return U, S[:npad, npad].copy()
 
 
+@pytest.fixture
+def compact_mode(request):
+    """Run a test with trs_set_option("compact", value) and restore the default afterwards."""
+    from python_stable_3d_truss_analysis_amd import _capi
+    lib = _capi.load()
+    assert lib.trs_set_option(b"compact", int(request.param)) == 0
+    yield bool(request.param)
+    lib.trs_set_option(b"compact", 0)
+
+
+@pytest.mark.parametrize("compact_mode", [0, 1], indirect=True, ids=["slab", "compact"])
 @pytest.mark.parametrize("name", ["bar-6_input_0", "bar-25_input_0", "bar-47_input_0", "bar-120_input_0",
                                   "bar-942_input_0"])
-def test_stages_against_oracle(gpu, name):
+def test_stages_against_oracle(gpu, name, compact_mode):
     data = H.load_json(name)
     ref = orc.solve(data)
     dev = _device_batch(gpu, [data])
@@ -106,7 +117,8 @@ def test_stages_against_oracle(gpu, name):
     S = dev.S.cpu().numpy()[0]
     meta = dev.env.cpu().numpy()[0][nchm + dev.rows // 64: nchm + dev.rows // 64 + 8]
     compact = bool(int(meta[0]) & 0x100)
-    assert compact == (slack == 1) and int(meta[0]) & 0xff == slack   # narrow envelopes leave as entry lists
+    # with the option on, narrow envelopes leave the assembly as entry lists
+    assert compact == (compact_mode and slack == 1) and int(meta[0]) & 0xff == slack
     if compact:
         # compact form: nothing in the slab; K_ff as per-tile entry lists in `work`, f in uf
         assert np.isnan(S).all()
@@ -216,6 +228,50 @@ def test_all_data_cases_one_ragged_batch_vs_reference_goldens(gpu):
             assert H.max_scaled_err(got, orc.densify(stored[sparse], count, width)) <= TOL_NORTH_STAR
         if dim == 2:  # embedded z axis stays exactly zero
             assert not res.displace[b, :, 2].any() and not res.internal[b, nM:].any()
+
+
+@pytest.mark.parametrize("compact_mode", [1], indirect=True, ids=["compact"])
+def test_fused_factorisation_end_to_end(gpu, compact_mode):
+    """The opt-in compact form (K_ff as per-tile entry lists, tiles formed inside the factorisation): every
+    bundled case and the ragged cube fixtures against the golden vectors, and bit for bit against the slab
+    form - the tiles it forms are the tiles the slab form stores."""
+    from python_stable_3d_truss_analysis_amd import _capi
+    names = H.data_case_names()
+    datas = [H.load_json(nm) for nm in names] + [d for _, d, _ in H.ragged_cube_cases()]
+    packed = gpu.pack_json(datas)
+    z = H.dense_golden()
+    golds = [{k: z[f"{nm}/{k}"] for k in ("u", "f_ext", "N")} for nm in names] + \
+            [g for _, _, g in H.ragged_cube_cases()]
+    res = {}
+    for reorder in (False, True):
+        _capi.load().trs_set_option(b"compact", 1)
+        fused = gpu.solve_batch(packed, reorder=reorder)
+        _capi.load().trs_set_option(b"compact", 0)
+        slab = gpu.solve_batch(packed, reorder=reorder)
+        assert not fused.info.any()
+        for b, (data, gold) in enumerate(zip(datas, golds)):
+            dim, nJ, nM = orc.truss_dim(data), len(data["joint"]), len(data["member"])
+            assert H.max_scaled_err(fused.displace[b, :nJ, :dim], gold["u"]) <= TOL_FP64, (b, reorder)
+            assert H.max_scaled_err(fused.external[b, :nJ, :dim], gold["f_ext"]) <= TOL_FP64, (b, reorder)
+            assert H.max_scaled_err(fused.internal[b, :nM], gold["N"]) <= TOL_FP64, (b, reorder)
+        np.testing.assert_array_equal(fused.displace, slab.displace)
+        np.testing.assert_array_equal(fused.internal, slab.internal)
+        np.testing.assert_array_equal(fused.external, slab.external)
+    # at BASELINE's batch: bar-942 x 4096, every copy identical to the slab form's
+    data = H.load_json("bar-942_input_0")
+    big = gpu.pack_json([data]).replicate(4096)
+    _capi.load().trs_set_option(b"compact", 1)
+    dev = gpu.DeviceBatch(big)
+    dev.solve()
+    a = dev.result()
+    slack = int(dev.env.cpu().numpy()[0][dev.rows // 16 + dev.rows // 64])
+    assert slack & 0x100 and (slack & 0xff) == 1
+    _capi.load().trs_set_option(b"compact", 0)
+    dev2 = gpu.DeviceBatch(big.take(np.arange(8)))
+    dev2.solve()
+    b8 = dev2.result()
+    assert not a.info.any()
+    assert (a.displace == b8.displace[0]).all() and (a.internal == b8.internal[0]).all()
 
 
 def test_cube7_reference_files(gpu):

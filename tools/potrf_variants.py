@@ -36,15 +36,15 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--case", default="bar-942_input_0")
     ap.add_argument("--dense", action="store_true", help="no envelope tile skipping")
-    ap.add_argument("--slab", action="append", default=[],
-                    help="tags (repeatable) that run with trs_set_option('compact', 0): stiffness matrix through the slab")
+    ap.add_argument("--fused", action="append", default=[],
+                    help="tags (repeatable) that run with trs_set_option('compact', 1): compact entry lists + fused factorisation")
     args = ap.parse_args()
     with open(os.path.join(ROOT, "tests", "golden", "data", args.case + ".json")) as fh:
         data = json.load(fh)
     dev = batch.DeviceBatch(batch.pack_json([data]).replicate(args.batch), use_envelope=not args.dense)
     libs = {t: load_variant(t.split("@")[0]) for t in args.tags}   # 'tag@x' = a second instance of a build
-    for t in args.slab:
-        libs[t].trs_set_option(b"compact", 0)
+    for t in args.fused:
+        libs[t].trs_set_option(b"compact", 1)
     stages = ("dofmap", "assemble", "potrf", "potrs", "recover")
     times = {t: {s: [] for s in stages} for t in args.tags}
     ref_u = None
