@@ -54,23 +54,31 @@ def load_case(name):
         return json.load(fh)
 
 
-def algorithmic_counts(n, nJ, nM, env_cend=None):
+def algorithmic_counts(n, nJ, nM, env_cend=None, narrow=False):
     """Per-truss algorithmic work (DESIGN.md section 'Kernels').  With an envelope only the tiles
-    t .. cend[t]-1 of the rows of chunk t are written / read (csrc/trs_common.h)."""
+    t .. cend[t]-1 of the rows of chunk t are written / read (csrc/trs_common.h).  The load vector of
+    a matrix of the wave-per-matrix factorisation (`narrow`) travels in uf (8 bytes per row); the
+    work-group factorisation carries it as a 16-wide column chunk of the slab."""
     npad = (n + 63) // 64 * 64
-    nch = npad // 16
     inputs = 8 * nM + 16 * nM + 24 * nJ + nJ + 24 * nJ
-    # upper part by 16-row tiles incl. diagonal tiles, + rhs column chunk (16 wide)
+    # upper part by 16-row tiles incl. diagonal tiles (+ the load-column chunk in the slab when not narrow)
     row_end = (lambda c: npad) if env_cend is None else (lambda c: 16 * int(env_cend[c // 16]))
-    upper = sum((row_end(c) + 16 - (c // 16) * 16) for c in range(npad)) * 8
+    col = 0 if narrow else 16
+    upper = sum((row_end(c) + col - (c // 16) * 16) for c in range(npad)) * 8
+    vec = 8 * npad if narrow else 0
     return {
         "potrf_flops": n ** 3 / 3.0 + n ** 2,           # factor + fused forward substitution
-        "assemble_bytes": inputs + upper,               # K written once (upper part) + inputs
+        "assemble_bytes": inputs + upper + vec,         # K written once (upper part), f, + inputs
         "assemble_bytes_full_contract": inputs + 8 * n * n + 8 * n,  # SURVEY section 8d figure
-        "potrf_bytes": 2 * upper,                       # stored part of K read once, U written once
-        "potrs_bytes": upper + 8 * n,                   # stored part of U read once (incl. y), u out
+        "potrf_bytes": 2 * upper + 2 * vec,             # stored part of K read once, U written once; f in, y out
+        "potrs_bytes": upper + 2 * vec + (0 if narrow else 8 * n),  # stored part of U read once, y in, u out
         "recover_bytes": 8 * nM + 16 * nM + 24 * nJ + 8 * n + 24 * nJ + 24 * nJ + 8 * nM,
+        "slab_tile_bytes": upper,
     }
+
+
+def npad_of(n):
+    return (n + 63) // 64 * 64
 
 
 def potrf_tile_flops(n, env_ft=None, env_last=None, env_cend=None, narrow=False):
@@ -373,7 +381,19 @@ def main():
                 if narrow else "trs_potrf_kernel"
             env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nchm]
             tile_flops = potrf_tile_flops(n, env_ft, env_last, env_cend, narrow)
-            counts = algorithmic_counts(n, nJ, nM, env_cend)
+            counts = algorithmic_counts(n, nJ, nM, env_cend, narrow)
+            if compact:  # the factorisation reads the entry lists instead of the stiffness tiles
+                meta = env[nchm + dev.rows // 64: nchm + dev.rows // 64 + 8]
+                work = dev.work.view(-1)
+                tb_off, td_off = int(meta[2]) * 16, int(meta[1]) * 16
+                ntile = int(work[tb_off + 4 * (npad_of(n) // 16): tb_off + 4 * (npad_of(n) // 16) + 4]
+                            .cpu().numpy().view(np.int32)[0])
+                last = work[td_off + 8 * (ntile - 1): td_off + 8 * ntile].cpu().numpy().view(np.int32)
+                entries = int(last[0] + last[1])
+                lists = 10 * entries + 8 * ntile + 4 * (npad_of(n) // 16 + 1)
+                counts["compact_list_bytes"] = lists
+                counts["assemble_bytes"] += lists - counts["slab_tile_bytes"]
+                counts["potrf_bytes"] += lists - counts["slab_tile_bytes"]
         else:
             tile_flops = potrf_tile_flops(n)
             counts = algorithmic_counts(n, nJ, nM)
@@ -404,8 +424,8 @@ def main():
                     "hbm": {"achieved": potrf_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac},
                     "flop_model": "MFMA work inside the 16x16-tile envelope of K_ff (what the kernel "
                                   "executes; equals the dense tile count with --dense)",
-                    "byte_model": "stored slab tiles inside the envelope (+ load column): read once, "
-                                  "written once",
+                    "byte_model": "stiffness tiles inside the envelope (or their compact entry lists) read once, "
+                                  "factor tiles written once, load vector in / out (uf)",
                     "dense_equivalent_tflops": dense_flops * args.batch / potrf_s / 1e12,
                     "dense_flop_per_truss": dense_flops}
         if intensity >= balance:

@@ -17,7 +17,7 @@ from collections import defaultdict
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return name.split("(")[0].split("<")[0]
+    return name.split("(")[0]   # template arguments stay: trs_potrf_narrow_kernel<false> / <true>
 
 
 def main(src, dst):
