@@ -146,6 +146,63 @@ def pack_json(data_list):
     return pack_arrays(xyz, conn, mtype, sup, loads, dims)
 
 
+_JSON_ERRORS = {1: "JSON syntax", 2: "inconsistent coordinate / load dimension", 3: "unknown or invalid support type",
+                4: "joint id out of range", 5: "does not fit the padding", 6: "file cannot be read"}
+
+
+def _pack_json_native(count, call):
+    """Two passes through the native reader (`csrc/jsonpack.c`): sizes, then the padded arrays."""
+    import ctypes
+    nJ = np.zeros([count], dtype=np.int32); nM = np.zeros([count], dtype=np.int32)
+    dim = np.full([count], 3, dtype=np.int32)
+    ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+    def run(nJ_max, nM_max, arrays):
+        rc = call(nJ_max, nM_max, *(ptr(a) for a in arrays), ptr(nJ), ptr(nM), ptr(dim))
+        if rc != 0:
+            index, code = (-rc) // 1000 - 1, (-rc) % 1000
+            raise ValueError(f"truss JSON #{index}: {_JSON_ERRORS.get(code, code)}")
+
+    run(0, 0, [None] * 7)
+    jm, mm = max(1, int(nJ.max(initial=1))), max(1, int(nM.max(initial=1)))
+    xyz = np.empty([count, jm, 3]); loads = np.empty([count, jm, 3])
+    conn = np.empty([count, mm, 2], dtype=np.int32)
+    E = np.empty([count, mm]); A = np.empty([count, mm]); rho = np.empty([count, mm])
+    cbits = np.empty([count, jm], dtype=np.uint8)
+    run(jm, mm, [xyz, conn, E, A, rho, cbits, loads])
+    return PackedBatch(xyz, conn, E, A, rho, cbits, loads, nJ, nM, dim, count_free(cbits, nJ))
+
+
+def pack_json_texts(texts):
+    """Reference-format JSON documents (`bytes` or `str`, one truss each) -> `PackedBatch` through the
+    native bulk reader (`csrc/jsonpack.c`, OpenMP over the documents): no Python objects per joint or
+    member.  Same arrays as `pack_json([json.loads(t) for t in texts])`."""
+    import ctypes
+    from .generate import _load
+    lib = _load()
+    raw = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in texts]
+    B = len(raw)
+    arr = (ctypes.c_char_p * B)(*raw)
+    lens = np.array([len(r) for r in raw], dtype=np.int64)
+    lib.trs_json_pack.restype = ctypes.c_int
+    return _pack_json_native(B, lambda jm, mm, *rest: lib.trs_json_pack(
+        ctypes.c_int(B), arr, lens.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(jm), ctypes.c_int(mm), *rest))
+
+
+def pack_json_files(paths):
+    """Truss JSON FILES -> `PackedBatch`; the files are read and parsed natively, in parallel
+    (the bulk form of `Truss.LoadFromJSON`, reference `truss.py:401-421`)."""
+    import ctypes
+    from .generate import _load
+    lib = _load()
+    raw = [os.fsencode(p) for p in paths]
+    B = len(raw)
+    arr = (ctypes.c_char_p * B)(*raw)
+    lib.trs_json_pack_files.restype = ctypes.c_int
+    return _pack_json_native(B, lambda jm, mm, *rest: lib.trs_json_pack_files(
+        ctypes.c_int(B), arr, ctypes.c_int(jm), ctypes.c_int(mm), *rest))
+
+
 @dataclass
 class BatchResult:
     """Dense host results of a batched solve: displace/external [B,nJ_max,3], internal [B,nM_max],

@@ -1,0 +1,410 @@
+/* Bulk reader of truss JSON files straight into the padded batch arrays.
+ *
+ * Replaces, for many files at once, the reference's per-object loader Truss.LoadFromJSON
+ * (slientruss3d/truss.py:401-421) + the packing of the resulting objects: schema of
+ * detail/combine_with_JSON.md:71-163
+ *
+ *   {"joint":  [[[x, y(, z)], "NO"|"PIN"|"ROLLER_X"|"ROLLER_Y"|"ROLLER_Z"], ...],
+ *    "force":  [[jointID, [fx, fy(, fz)]], ...],
+ *    "member": [[[joint0, joint1], [a, e, density]], ...],
+ *    (output files also carry "displace", "external", "internal", "weight": skipped)}
+ *
+ * Semantics kept from the reference: joints / members are numbered in file order (truss.py:175,185);
+ * a load whose every component is below 1e-10 is dropped (truss.py:181-182); a later load on the same
+ * joint replaces an earlier one (dict assignment); ROLLER_Z is invalid in 2D (type.py:73-74).
+ * Numbers go through strtod: correctly rounded, bit-identical to Python's float().
+ * A 2D truss is embedded with z = 0 and the z axis constrained at every joint (cbits | 4), as
+ * batch.pack_arrays does.  One pass for the sizes, one to fill; OpenMP over the files.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ZERO_EPS 1e-10
+
+typedef struct {
+    const char *p, *end;
+    int err;
+} cur_t;
+
+static void skip_ws(cur_t *c) {
+    while (c->p < c->end && (*c->p == ' ' || *c->p == '\n' || *c->p == '\t' || *c->p == '\r')) ++c->p;
+}
+static int peek(cur_t *c) {
+    skip_ws(c);
+    return c->p < c->end ? (unsigned char)*c->p : -1;
+}
+static int eat(cur_t *c, char ch) {
+    if (peek(c) == (unsigned char)ch) {
+        ++c->p;
+        return 1;
+    }
+    c->err = 1;
+    return 0;
+}
+/* after a value inside an array: ',' -> 1 (another element follows), ']' -> 0 */
+static int more(cur_t *c) {
+    const int ch = peek(c);
+    if (ch == ',') {
+        ++c->p;
+        return 1;
+    }
+    if (ch == ']') {
+        ++c->p;
+        return 0;
+    }
+    c->err = 1;
+    return 0;
+}
+/* sizes-only pass: step over a number without converting it */
+static void skip_number(cur_t *c) {
+    skip_ws(c);
+    const char *q = c->p;
+    while (q < c->end && *q != ',' && *q != ']' && *q != '}' && *q != ' ' && *q != '\n') ++q;
+    if (q == c->p) c->err = 1;
+    c->p = q;
+}
+static const double POW10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+static double number(cur_t *c) {
+    skip_ws(c);
+    {   /* fast path (exact): at most 15 significant digits and a power of ten that is itself exact -
+           integers, "1e7", "0.1", "62.5"; everything else goes to strtod below */
+        const char *q = c->p;
+        int neg = 0, digits = 0, frac = 0, seen_dot = 0, ok = 1;
+        uint64_t mant = 0;
+        if (q < c->end && *q == '-') {
+            neg = 1;
+            ++q;
+        }
+        const char *d0 = q;
+        while (q < c->end && ((*q >= '0' && *q <= '9') || (*q == '.' && !seen_dot))) {
+            if (*q == '.') {
+                seen_dot = 1;
+            } else {
+                if (mant || *q != '0') ++digits;
+                mant = mant * 10 + (uint64_t)(*q - '0');
+                frac += seen_dot;
+            }
+            ++q;
+            if (digits > 15) {
+                ok = 0;
+                break;
+            }
+        }
+        if (ok && q > d0 && !(q == d0 + 1 && *d0 == '.')) {
+            int ex = 0;
+            if (q < c->end && (*q == 'e' || *q == 'E')) {
+                const char *e = q + 1;
+                int eneg = 0, ed = 0;
+                if (e < c->end && (*e == '-' || *e == '+')) eneg = *e++ == '-';
+                while (e < c->end && *e >= '0' && *e <= '9' && ed < 4) {
+                    ex = ex * 10 + (*e++ - '0');
+                    ++ed;
+                }
+                if (ed == 0 || (e < c->end && *e >= '0' && *e <= '9')) ok = 0;
+                ex = eneg ? -ex : ex;
+                q = e;
+            }
+            const int p10 = ex - frac;
+            const int ch = q < c->end ? *q : ',';
+            if (ok && p10 >= -22 && p10 <= 22 && (ch == ',' || ch == ']' || ch == '}' || ch == ' ' || ch == '\n')) {
+                double v = (double)mant;  /* < 10^15 < 2^53: exact; one correctly rounded mul / div follows */
+                v = p10 < 0 ? v / POW10[-p10] : v * POW10[p10];
+                c->p = q;
+                return neg ? -v : v;
+            }
+        }
+    }
+    char buf[64];
+    size_t n = 0;
+    while (c->p + n < c->end && n < sizeof buf - 1) {
+        const char ch = c->p[n];
+        if ((ch >= '0' && ch <= '9') || ch == '-' || ch == '+' || ch == '.' || ch == 'e' || ch == 'E' ||
+            ch == 'N' || ch == 'a' || ch == 'I' || ch == 'n' || ch == 'f' || ch == 'i' || ch == 't' || ch == 'y')
+            buf[n++] = ch;  /* digits, exponent, and Python's NaN / Infinity spellings */
+        else
+            break;
+    }
+    buf[n] = 0;
+    char *stop = NULL;
+    const double v = strtod(buf, &stop);
+    if (n == 0 || stop == buf) c->err = 1;
+    c->p += stop ? (size_t)(stop - buf) : 0;
+    return v;
+}
+/* "..." without escapes of interest; returns length, copies at most cap-1 bytes */
+static int string(cur_t *c, char *out, int cap) {
+    if (!eat(c, '"')) return -1;
+    int n = 0;
+    while (c->p < c->end && *c->p != '"') {
+        if (*c->p == '\\' && c->p + 1 < c->end) ++c->p;
+        if (n < cap - 1) out[n] = *c->p;
+        ++n;
+        ++c->p;
+    }
+    if (c->p >= c->end) {
+        c->err = 1;
+        return -1;
+    }
+    ++c->p;
+    out[n < cap ? n : cap - 1] = 0;
+    return n;
+}
+static void skip_value(cur_t *c) {
+    const int ch = peek(c);
+    if (ch == '"') {
+        char tmp[2];
+        string(c, tmp, 2);
+    } else if (ch == '[' || ch == '{') {
+        const char open = (char)ch, close = ch == '[' ? ']' : '}';
+        int depth = 0;
+        while (c->p < c->end) {
+            const char x = *c->p;
+            if (x == '"') {
+                char tmp[2];
+                string(c, tmp, 2);
+                continue;
+            }
+            if (x == open) ++depth;
+            if (x == close && --depth == 0) {
+                ++c->p;
+                return;
+            }
+            ++c->p;
+        }
+        c->err = 1;
+    } else {  /* number / true / false / null */
+        while (c->p < c->end && *c->p != ',' && *c->p != '}' && *c->p != ']') ++c->p;
+    }
+}
+
+static int support_bits(const char *name, int dim) {
+    if (!strcmp(name, "NO")) return 0;
+    if (!strcmp(name, "PIN")) return dim == 3 ? 7 : 3;
+    if (!strcmp(name, "ROLLER_X")) return 1;
+    if (!strcmp(name, "ROLLER_Y")) return 2;
+    if (!strcmp(name, "ROLLER_Z")) return dim == 3 ? 4 : -1;
+    return -1;
+}
+
+/* One truss.  With xyz == NULL only the sizes are produced.  Returns 0 or an error code:
+ * 1 syntax, 2 inconsistent dimension, 3 unknown / invalid support, 4 joint id out of range,
+ * 5 does not fit nJ_max / nM_max. */
+static int parse_one(const char *text, size_t len, int nJ_max, int nM_max, double *xyz, int32_t *conn,
+                     double *E, double *A, double *rho, uint8_t *cbits, double *loads, int32_t *nJ_out,
+                     int32_t *nM_out, int32_t *dim_out) {
+    cur_t c = {text, text + len, 0};
+    int nJ = 0, nM = 0, dim = 0, rc = 0;
+    const int fill = xyz != NULL;
+    /* "force" may precede "joint" in a hand-written file: remember where it starts and read it last */
+    const char *force_at = NULL;
+    if (!eat(&c, '{')) return 1;
+    if (peek(&c) == '}') goto done;
+    for (;;) {
+        char key[16];
+        if (string(&c, key, sizeof key) < 0 || !eat(&c, ':')) return 1;
+        if (!strcmp(key, "joint")) {
+            if (!eat(&c, '[')) return 1;
+            if (peek(&c) == ']') {
+                ++c.p;
+            } else {
+                do {
+                    double v[3] = {0.0, 0.0, 0.0};
+                    int k = 0;
+                    char sup[16];
+                    if (!eat(&c, '[') || !eat(&c, '[')) return 1;
+                    do {
+                        if (fill) {
+                            const double x = number(&c);
+                            if (k < 3) v[k] = x;
+                        } else {
+                            skip_number(&c);
+                        }
+                        ++k;
+                    } while (more(&c) && !c.err);
+                    if (!eat(&c, ',') || string(&c, sup, sizeof sup) < 0 || !eat(&c, ']')) return 1;
+                    if (k != 2 && k != 3) return 2;
+                    if (dim == 0) dim = k;
+                    if (k != dim) return 2;
+                    const int bits = support_bits(sup, dim);
+                    if (bits < 0) return 3;
+                    if (fill) {
+                        if (nJ >= nJ_max) return 5;
+                        xyz[3 * nJ] = v[0];
+                        xyz[3 * nJ + 1] = v[1];
+                        xyz[3 * nJ + 2] = v[2];
+                        cbits[nJ] = (uint8_t)(bits | (dim == 2 ? 4 : 0));
+                    }
+                    ++nJ;
+                } while (more(&c) && !c.err);
+            }
+        } else if (!strcmp(key, "member")) {
+            if (!eat(&c, '[')) return 1;
+            if (peek(&c) == ']') {
+                ++c.p;
+            } else {
+                do {
+                    if (!fill) {  /* sizes only: count the element and step over it */
+                        skip_ws(&c);
+                        skip_value(&c);
+                        ++nM;
+                        continue;
+                    }
+                    if (!eat(&c, '[') || !eat(&c, '[')) return 1;
+                    const double j0 = number(&c);
+                    if (!eat(&c, ',')) return 1;
+                    const double j1 = number(&c);
+                    if (!eat(&c, ']') || !eat(&c, ',') || !eat(&c, '[')) return 1;
+                    const double a = number(&c);
+                    if (!eat(&c, ',')) return 1;
+                    const double e = number(&c);
+                    if (!eat(&c, ',')) return 1;
+                    const double d = number(&c);
+                    if (!eat(&c, ']') || !eat(&c, ']')) return 1;
+                    if (fill) {
+                        if (nM >= nM_max) return 5;
+                        conn[2 * nM] = (int32_t)j0;
+                        conn[2 * nM + 1] = (int32_t)j1;
+                        A[nM] = a;
+                        E[nM] = e;
+                        rho[nM] = d;
+                    }
+                    ++nM;
+                } while (more(&c) && !c.err);
+            }
+        } else if (!strcmp(key, "force")) {
+            skip_ws(&c);
+            force_at = c.p;
+            skip_value(&c);
+        } else {
+            skip_value(&c);
+        }
+        if (c.err) return 1;
+        const int ch = peek(&c);
+        if (ch == ',') {
+            ++c.p;
+            continue;
+        }
+        if (ch == '}') break;
+        return 1;
+    }
+done:
+    if (fill) {
+        for (int j = nJ; j < nJ_max; ++j) {
+            xyz[3 * j] = xyz[3 * j + 1] = xyz[3 * j + 2] = 0.0;
+            cbits[j] = 0;
+        }
+        for (int j = 0; j < 3 * nJ_max; ++j) loads[j] = 0.0;
+        for (int m = nM; m < nM_max; ++m) {
+            conn[2 * m] = conn[2 * m + 1] = 0;
+            E[m] = A[m] = 1.0;
+            rho[m] = 0.0;
+        }
+        for (int m = 0; m < nM; ++m)
+            if (conn[2 * m] < 0 || conn[2 * m] >= nJ || conn[2 * m + 1] < 0 || conn[2 * m + 1] >= nJ) rc = 4;
+        if (force_at != NULL) {
+            cur_t f = {force_at, text + len, 0};
+            if (peek(&f) == '[') {  /* a generator's empty dict {} means no loads */
+                ++f.p;
+                if (peek(&f) == ']') {
+                    ++f.p;
+                } else {
+                    do {
+                        double v[3] = {0.0, 0.0, 0.0};
+                        int k = 0;
+                        if (!eat(&f, '[')) return 1;
+                        const double jd = number(&f);
+                        if (!eat(&f, ',') || !eat(&f, '[')) return 1;
+                        do {
+                            const double x = number(&f);
+                            if (k < 3) v[k] = x;
+                            ++k;
+                        } while (more(&f) && !f.err);
+                        if (!eat(&f, ']')) return 1;
+                        if (k != dim) return 2;
+                        const int j = (int)jd;
+                        if (j < 0 || j >= nJ) return 4;
+                        /* zero vectors are dropped on insert (truss.py:181-182) */
+                        if (fabs(v[0]) >= ZERO_EPS || fabs(v[1]) >= ZERO_EPS || fabs(v[2]) >= ZERO_EPS) {
+                            loads[3 * j] = v[0];
+                            loads[3 * j + 1] = v[1];
+                            loads[3 * j + 2] = v[2];
+                        }
+                    } while (more(&f) && !f.err);
+                }
+                if (f.err) return 1;
+            }
+        }
+    }
+    *nJ_out = nJ;
+    *nM_out = nM;
+    *dim_out = dim == 0 ? 3 : dim;
+    return rc;
+}
+
+/* B JSON texts -> padded batch arrays.  xyz == NULL: sizes only (nJ, nM, dim).  Returns 0, or
+ * -(1000 * (index of the first bad text + 1) + error code of parse_one). */
+int trs_json_pack(int B, const char *const *texts, const int64_t *lens, int nJ_max, int nM_max,
+                  double *xyz, int32_t *conn, double *E, double *A, double *rho, uint8_t *cbits,
+                  double *loads, int32_t *nJ, int32_t *nM, int32_t *dim) {
+    int first_bad = B, code = 0;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int b = 0; b < B; ++b) {
+        int rc;
+        if (xyz == NULL)
+            rc = parse_one(texts[b], (size_t)lens[b], 0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, nJ + b,
+                           nM + b, dim + b);
+        else
+            rc = parse_one(texts[b], (size_t)lens[b], nJ_max, nM_max, xyz + (size_t)b * 3 * nJ_max,
+                           conn + (size_t)b * 2 * nM_max, E + (size_t)b * nM_max, A + (size_t)b * nM_max,
+                           rho + (size_t)b * nM_max, cbits + (size_t)b * nJ_max,
+                           loads + (size_t)b * 3 * nJ_max, nJ + b, nM + b, dim + b);
+        if (rc != 0) {
+#pragma omp critical
+            if (b < first_bad) {
+                first_bad = b;
+                code = rc;
+            }
+        }
+    }
+    return first_bad < B ? -(1000 * (first_bad + 1) + code) : 0;
+}
+
+/* The same from files: every file is read natively (no Python I/O), parsed and released.
+ * Error code 6 = the file cannot be read. */
+int trs_json_pack_files(int B, const char *const *paths, int nJ_max, int nM_max, double *xyz,
+                        int32_t *conn, double *E, double *A, double *rho, uint8_t *cbits, double *loads,
+                        int32_t *nJ, int32_t *nM, int32_t *dim) {
+    int first_bad = B, code = 0;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int b = 0; b < B; ++b) {
+        int rc = 6;
+        FILE *fh = fopen(paths[b], "rb");
+        char *buf = NULL;
+        long size = 0;
+        if (fh != NULL && fseek(fh, 0, SEEK_END) == 0 && (size = ftell(fh)) >= 0 && fseek(fh, 0, SEEK_SET) == 0 &&
+            (buf = (char *)malloc((size_t)size + 1)) != NULL && fread(buf, 1, (size_t)size, fh) == (size_t)size) {
+            if (xyz == NULL)
+                rc = parse_one(buf, (size_t)size, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, nJ + b, nM + b,
+                               dim + b);
+            else
+                rc = parse_one(buf, (size_t)size, nJ_max, nM_max, xyz + (size_t)b * 3 * nJ_max,
+                               conn + (size_t)b * 2 * nM_max, E + (size_t)b * nM_max, A + (size_t)b * nM_max,
+                               rho + (size_t)b * nM_max, cbits + (size_t)b * nJ_max,
+                               loads + (size_t)b * 3 * nJ_max, nJ + b, nM + b, dim + b);
+        }
+        free(buf);
+        if (fh != NULL) fclose(fh);
+        if (rc != 0) {
+#pragma omp critical
+            if (b < first_bad) {
+                first_bad = b;
+                code = rc;
+            }
+        }
+    }
+    return first_bad < B ? -(1000 * (first_bad + 1) + code) : 0;
+}
