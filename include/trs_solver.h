@@ -171,6 +171,20 @@ int trs_solve_small(int B, int nJ_max, int nM_max, int n_max_bound,
                     double *weight /* [B] or NULL */, double *stress_vio /* [B] */, double *disp_vio /* [B] */,
                     void *stream);
 
+/* Graph features of a solved batch of 3D trusses, on the device (the consumer of the path in the
+ * dataset workload: TrussHeteroDataCreator, data.py:116-282; GetAngles, utils.py:105-113): float32
+ * joint_x [B][nJ_max][7 (+3 with a prior)], member_x [B][nM_max][8 (+1 prior) (+1 regression)],
+ * joint_y [B][nJ_max][3] and member_y [B][nM_max] (regression only), weight [B] (double).  u_* are the
+ * dense displacements [B][nJ_max][3], N_* the member forces [B][nM_max] of the solve with the real
+ * sections (act) and with every member set to one fixed section of area fixedArea (pri); NULL = absent.
+ * Bit-identical to the host version trs_graph_features of include/trs_host.h. */
+int trs_graph_features_dev(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
+                           const double *A, const double *rho, const uint8_t *cbits, const double *loads,
+                           const int32_t *nJ, const int32_t *nM, const double *u_act, const double *N_act,
+                           const double *u_pri, const double *N_pri, double fixedArea, double forceScale,
+                           double displaceScale, double positionScale, int regression, float *joint_x,
+                           float *member_x, float *joint_y, float *member_y, double *weight, void *stream);
+
 /* The whole Truss.Solve() pipeline (truss.py:329-364) on one stream: trs_solve_small when the batch
  * shape qualifies (the slab, uf, work and env arguments are then not touched), otherwise
  * dofmap -> assemble -> potrf -> potrs -> recover.  Workspace pointers as above. */

@@ -32,6 +32,8 @@ SIGNATURES = {
     "trs_solve_small_fits": (_I, [_I, _I, _I]),
     "trs_solve_small": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                              _D, _D, _P, _P, _P, _P]),
+    "trs_graph_features_dev": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D,
+                                    _I, _P, _P, _P, _P, _P, _P]),
     "trs_solve": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
                        _P, _P, _P, _P, _P, _P, _P]),
 }

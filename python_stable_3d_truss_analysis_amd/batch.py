@@ -497,16 +497,29 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30):
     return groups
 
 
-def _solve_small_host(packed: PackedBatch, torch, dev, variants):
+@dataclass
+class DeviceResult:
+    """Dense results of a batched solve left on the device (torch tensors, caller's joint order):
+    displace / external [B,nJ_max,3] f64, internal [B,nM_max] f64, info [B] i32; `inputs` maps
+    DeviceBatch.INPUT_FIELDS to the resident input tensors (shared by the results of one call)."""
+    displace: object
+    external: object
+    internal: object
+    info: object
+    inputs: dict
+
+
+def _solve_small_host(packed: PackedBatch, torch, dev, variants, on_device=False):
     """Host arrays in -> host results out for a batch that qualifies for the fused small-system kernel
     as a whole: ONE upload (every input packed into one byte buffer), one `trs_solve_small` launch per
     section variant, ONE download.  This is what `Truss.Solve()` of a small truss costs: two copies and
-    a kernel.  Returns a list of `BatchResult`, one per variant."""
+    a kernel.  Returns a list of `BatchResult`, one per variant (`on_device`: of `DeviceResult`, nothing
+    is downloaded)."""
     lib = _capi.load()
     B, nJm, nMm = packed.B, packed.nJ_max, packed.nM_max
     ins = [("xyz", packed.xyz, np.float64), ("loads", packed.loads, np.float64), ("E", packed.E, np.float64),
-           ("A", packed.A, np.float64), ("conn", packed.conn, np.int32), ("nJ", packed.nJ, np.int32),
-           ("nM", packed.nM, np.int32), ("cbits", packed.cbits, np.uint8)]
+           ("A", packed.A, np.float64), ("rho", packed.rho, np.float64), ("conn", packed.conn, np.int32),
+           ("nJ", packed.nJ, np.int32), ("nM", packed.nM, np.int32), ("cbits", packed.cbits, np.uint8)]
     off, total = {}, 0
     for name, arr, dt in ins:
         off[name] = total
@@ -543,6 +556,18 @@ def _solve_small_host(packed: PackedBatch, torch, dev, variants):
                 pin + off["cbits"], pin + off["loads"], pin + off["nJ"], pin + off["nM"], o, o + nu,
                 o + 2 * nu, o + 2 * nu + nn, None, None, None, 0.0, 0.0, None, None, None, stream),
                 "trs_solve_small")
+    if on_device:
+        tdt = {np.float64: torch.float64, np.int32: torch.int32, np.uint8: torch.uint8}
+        inputs = {name: din[off[name]: off[name] + arr.size * np.dtype(dt).itemsize].view(tdt[dt]).view(arr.shape)
+                  for name, arr, dt in ins}
+        out = []
+        for slot in range(len(variants)):
+            d = dout[slot * per: (slot + 1) * per]
+            out.append(DeviceResult(d[:nu].view(torch.float64).view(B, nJm, 3),
+                                    d[nu: 2 * nu].view(torch.float64).view(B, nJm, 3),
+                                    d[2 * nu: 2 * nu + nn].view(torch.float64).view(B, nMm),
+                                    d[2 * nu + nn: 2 * nu + nn + 4 * B].view(torch.int32), inputs))
+        return out
     hout = dout.cpu().numpy()
     results = []
     for slot in range(len(variants)):
@@ -554,7 +579,8 @@ def _solve_small_host(packed: PackedBatch, torch, dev, variants):
     return results
 
 
-def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False, sections=None):
+def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False, sections=None,
+                on_device=False):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
 
     The packed inputs go up once; a ragged batch is bucketed by padded system size
@@ -568,7 +594,10 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     `sections=[None, (a, e, density), ...]` solves the same trusses several times - `None` with their
     own member sections, a triple with every member set to it (the "fixed member type" prior of the
     reference's dataset path, `data.py:107-114`) - and returns a list of results: the geometry is
-    uploaded, reordered and bucketed once, only A and E change between the solves."""
+    uploaded, reordered and bucketed once, only A and E change between the solves.
+
+    `on_device=True` leaves the results on the GPU (`DeviceResult`, torch tensors in the caller's joint
+    order, plus the resident inputs) for device-side consumers such as the graph-feature kernel."""
     packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
         else pack_trusses(list(trusses_or_packed))
     torch, dev = _require_gpu(device)
@@ -576,10 +605,11 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     variants = [None] if sections is None else list(sections)
     if B and _capi.load().trs_solve_small_fits(nJ_max, nM_max, packed.n_max):
         # every truss is small: the fused kernel, no bucketing, no reordering (nothing to gain from it)
-        out = _solve_small_host(packed, torch, dev, variants)
+        out = _solve_small_host(packed, torch, dev, variants, on_device)
         return out[0] if sections is None else out
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
     full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS}
+    original = dict(full)   # the caller's joint order (the reordering below makes new tensors)
     perm = None
     if reorder:
         perm = up(rcm_permutation(packed).astype(np.int64))                  # [B, nJ_max], joint k := old perm[k]
@@ -651,6 +681,9 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
             u = torch.zeros_like(u).scatter_(1, by_joint, u)
             f_ext = torch.zeros_like(f_ext).scatter_(1, by_joint, f_ext)
         o["u"], o["f_ext"] = u, f_ext
+    if on_device:
+        results = [DeviceResult(o["u"], o["f_ext"], o["N"], o["info"], original) for o in outs]
+        return results[0] if sections is None else results
     torch.cuda.synchronize(dev)
     for o in outs:
         results.append(BatchResult(o["u"].cpu().numpy(), o["f_ext"].cpu().numpy(), o["N"].cpu().numpy(),

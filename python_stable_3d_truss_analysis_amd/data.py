@@ -150,26 +150,23 @@ def _implicit_edges(conn, nJ, nM):
     return np.stack(np.nonzero(jj)), np.stack(np.nonzero(mm))
 
 
-def hetero_tensors_batch(packed: PackedBatch, actual: BatchResult, prior: BatchResult, fixedArea,
-                         taskType=TaskType.OPTIMIZATION, metapathType=MetapathType.NO_IMPLICIT,
-                         forceScale=1., displaceScale=1., positionScale=1., sources=None):
-    """Graphs of a whole solved batch: `actual` / `prior` are the dense results of the two batched
-    solves (`prior` may be None).  Returns one graph per truss.
+def _feature_shapes(B, nJm, nMm, has_prior, regression):
+    FJ = 7 + (3 if has_prior else 0)
+    FM = 8 + (1 if has_prior else 0) + (1 if regression else 0)
+    return FJ, FM
 
-    The features of ALL trusses are formed natively (`csrc/graphfeat.c`, OpenMP over the batch; same
-    formulas as `graph_arrays`, which stays the single-truss path) straight into float32 batch
-    tensors; a truss's graph holds slices of those batch tensors."""
+
+def feature_tensors_host(packed: PackedBatch, actual: BatchResult, prior: BatchResult, fixedArea, taskType,
+                         forceScale=1., displaceScale=1., positionScale=1.):
+    """float32 feature tensors of a solved batch, formed natively on the HOST (`csrc/graphfeat.c`,
+    OpenMP over the batch; same formulas as `graph_arrays`, which stays the single-truss path):
+    dict joint_x [B,nJ,FJ], member_x [B,nM,FM], joint_y / member_y (regression), weight [B] (numpy)."""
     import ctypes
     import torch
     from .generate import _load
-    if taskType not in (TaskType.OPTIMIZATION, TaskType.REGRESSION):
-        raise InvalidTaskTypeError(f"Invalid task type [{taskType}].")
-    if (np.asarray(packed.dim) != 3).any():
-        raise NotImplementedError("graph features are defined for 3D trusses (utils.py:105-113)")
     B, nJm, nMm = packed.B, packed.nJ_max, packed.nM_max
     regression = taskType == TaskType.REGRESSION
-    FJ = 7 + (3 if prior is not None else 0)
-    FM = 8 + (1 if prior is not None else 0) + (1 if regression else 0)
+    FJ, FM = _feature_shapes(B, nJm, nMm, prior is not None, regression)
     joint_x = torch.empty([B, nJm, FJ], dtype=torch.float32)
     member_x = torch.empty([B, nMm, FM], dtype=torch.float32)
     joint_y = torch.empty([B, nJm, 3], dtype=torch.float32) if regression else None
@@ -191,8 +188,64 @@ def hetero_tensors_batch(packed: PackedBatch, actual: BatchResult, prior: BatchR
         tptr(joint_x), tptr(member_x), tptr(joint_y), tptr(member_y), ptr(weight))
     if rc != 0:
         raise RuntimeError(f"trs_graph_features failed ({rc})")
-    conn = torch.from_numpy(keep[1].astype(np.int64))
-    j2m = torch.stack([conn.reshape(B, -1), torch.arange(nMm).repeat_interleave(2).expand(B, -1)], dim=1)
+    return {"joint_x": joint_x, "member_x": member_x, "joint_y": joint_y, "member_y": member_y,
+            "weight": weight, "conn": torch.from_numpy(keep[1].astype(np.int64))}
+
+
+def feature_tensors_device(packed: PackedBatch, fixedMemberType, taskType, forceScale=1., displaceScale=1.,
+                           positionScale=1., device=None, reorder=False):
+    """The dataset sample pipeline entirely on the GPU (BASELINE config 5): both solves
+    (`solve_batch(..., sections=[None, fixed], on_device=True)`: one upload, one reordering) and the
+    feature kernel `trs_graph_features_dev` (`csrc/graphfeat.hip`) on the resident results - nothing but
+    the float32 feature tensors ever needs to leave the device.  Returns the same dict as
+    `feature_tensors_host` with torch tensors ON THE DEVICE (weight included), plus `info` [2,B]
+    (status of the two solves).  Bit-identical to the host path."""
+    import torch
+    from . import _capi
+    from .batch import solve_batch
+    if (np.asarray(packed.dim) != 3).any():
+        raise NotImplementedError("graph features are defined for 3D trusses (utils.py:105-113)")
+    regression = taskType == TaskType.REGRESSION
+    sections = [None] + ([(fixedMemberType.a, fixedMemberType.e, fixedMemberType.density)]
+                         if fixedMemberType is not None else [])
+    out = solve_batch(packed, device, reorder=reorder, sections=sections, on_device=True)
+    actual, prior = out[0], (out[1] if fixedMemberType is not None else None)
+    inp = actual.inputs
+    dev = actual.displace.device
+    B, nJm, nMm = packed.B, packed.nJ_max, packed.nM_max
+    FJ, FM = _feature_shapes(B, nJm, nMm, prior is not None, regression)
+    joint_x = torch.empty([B, nJm, FJ], dtype=torch.float32, device=dev)
+    member_x = torch.empty([B, nMm, FM], dtype=torch.float32, device=dev)
+    joint_y = torch.empty([B, nJm, 3], dtype=torch.float32, device=dev) if regression else None
+    member_y = torch.empty([B, nMm, 1], dtype=torch.float32, device=dev) if regression else None
+    weight = torch.empty([B], dtype=torch.float64, device=dev)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    cont = lambda t: t if t.is_contiguous() else t.contiguous()
+    ua, na = (cont(actual.displace), cont(actual.internal)) if regression else (None, None)
+    up, npr = (cont(prior.displace), cont(prior.internal)) if prior is not None else (None, None)
+    with torch.cuda.device(dev):
+        _capi.check(_capi.load().trs_graph_features_dev(
+            B, nJm, nMm, inp["xyz"].data_ptr(), inp["conn"].data_ptr(), inp["A"].data_ptr(), inp["rho"].data_ptr(),
+            inp["cbits"].data_ptr(), inp["loads"].data_ptr(), inp["nJ"].data_ptr(), inp["nM"].data_ptr(),
+            ptr(ua), ptr(na), ptr(up), ptr(npr), float(fixedMemberType.a if prior is not None else 1.0),
+            float(forceScale), float(displaceScale), float(positionScale), int(regression), ptr(joint_x),
+            ptr(member_x), ptr(joint_y), ptr(member_y), weight.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream), "trs_graph_features_dev")
+    info = torch.stack([actual.info, prior.info if prior is not None else torch.zeros_like(actual.info)])
+    return {"joint_x": joint_x, "member_x": member_x, "joint_y": joint_y, "member_y": member_y,
+            "weight": weight, "conn": inp["conn"].long(), "info": info}
+
+
+def graphs_from_tensors(packed: PackedBatch, tensors, metapathType=MetapathType.NO_IMPLICIT, sources=None):
+    """One graph per truss whose tensors are SLICES of the batch feature tensors (host or device)."""
+    import torch
+    B, nMm = packed.B, packed.nM_max
+    conn = tensors["conn"]
+    joint_x, member_x, joint_y, member_y = (tensors[k] for k in ("joint_x", "member_x", "joint_y", "member_y"))
+    weight = tensors["weight"]
+    weight = weight.cpu().numpy() if hasattr(weight, "cpu") else weight
+    member_ids = torch.arange(nMm, device=conn.device).repeat_interleave(2).expand(B, -1)
+    j2m = torch.stack([conn.reshape(B, -1), member_ids], dim=1)
     m2j = torch.flip(j2m, dims=[1])
     graphs = []
     for b in range(B):
@@ -209,10 +262,42 @@ def hetero_tensors_batch(packed: PackedBatch, actual: BatchResult, prior: BatchR
         g["member", "m2j", "joint"].edge_index = m2j[b, :, :2 * nM]
         if metapathType == MetapathType.USE_IMPLICIT:
             jj, mm = _implicit_edges(packed.conn[b, :nM], nJ, nM)
-            g["joint", "j2j", "joint"].edge_index = torch.from_numpy(jj)
-            g["member", "m2m", "member"].edge_index = torch.from_numpy(mm)
+            g["joint", "j2j", "joint"].edge_index = torch.from_numpy(jj).to(conn.device)
+            g["member", "m2m", "member"].edge_index = torch.from_numpy(mm).to(conn.device)
         graphs.append(g)
     return graphs
+
+
+def hetero_tensors_batch(packed: PackedBatch, actual: BatchResult, prior: BatchResult, fixedArea,
+                         taskType=TaskType.OPTIMIZATION, metapathType=MetapathType.NO_IMPLICIT,
+                         forceScale=1., displaceScale=1., positionScale=1., sources=None):
+    """Graphs of a whole solved batch from HOST results: `actual` / `prior` are the dense results of the
+    two batched solves (`prior` may be None).  Returns one graph per truss, holding slices of float32
+    batch tensors (`feature_tensors_host`).  `dataset_graphs` is the all-device form."""
+    if taskType not in (TaskType.OPTIMIZATION, TaskType.REGRESSION):
+        raise InvalidTaskTypeError(f"Invalid task type [{taskType}].")
+    if (np.asarray(packed.dim) != 3).any():
+        raise NotImplementedError("graph features are defined for 3D trusses (utils.py:105-113)")
+    tensors = feature_tensors_host(packed, actual, prior, fixedArea, taskType, forceScale, displaceScale,
+                                   positionScale)
+    return graphs_from_tensors(packed, tensors, metapathType, sources)
+
+
+def dataset_graphs(packed: PackedBatch, fixedMemberType=None, taskType=TaskType.OPTIMIZATION,
+                   metapathType=MetapathType.NO_IMPLICIT, forceScale=1., displaceScale=1., positionScale=1.,
+                   sources=None, device=None, reorder=False, to_host=False):
+    """Dataset samples of a packed batch with everything on the GPU: two solves + feature kernel
+    (`feature_tensors_device`), graphs holding slices of the DEVICE tensors (`to_host=True`: one download of
+    the float32 tensors first).  Raises `LinAlgError` if any of the solves met a non-positive pivot."""
+    if taskType not in (TaskType.OPTIMIZATION, TaskType.REGRESSION):
+        raise InvalidTaskTypeError(f"Invalid task type [{taskType}].")
+    tensors = feature_tensors_device(packed, fixedMemberType, taskType, forceScale, displaceScale,
+                                     positionScale, device, reorder)
+    if bool(tensors["info"].any().item()):
+        raise np.linalg.LinAlgError("Singular matrix")
+    if to_host:
+        tensors = {k: (v.cpu() if hasattr(v, "cpu") else v) for k, v in tensors.items()}
+    return graphs_from_tensors(packed, tensors, metapathType, sources)
 
 
 def solve_actual_and_prior(packed: PackedBatch, fixedMemberType=None, device=None, reorder=False,
