@@ -58,19 +58,19 @@ int trs_graph_features(int B, int nJ_max, int nM_max, const double *xyz, const i
                        float *member_x, float *joint_y, float *member_y, double *weight);
 
 /* Bulk JSON reader (truss.py:401-421 for many files at once; schema detail/combine_with_JSON.md:71-163):
- * B JSON texts (or files) -> the padded batch arrays above, plus dim[b] (2 or 3; a 2D truss is embedded
+ * B JSON texts -> the padded batch arrays above, plus dim[b] (2 or 3; a 2D truss is embedded
  * with z = 0 and bit 4 set in every cbits entry).  Call once with xyz == NULL for nJ[b], nM[b], dim[b]
  * (sizes-only pass), allocate to the maxima, call again to fill.  Loads below 1e-10 in every component
  * are dropped and unknown keys (the result keys of output files) are skipped, as the reference does.
  * Returns 0 or -(1000 * (index of the first bad input + 1) + code), code: 1 syntax, 2 inconsistent
- * dimension, 3 unknown / invalid support type, 4 joint id out of range, 5 does not fit the padding,
- * 6 unreadable file. */
+ * dimension, 3 unknown / invalid support type, 4 joint id out of range, 5 does not fit the padding. */
 int trs_json_pack(int B, const char *const *texts, const int64_t *lens, int nJ_max, int nM_max,
                   double *xyz, int32_t *conn, double *E, double *A, double *rho, uint8_t *cbits,
                   double *loads, int32_t *nJ, int32_t *nM, int32_t *dim);
-int trs_json_pack_files(int B, const char *const *paths, int nJ_max, int nM_max, double *xyz,
-                        int32_t *conn, double *E, double *A, double *rho, uint8_t *cbits, double *loads,
-                        int32_t *nJ, int32_t *nM, int32_t *dim);
+/* Files for trs_json_pack: read natively and in parallel into one buffer per file (bufs[b], lens[b];
+ * release with trs_json_free_files).  Returns 0 or -(1000 * (index of the first unreadable file + 1) + 6). */
+int trs_json_read_files(int B, const char *const *paths, char **bufs, int64_t *lens);
+void trs_json_free_files(int B, char **bufs);
 
 #ifdef __cplusplus
 }

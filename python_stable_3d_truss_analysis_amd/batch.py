@@ -190,7 +190,7 @@ def pack_json_texts(texts):
 
 
 def pack_json_files(paths):
-    """Truss JSON FILES -> `PackedBatch`; the files are read and parsed natively, in parallel
+    """Truss JSON FILES -> `PackedBatch`; the files are read (once) and parsed natively, in parallel
     (the bulk form of `Truss.LoadFromJSON`, reference `truss.py:401-421`)."""
     import ctypes
     from .generate import _load
@@ -198,9 +198,18 @@ def pack_json_files(paths):
     raw = [os.fsencode(p) for p in paths]
     B = len(raw)
     arr = (ctypes.c_char_p * B)(*raw)
-    lib.trs_json_pack_files.restype = ctypes.c_int
-    return _pack_json_native(B, lambda jm, mm, *rest: lib.trs_json_pack_files(
-        ctypes.c_int(B), arr, ctypes.c_int(jm), ctypes.c_int(mm), *rest))
+    bufs = (ctypes.c_void_p * B)()
+    lens = np.zeros([B], dtype=np.int64)
+    lib.trs_json_read_files.restype = ctypes.c_int
+    lib.trs_json_pack.restype = ctypes.c_int
+    rc = lib.trs_json_read_files(ctypes.c_int(B), arr, bufs, lens.ctypes.data_as(ctypes.c_void_p))
+    try:
+        if rc != 0:
+            raise ValueError(f"truss JSON #{(-rc) // 1000 - 1}: {_JSON_ERRORS[6]}")
+        return _pack_json_native(B, lambda jm, mm, *rest: lib.trs_json_pack(
+            ctypes.c_int(B), bufs, lens.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(jm), ctypes.c_int(mm), *rest))
+    finally:
+        lib.trs_json_free_files(ctypes.c_int(B), bufs)
 
 
 @dataclass
@@ -424,6 +433,81 @@ class DeviceBatch:
                            self.info.cpu().numpy())
 
 
+class StreamedSolver:
+    """Host -> device -> host pipeline for a stream of equally shaped batches (the feed of a resident
+    solver over PCIe): the upload of batch k+1, the solve of batch k and the download of batch k-1 overlap
+    on three HIP streams, with `slots` resident `DeviceBatch`es and page-locked staging buffers.
+
+        pipe = StreamedSolver(template_packed)
+        for packed in batches:                     # same padded shapes as the template
+            done = pipe.submit(pipe.stage(packed)) # returns the results of an EARLIER batch, or None
+        results = pipe.drain()
+
+    Results are views of the slot's pinned output buffers: valid until the slot is used again
+    (`slots` submissions later) - copy what must live longer."""
+
+    def __init__(self, template: PackedBatch, device=None, slots=2, use_envelope=True):
+        torch, dev = _require_gpu(device)
+        self.torch, self.device = torch, dev
+        self.dev = [DeviceBatch(template, dev, use_envelope=use_envelope) for _ in range(slots)]
+        self.host_in = [d.pinned_inputs(template) for d in self.dev]
+        self.host_out = [{k: torch.empty(getattr(d, k).shape, dtype=getattr(d, k).dtype).pin_memory()
+                          for k in ("u", "f_ext", "N", "info")} for d in self.dev]
+        self.s_up, self.s_run, self.s_down = (torch.cuda.Stream(dev) for _ in range(3))
+        self.ev_up = [torch.cuda.Event() for _ in range(slots)]
+        self.ev_run = [torch.cuda.Event() for _ in range(slots)]
+        self.ev_down = [torch.cuda.Event() for _ in range(slots)]
+        self.count = 0
+        self.pending = []   # slots whose download is in flight, oldest first
+
+    def stage(self, packed: PackedBatch):
+        """Copy a batch's host arrays into the next slot's page-locked staging buffers."""
+        slot = self.count % len(self.dev)
+        self.ev_up[slot].synchronize()   # the previous upload out of this staging buffer has finished
+        for f in DeviceBatch.INPUT_FIELDS:
+            self.host_in[slot][f].numpy()[...] = getattr(packed, f)
+        return self.host_in[slot]
+
+    def submit(self, host_inputs=None):
+        """Enqueue upload -> solve -> download of one batch (`host_inputs`: pinned tensors by field name,
+        default: the slot's staging buffers).  Returns the `BatchResult` of the batch submitted `slots`
+        calls ago once its download has finished, else None."""
+        t = self.torch
+        n = len(self.dev)
+        slot = self.count % n
+        self.count += 1
+        done = None
+        if len(self.pending) == n:   # the slot is about to be reused: hand out its previous results
+            done = self._take(self.pending.pop(0))
+        dev, src = self.dev[slot], host_inputs if host_inputs is not None else self.host_in[slot]
+        with t.cuda.stream(self.s_up):
+            self.s_up.wait_event(self.ev_run[slot])     # the slot's previous solve no longer reads its inputs
+            dev.upload(src)
+            self.ev_up[slot].record(self.s_up)
+        with t.cuda.stream(self.s_run):
+            self.s_run.wait_event(self.ev_up[slot])
+            self.s_run.wait_event(self.ev_down[slot])   # the slot's previous results have been downloaded
+            dev.solve()
+            self.ev_run[slot].record(self.s_run)
+        with t.cuda.stream(self.s_down):
+            self.s_down.wait_event(self.ev_run[slot])
+            dev.download(self.host_out[slot])
+            self.ev_down[slot].record(self.s_down)
+        self.pending.append(slot)
+        return done
+
+    def _take(self, slot):
+        self.ev_down[slot].synchronize()
+        o = self.host_out[slot]
+        return BatchResult(o["u"].numpy(), o["f_ext"].numpy(), o["N"].numpy(), o["info"].numpy())
+
+    def drain(self):
+        """Wait for everything in flight; the results of the batches not yet handed out, oldest first."""
+        out = [self._take(s) for s in self.pending]
+        self.pending = []
+        return out
+
+
 def rcm_permutation(packed: PackedBatch):
     """Reverse Cuthill-McKee joint order of every truss (native, `csrc/reorder.c`):
     perm[b, k] = old id of the joint that becomes joint k.  Shrinks the envelope of the reduced
@@ -612,7 +696,7 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     original = dict(full)   # the caller's joint order (the reordering below makes new tensors)
     perm = None
     if reorder:
-        perm = up(rcm_permutation(packed).astype(np.int64))                  # [B, nJ_max], joint k := old perm[k]
+        perm = up(rcm_permutation(packed)).long()                            # [B, nJ_max], joint k := old perm[k]
         inverse = torch.empty_like(perm)
         inverse.scatter_(1, perm, torch.arange(nJ_max, device=dev).expand(B, -1))
         by_joint = perm[:, :, None].expand(-1, -1, 3)

@@ -373,38 +373,33 @@ int trs_json_pack(int B, const char *const *texts, const int64_t *lens, int nJ_m
     return first_bad < B ? -(1000 * (first_bad + 1) + code) : 0;
 }
 
-/* The same from files: every file is read natively (no Python I/O), parsed and released.
- * Error code 6 = the file cannot be read. */
-int trs_json_pack_files(int B, const char *const *paths, int nJ_max, int nM_max, double *xyz,
-                        int32_t *conn, double *E, double *A, double *rho, uint8_t *cbits, double *loads,
-                        int32_t *nJ, int32_t *nM, int32_t *dim) {
-    int first_bad = B, code = 0;
+/* File contents for trs_json_pack: every file is read natively (no Python I/O), in parallel, into a
+ * buffer of its own: bufs[b] (release with trs_json_free_files), lens[b].  Returns 0 or
+ * -(1000 * (index of the first unreadable file + 1) + 6). */
+int trs_json_read_files(int B, const char *const *paths, char **bufs, int64_t *lens) {
+    int first_bad = B;
 #pragma omp parallel for schedule(dynamic, 64)
     for (int b = 0; b < B; ++b) {
-        int rc = 6;
+        bufs[b] = NULL;
+        lens[b] = 0;
         FILE *fh = fopen(paths[b], "rb");
-        char *buf = NULL;
         long size = 0;
-        if (fh != NULL && fseek(fh, 0, SEEK_END) == 0 && (size = ftell(fh)) >= 0 && fseek(fh, 0, SEEK_SET) == 0 &&
-            (buf = (char *)malloc((size_t)size + 1)) != NULL && fread(buf, 1, (size_t)size, fh) == (size_t)size) {
-            if (xyz == NULL)
-                rc = parse_one(buf, (size_t)size, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, nJ + b, nM + b,
-                               dim + b);
-            else
-                rc = parse_one(buf, (size_t)size, nJ_max, nM_max, xyz + (size_t)b * 3 * nJ_max,
-                               conn + (size_t)b * 2 * nM_max, E + (size_t)b * nM_max, A + (size_t)b * nM_max,
-                               rho + (size_t)b * nM_max, cbits + (size_t)b * nJ_max,
-                               loads + (size_t)b * 3 * nJ_max, nJ + b, nM + b, dim + b);
-        }
-        free(buf);
+        char *buf = NULL;
+        int ok = fh != NULL && fseek(fh, 0, SEEK_END) == 0 && (size = ftell(fh)) >= 0 && fseek(fh, 0, SEEK_SET) == 0 &&
+                 (buf = (char *)malloc((size_t)size + 1)) != NULL && fread(buf, 1, (size_t)size, fh) == (size_t)size;
         if (fh != NULL) fclose(fh);
-        if (rc != 0) {
+        if (ok) {
+            bufs[b] = buf;
+            lens[b] = size;
+        } else {
+            free(buf);
 #pragma omp critical
-            if (b < first_bad) {
-                first_bad = b;
-                code = rc;
-            }
+            if (b < first_bad) first_bad = b;
         }
     }
-    return first_bad < B ? -(1000 * (first_bad + 1) + code) : 0;
+    return first_bad < B ? -(1000 * (first_bad + 1) + 6) : 0;
+}
+
+void trs_json_free_files(int B, char **bufs) {
+    for (int b = 0; b < B; ++b) free(bufs[b]);
 }
