@@ -181,3 +181,36 @@ def test_config5_dataset_16384_samples_through_the_sharded_entry_point():
     one = gdata.solve_actual_and_prior(packed.take(np.arange(512)), fixed, device="cuda:0", reorder=True)
     assert np.array_equal(one[0].displace, actual.displace[:512, :one[0].displace.shape[1]])
     assert np.array_equal(one[1].internal, prior.internal[:512, :one[1].internal.shape[1]])
+
+
+# ---- feed path: overlapped upload / solve / download ------------------------------------------------------
+
+def test_streamed_solver_pipelines_a_stream_of_batches():
+    """`batch.StreamedSolver`: six different batches (bar-942 copies with scaled loads and sections)
+    through the three-stream pipeline with two resident slots; every result equals the plain solve of
+    that batch bit for bit, in submission order."""
+    from python_stable_3d_truss_analysis_amd import batch
+    base = batch.pack_json([H.load_json("bar-942_input_0")]).replicate(64)
+    rng = np.random.default_rng(3)
+    batches = []
+    for k in range(6):
+        p = base.take(np.arange(64))
+        p.loads *= rng.uniform(0.5, 2.0, size=(64, 1, 1))
+        p.A *= rng.uniform(0.8, 1.25, size=p.A.shape)
+        batches.append(p)
+    pipe = batch.StreamedSolver(base, slots=2)
+    got = []
+    for p in batches:
+        done = pipe.submit(pipe.stage(p))
+        if done is not None:
+            got.append(batch.BatchResult(*(np.array(a) for a in (done.displace, done.external, done.internal, done.info))))
+    got += [batch.BatchResult(*(np.array(a) for a in (d.displace, d.external, d.internal, d.info))) for d in pipe.drain()]
+    assert len(got) == 6
+    for p, res in zip(batches, got):
+        dev = batch.DeviceBatch(p)
+        dev.solve()
+        want = dev.result()
+        assert not want.info.any()
+        np.testing.assert_array_equal(res.displace, want.displace)
+        np.testing.assert_array_equal(res.external, want.external)
+        np.testing.assert_array_equal(res.internal, want.internal)
