@@ -440,49 +440,51 @@ class StreamedSolver:
 
         pipe = StreamedSolver(template_packed)
         for packed in batches:                     # same padded shapes as the template
-            done = pipe.submit(pipe.stage(packed)) # returns the results of an EARLIER batch, or None
-        results = pipe.drain()
+            done = pipe.submit(pipe.stage(packed)) # the results of the batch submitted `slots` calls ago, or None
+            ...consume `done` here...
+        for done in pipe.drain(): ...
 
-    Results are views of the slot's pinned output buffers: valid until the slot is used again
-    (`slots` submissions later) - copy what must live longer."""
+    Results are views of page-locked output buffers (a ring of slots + 1): what `submit` returns stays
+    valid until the NEXT call of `submit`; `drain` results until the pipe is used again.  Only what the
+    solve reads is uploaded (`fields`; the densities are not part of `Truss.Solve()`)."""
 
-    def __init__(self, template: PackedBatch, device=None, slots=2, use_envelope=True):
+    def __init__(self, template: PackedBatch, device=None, slots=2, use_envelope=True,
+                 fields=("xyz", "conn", "E", "A", "cbits", "loads", "nJ", "nM")):
         torch, dev = _require_gpu(device)
-        self.torch, self.device = torch, dev
+        self.torch, self.device, self.fields = torch, dev, tuple(fields)
         self.dev = [DeviceBatch(template, dev, use_envelope=use_envelope) for _ in range(slots)]
-        self.host_in = [d.pinned_inputs(template) for d in self.dev]
-        self.host_out = [{k: torch.empty(getattr(d, k).shape, dtype=getattr(d, k).dtype).pin_memory()
-                          for k in ("u", "f_ext", "N", "info")} for d in self.dev]
+        self.host_in = [{f: v for f, v in d.pinned_inputs(template).items() if f in self.fields} for d in self.dev]
+        self.host_out = [{k: torch.empty(getattr(self.dev[0], k).shape, dtype=getattr(self.dev[0], k).dtype).pin_memory()
+                          for k in ("u", "f_ext", "N", "info")} for _ in range(slots + 1)]
         self.s_up, self.s_run, self.s_down = (torch.cuda.Stream(dev) for _ in range(3))
-        self.ev_up = [torch.cuda.Event() for _ in range(slots)]
-        self.ev_run = [torch.cuda.Event() for _ in range(slots)]
-        self.ev_down = [torch.cuda.Event() for _ in range(slots)]
+        self.ev_up = [torch.cuda.Event() for _ in range(slots)]       # upload into device slot finished
+        self.ev_run = [torch.cuda.Event() for _ in range(slots)]      # solve on device slot finished
+        self.ev_down = [torch.cuda.Event() for _ in range(slots)]     # device slot's results downloaded
         self.count = 0
-        self.pending = []   # slots whose download is in flight, oldest first
+        self.pending = []   # (device slot, host buffer) of the downloads in flight, oldest first
 
     def stage(self, packed: PackedBatch):
         """Copy a batch's host arrays into the next slot's page-locked staging buffers."""
         slot = self.count % len(self.dev)
         self.ev_up[slot].synchronize()   # the previous upload out of this staging buffer has finished
-        for f in DeviceBatch.INPUT_FIELDS:
+        for f in self.fields:
             self.host_in[slot][f].numpy()[...] = getattr(packed, f)
         return self.host_in[slot]
 
     def submit(self, host_inputs=None):
         """Enqueue upload -> solve -> download of one batch (`host_inputs`: pinned tensors by field name,
         default: the slot's staging buffers).  Returns the `BatchResult` of the batch submitted `slots`
-        calls ago once its download has finished, else None."""
+        calls ago (its download has finished), else None."""
         t = self.torch
         n = len(self.dev)
-        slot = self.count % n
+        slot, hbuf = self.count % n, self.count % (n + 1)
         self.count += 1
-        done = None
-        if len(self.pending) == n:   # the slot is about to be reused: hand out its previous results
-            done = self._take(self.pending.pop(0))
+        done = self._take(self.pending.pop(0)) if len(self.pending) == n else None
         dev, src = self.dev[slot], host_inputs if host_inputs is not None else self.host_in[slot]
         with t.cuda.stream(self.s_up):
             self.s_up.wait_event(self.ev_run[slot])     # the slot's previous solve no longer reads its inputs
-            dev.upload(src)
+            for f in self.fields:
+                getattr(dev, f).copy_(src[f], non_blocking=True)
             self.ev_up[slot].record(self.s_up)
         with t.cuda.stream(self.s_run):
             self.s_run.wait_event(self.ev_up[slot])
@@ -491,19 +493,20 @@ class StreamedSolver:
             self.ev_run[slot].record(self.s_run)
         with t.cuda.stream(self.s_down):
             self.s_down.wait_event(self.ev_run[slot])
-            dev.download(self.host_out[slot])
+            dev.download(self.host_out[hbuf])
             self.ev_down[slot].record(self.s_down)
-        self.pending.append(slot)
+        self.pending.append((slot, hbuf))
         return done
 
-    def _take(self, slot):
+    def _take(self, entry):
+        slot, hbuf = entry
         self.ev_down[slot].synchronize()
-        o = self.host_out[slot]
+        o = self.host_out[hbuf]
         return BatchResult(o["u"].numpy(), o["f_ext"].numpy(), o["N"].numpy(), o["info"].numpy())
 
     def drain(self):
         """Wait for everything in flight; the results of the batches not yet handed out, oldest first."""
-        out = [self._take(s) for s in self.pending]
+        out = [self._take(e) for e in self.pending]
         self.pending = []
         return out
 
