@@ -70,7 +70,10 @@ def config4(out):
 
 
 def config5(B, out):
-    """Dataset sample = generate -> two batched solves (actual + fixed section) -> graph tensors."""
+    """Dataset sample = generate -> two batched solves (actual + fixed section) -> graph tensors.
+    Host form: results downloaded, features formed on the host (graphfeat.c).  Device form: the two solves
+    share one upload / reordering, the features are formed on the GPU (graphfeat.hip) and only float32
+    feature tensors come down."""
     from python_stable_3d_truss_analysis_amd import data as gdata
     from python_stable_3d_truss_analysis_amd.type import TaskType
     rng = np.random.default_rng(1)
@@ -78,15 +81,33 @@ def config5(B, out):
     packed = gen.generate_cube_batch(rng.integers(8, 191, size=B), gridRange=(6, 6, 6), seed=11)
     t1 = time.perf_counter()
     fixed = MemberType(1., 1e7, 0.1)
-    gdata.solve_actual_and_prior(packed.take(np.arange(min(B, 256))), fixed, reorder=True)   # warm
+    gdata.solve_actual_and_prior(packed.take(np.arange(min(B, 256))), fixed, device="cuda:0", reorder=True)   # warm
     t2 = time.perf_counter()
-    actual, prior = gdata.solve_actual_and_prior(packed, fixed, reorder=True)
+    actual, prior = gdata.solve_actual_and_prior(packed, fixed, device="cuda:0", reorder=True)
     t3 = time.perf_counter()
     graphs = gdata.hetero_tensors_batch(packed, actual, prior, fixed.a, TaskType.REGRESSION)
     t4 = time.perf_counter()
-    out["config5"] = {"B": B, "generate_s": t1 - t0, "two_solves_end_to_end_s": t3 - t2, "graphs_s": t4 - t3,
-                      "samples_per_s": B / ((t1 - t0) + (t3 - t2) + (t4 - t3)), "graphs": len(graphs),
-                      "info_nonzero": int((actual.info != 0).sum() + (prior.info != 0).sum())}
+    out["config5_host_features"] = {
+        "B": B, "generate_s": t1 - t0, "two_solves_end_to_end_s": t3 - t2, "graphs_s": t4 - t3,
+        "samples_per_s": B / ((t1 - t0) + (t3 - t2) + (t4 - t3)), "graphs": len(graphs),
+        "info_nonzero": int((actual.info != 0).sum() + (prior.info != 0).sum())}
+    del graphs, actual, prior
+    gdata.feature_tensors_device(packed.take(np.arange(min(B, 256))), fixed, TaskType.REGRESSION, reorder=True)
+    torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    tensors = gdata.feature_tensors_device(packed, fixed, TaskType.REGRESSION, reorder=True)
+    torch.cuda.synchronize()
+    t6 = time.perf_counter()
+    host = {k: v.cpu() for k, v in tensors.items() if hasattr(v, "cpu") and k != "conn"}
+    t7 = time.perf_counter()
+    graphs = gdata.graphs_from_tensors(packed, {**host, "conn": tensors["conn"].cpu()})
+    t8 = time.perf_counter()
+    out["config5_device_features"] = {
+        "B": B, "generate_s": t1 - t0, "solves_and_features_on_device_s": t6 - t5, "download_float32_s": t7 - t6,
+        "graph_objects_s": t8 - t7,
+        "samples_per_s_tensors": B / ((t1 - t0) + (t6 - t5) + (t7 - t6)),
+        "samples_per_s_with_graph_objects": B / ((t1 - t0) + (t6 - t5) + (t8 - t6)),
+        "info_nonzero": int(host["info"].sum())}
 
 
 def main():
