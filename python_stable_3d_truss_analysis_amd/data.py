@@ -236,36 +236,61 @@ def feature_tensors_device(packed: PackedBatch, fixedMemberType, taskType, force
             "weight": weight, "conn": inp["conn"].long(), "info": info}
 
 
-def graphs_from_tensors(packed: PackedBatch, tensors, metapathType=MetapathType.NO_IMPLICIT, sources=None):
-    """One graph per truss whose tensors are SLICES of the batch feature tensors (host or device)."""
-    import torch
-    B, nMm = packed.B, packed.nM_max
-    conn = tensors["conn"]
-    joint_x, member_x, joint_y, member_y = (tensors[k] for k in ("joint_x", "member_x", "joint_y", "member_y"))
-    weight = tensors["weight"]
-    weight = weight.cpu().numpy() if hasattr(weight, "cpu") else weight
-    member_ids = torch.arange(nMm, device=conn.device).repeat_interleave(2).expand(B, -1)
-    j2m = torch.stack([conn.reshape(B, -1), member_ids], dim=1)
-    m2j = torch.flip(j2m, dims=[1])
-    graphs = []
-    for b in range(B):
+class GraphList:
+    """The graphs of a solved batch as a sequence: `len`, indexing, slicing and iteration like a list, but a
+    graph OBJECT (HeteroData when torch_geometric is importable) is only built when it is asked for - its
+    tensors are slices of the batch feature tensors (host or device), so building all graphs of a
+    100 000-sample batch up front would cost more Python time than the two solves and the feature kernel."""
+
+    def __init__(self, packed, tensors, metapathType, sources):
+        import torch
+        self.packed, self.tensors, self.metapathType, self.sources = packed, tensors, metapathType, sources
+        conn = tensors["conn"]
+        B, nMm = packed.B, packed.nM_max
+        member_ids = torch.arange(nMm, device=conn.device).repeat_interleave(2).expand(B, -1)
+        self._j2m = torch.stack([conn.reshape(B, -1), member_ids], dim=1)
+        self._m2j = torch.flip(self._j2m, dims=[1])
+        weight = tensors["weight"]
+        self._weight = weight.cpu().numpy() if hasattr(weight, "cpu") else weight
+
+    def __len__(self):
+        return self.packed.B
+
+    def __iter__(self):
+        return (self[b] for b in range(len(self)))
+
+    def __getitem__(self, b):
+        import torch
+        if isinstance(b, slice):
+            return [self[i] for i in range(*b.indices(len(self)))]
+        if b < 0:
+            b += len(self)
+        if not 0 <= b < len(self):
+            raise IndexError(b)
+        t, packed = self.tensors, self.packed
         nJ, nM = int(packed.nJ[b]), int(packed.nM[b])
         g = _new_graph()
-        g["src"] = None if sources is None else sources[b]
-        g["originWeight"] = float(weight[b])
-        g["joint"].x = joint_x[b, :nJ]
-        g["member"].x = member_x[b, :nM]
-        if joint_y is not None:
-            g["joint"].y = joint_y[b, :nJ]
-            g["member"].y = member_y[b, :nM]
-        g["joint", "j2m", "member"].edge_index = j2m[b, :, :2 * nM]
-        g["member", "m2j", "joint"].edge_index = m2j[b, :, :2 * nM]
-        if metapathType == MetapathType.USE_IMPLICIT:
+        g["src"] = None if self.sources is None else self.sources[b]
+        g["originWeight"] = float(self._weight[b])
+        g["joint"].x = t["joint_x"][b, :nJ]
+        g["member"].x = t["member_x"][b, :nM]
+        if t["joint_y"] is not None:
+            g["joint"].y = t["joint_y"][b, :nJ]
+            g["member"].y = t["member_y"][b, :nM]
+        g["joint", "j2m", "member"].edge_index = self._j2m[b, :, :2 * nM]
+        g["member", "m2j", "joint"].edge_index = self._m2j[b, :, :2 * nM]
+        if self.metapathType == MetapathType.USE_IMPLICIT:
             jj, mm = _implicit_edges(packed.conn[b, :nM], nJ, nM)
-            g["joint", "j2j", "joint"].edge_index = torch.from_numpy(jj).to(conn.device)
-            g["member", "m2m", "member"].edge_index = torch.from_numpy(mm).to(conn.device)
-        graphs.append(g)
-    return graphs
+            dev = t["conn"].device
+            g["joint", "j2j", "joint"].edge_index = torch.from_numpy(jj).to(dev)
+            g["member", "m2m", "member"].edge_index = torch.from_numpy(mm).to(dev)
+        return g
+
+
+def graphs_from_tensors(packed: PackedBatch, tensors, metapathType=MetapathType.NO_IMPLICIT, sources=None):
+    """One graph per truss whose tensors are SLICES of the batch feature tensors (host or device), as a
+    lazily materialised sequence (`GraphList`; `list(...)` builds every graph object)."""
+    return GraphList(packed, tensors, metapathType, sources)
 
 
 def hetero_tensors_batch(packed: PackedBatch, actual: BatchResult, prior: BatchResult, fixedArea,
