@@ -650,7 +650,12 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
                 const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
                 const unsigned vo = S.lane_off(s >= smin[v]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[v][s][r] = S.load_at(vo, o + r * (S.ld * 32));
+                for (int r = 0; r < 4; ++r)
+#ifdef TRS_EXP_NO_KLOADS
+                    acc[v][s][r] = 0.0 * (double)(o + (int)vo);
+#else
+                    acc[v][s][r] = S.load_at(vo, o + r * (S.ld * 32));
+#endif
             }
     }
     if (r0 > kstart) {
@@ -678,7 +683,12 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
             for (int d = 0; d < DEPTHN; ++d) {
                 const int nd = (d + DEPTHN - 1) % DEPTHN;
 #pragma unroll
-                for (int s = 0; s < CT; ++s) fb[nd][s] = S.load(ob + (d + DEPTHN - 1) * step + 128 * s);
+                for (int s = 0; s < CT; ++s)
+#ifdef TRS_EXP_NO_IFB      // timing experiment only (wrong results): the items' block-side fragment loads
+                    fb[nd][s] = 0.0 * (double)(ob + s);
+#else
+                    fb[nd][s] = S.load(ob + (d + DEPTHN - 1) * step + 128 * s);
+#endif
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
                     fa[nd][v] = aload(oa + (d + DEPTHN - 1) * step, v, k0 + 4 * (d + DEPTHN - 1));
@@ -820,7 +830,12 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
 #pragma unroll
             for (int u = 0; u < CT; ++u)
 #pragma unroll
-                for (int s = 0; s <= u; ++s) tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+                for (int s = 0; s <= u; ++s)
+#ifdef TRS_EXP_NO_KLOADS   // timing experiment only (wrong results): the stiffness tile loads
+                    for (int r = 0; r < 4; ++r) t[u][s][r] = (u == s && (lane >> 4) + 4 * r == (lane & 15)) ? 1e6 : 0.0;
+#else
+                    tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+#endif
 #pragma unroll
             for (int s = 0; s < CT; ++s) ytile_load(y[s], Y, r0 + 16 * s);
         }
@@ -834,7 +849,11 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
             auto yload = [&](int off) { return Y.load(off); };
             double fb[DEPTHN][CT], fy[DEPTHN];
             auto bload = [&](int off, int c, int k) {  // zero where chunk c is left of its envelope
+#ifdef TRS_EXP_NO_DLOADS   // timing experiment only (wrong results): what the block update's re-reads cost
+                return 0.0 * (double)(off + c + k);
+#else
                 return S.load_at(S.lane_off(k >= bks[c]), off + 128 * c);
+#endif
             };
 #pragma unroll
             for (int d = 0; d < DEPTHN - 1; ++d) {
@@ -876,7 +895,12 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
 #pragma unroll
         for (int s = 0; s < CT; ++s) {
             if (bad_col == 0) {
+#ifdef TRS_EXP_NO_CHOL16   // timing experiment only (wrong results): the serial 16x16 factorisations
+                Chol16 f{t[s][s], -1};
+                for (int r = 0; r < 4; ++r) Wl[s * 256 + r * 64 + lane] = ((lane >> 4) + 4 * r == (lane & 15)) ? 1.0 : 0.0;
+#else
                 const Chol16 f = chol16_invert(t[s][s], sc, Wl + s * 256);
+#endif
                 t[s][s] = f.u;
                 __builtin_amdgcn_wave_barrier();
                 if (f.bad >= 0) bad_col = r0 + 16 * s + f.bad + 1;
