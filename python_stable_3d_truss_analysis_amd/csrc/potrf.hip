@@ -86,7 +86,7 @@ struct PanelLds {
     // wave: T[half][t_idx(u,s)].  Once the factor wave holds them in registers the same memory is
     // reused for the operand fragments it produces (the D waves write T again only after the
     // panel's closing barrier):
-    //   W(s)   = T[0][s]      inv(L_ss) as MFMA A-fragments: [r*64 + lane] = inv(L_ss)[lane & 15][4 r + (lane >> 4)]
+    //   W(s)   = T[0][s]      inv(L_ss) as MFMA A-fragments, swizzled (wfrag_index / wfrag_lane, trs_chol16.h)
     //   Lf(i)  = T[0][4 + i]  L_{u,s} (u > s), i = lf_idx(u,s): the D-form registers of the tile
     //                          (rows of tile u, columns of tile s) = its A-fragments
     double T[2][10][256];
@@ -241,7 +241,7 @@ __device__ __forceinline__ void factor_block(const Slab& S, const int r0, PanelL
         if (ok) {
             double wf[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) wf[r] = sm.W(s)[r * 64 + lane];
+            for (int r = 0; r < 4; ++r) wf[r] = sm.W(s)[wfrag_lane(r, lane)];
 #pragma unroll
             for (int u = s + 1; u < CT; ++u) {
                 d4 x = d4{0.0, 0.0, 0.0, 0.0};
@@ -347,7 +347,7 @@ __device__ __forceinline__ void panel_item(const Slab& S, const int r0, const in
     for (int s = 0; s < CT; ++s) {
         double wf[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wf[r] = sm.W(s)[r * 64 + lane];
+        for (int r = 0; r < 4; ++r) wf[r] = sm.W(s)[wfrag_lane(r, lane)];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {  // X_s^T = inv(L_ss) T_s^T
             d4 x = d4{0.0, 0.0, 0.0, 0.0};
@@ -709,7 +709,7 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
             if (s >= smin[v]) {
                 d4 x = d4{0.0, 0.0, 0.0, 0.0};  // X_s^T = inv(L_ss) T_s^T
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + r * 64 + lane], acc[v][s][r], x);
+                for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + wfrag_lane(r, lane)], acc[v][s][r], x);
                 acc[v][s] = x;
 #pragma unroll
                 for (int s2 = s + 1; s2 < CT; ++s2)  // T_{s2}^T -= L_{s2,s} X_s^T
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
             if (bad_col == 0) {
 #ifdef TRS_EXP_NO_CHOL16   // timing experiment only (wrong results): the serial 16x16 factorisations
                 Chol16 f{t[s][s], -1};
-                for (int r = 0; r < 4; ++r) Wl[s * 256 + r * 64 + lane] = ((lane >> 4) + 4 * r == (lane & 15)) ? 1.0 : 0.0;
+                for (int r = 0; r < 4; ++r) Wl[s * 256 + wfrag_lane(r, lane)] = ((lane >> 4) + 4 * r == (lane & 15)) ? 1.0 : 0.0;
 #else
                 const Chol16 f = chol16_invert(t[s][s], sc, Wl + s * 256);
 #endif
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
                 if (s + 1 < CT) {
                     double wf[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) wf[r] = Wl[s * 256 + r * 64 + lane];
+                    for (int r = 0; r < 4; ++r) wf[r] = Wl[s * 256 + wfrag_lane(r, lane)];
 #pragma unroll
                     for (int u = s + 1; u < CT; ++u) {
                         d4 x = d4{0.0, 0.0, 0.0, 0.0};
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
         for (int s = 0; s < CT; ++s) {
             d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + r * 64 + lane], y[s][r], x);
+            for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + wfrag_lane(r, lane)], y[s][r], x);
             y[s] = x;
 #pragma unroll
             for (int s2 = s + 1; s2 < CT; ++s2)

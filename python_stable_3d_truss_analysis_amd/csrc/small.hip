@@ -288,7 +288,7 @@ __global__ __launch_bounds__(SNT) void trs_solve_small_kernel(const SmallArgs a)
             const int k = tid & 15;
             double wk[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) wk[c] = c <= k ? invw[(c >> 2) * 64 + (c & 3) * 16 + k] : 0.0;
+            for (int c = 0; c < 16; ++c) wk[c] = c <= k ? invw[wfrag_index(k, c)] : 0.0;
             for (int rr = tid >> 4; rr < rows_below; rr += SNT / 16) {
                 const int i = 16 * (J + 1) + rr;
                 double* row = i < 16 * nb ? Kb + sm_base(i >> 4) + (i & 15) * sm_width(i >> 4) : Kb + yrow;

@@ -35,8 +35,24 @@ __device__ __forceinline__ d4 mfma_f64_negA(double a, double b, d4 c) {
 //   sc      : LDS scratch (block gather)
 //   wfrag   : receives inv(L) as A-fragments (layout of PanelLds::W[s])
 // Returns the tile and the 0-based index of the first non-positive pivot, or -1 (wave-uniform).
+// inv(L_ss) as MFMA A-fragments in LDS: element W[t][c] (row t, column c of the 16 x 16 inverse) belongs to
+// lane (lq = c & 3, li = t) of k-step r = c >> 2.  Stored SWIZZLED, at r * 64 + lq * 16 + (li ^ c): the writers
+// (chol16_invert: 16 lanes of one quarter-wave hold 16 columns c of one row t) and the readers (a wave reads
+// k-step r: lanes (lq, li) = 64 consecutive doubles up to the XOR) then both touch every LDS bank once.
+// Unswizzled, the 16 writing lanes sit 32 dwords apart: a 16-way bank conflict on every store.
+#ifndef TRS_NO_WSWIZZLE
+__device__ __forceinline__ int wfrag_index(int t, int c) { return (c >> 2) * 64 + (c & 3) * 16 + (t ^ c); }
+// the same for the reading lane: index of this lane's element of k-step r
+__device__ __forceinline__ int wfrag_lane(int r, int lane) {
+    return r * 64 + (lane & 48) + ((lane & 15) ^ (4 * r + (lane >> 4)));
+}
+#else  // A/B builds: the plain layout of round 1
+__device__ __forceinline__ int wfrag_index(int t, int c) { return (c >> 2) * 64 + (c & 3) * 16 + t; }
+__device__ __forceinline__ int wfrag_lane(int r, int lane) { return r * 64 + lane; }
+#endif
+
 struct ChScratch {
-    double G[16][4];  // G[row][q] = T[row][4 b + q] of the running block
+    double G[4][16];  // G[q][row] = T[row][4 b + q] of the running block (conflict-free both ways)
 };
 struct Chol16 {
     d4 u;
@@ -68,11 +84,11 @@ static __device__ __noinline__ Chol16 chol16_invert_lds(d4 t, lds_f64* G, lds_f6
     for (int b = 0; b < 4; ++b) {
         const int j0 = 4 * b;
         // row-owner copy of the block's 4 columns (by symmetry row j0+q of the D-form tile)
-        G[4 * li + lq] = t[b];
+        G[16 * lq + li] = t[b];
         __builtin_amdgcn_wave_barrier();
         double c[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) c[q] = G[4 * li + q];
+        for (int q = 0; q < 4; ++q) c[q] = G[16 * q + li];
         __builtin_amdgcn_wave_barrier();
         double rinv[4], m[4][4];  // wave-uniform: 1 / L[j0+q][j0+q], L[j0+q2][j0+q]
 #pragma unroll
@@ -101,9 +117,9 @@ static __device__ __noinline__ Chol16 chol16_invert_lds(d4 t, lds_f64* G, lds_f6
         const double e01 = (li & 1) ? e1 : e0, e23 = (li & 1) ? e3 : e2;
         const double ma = (li >> 2) == b ? ((li & 2) ? e23 : e01) : 0.0;
         const d4 wb = mfma_f64(ma, R[b], zero);  // register b = W[j0+lq][li], the others are zero
-        // A-fragment layout of PanelLds::W: wfrag[r*64 + lane'] = W[t = li'][c = 4 r + lq']; the element
+        // A-fragment layout of PanelLds::W (swizzled, wfrag_index above): the element
         // (t = j0+lq, c = li) held here lands at 16 li + j0 + lq
-        wfrag[16 * li + j0 + lq] = wb[b];
+        wfrag[wfrag_index(j0 + lq, li)] = wb[b];
         // result tile: U on and above the diagonal; the otherwise unused strictly-lower part carries
         // inv(L) (its diagonal is 1 / diag(U)) for the 16 x 16 steps of the back substitution
         u[b] = (j0 + lq <= li) ? p : wb[b];
