@@ -337,7 +337,8 @@ def main():
     # reference point outside the timed region (rank 0): the same kernels with the envelope switched
     # off, i.e. the dense factorisation that SURVEY section 8d's FLOP figure describes
     dense_ms = None
-    if rank == 0 and not args.dense and not args.no_dense_ref:
+    # (the informational legs below run at N = 1 only: at N > 1 they would only keep the other ranks waiting)
+    if world == 1 and not args.dense and not args.no_dense_ref:
         dense = batch.DeviceBatch(packed, device, use_envelope=False)
         dense.solve(); torch.cuda.synchronize(device)
         dense.dofmap(); dense.assemble()
@@ -349,7 +350,7 @@ def main():
     # informational: the same step fed from / drained to page-locked host memory over PCIe, upload of the
     # next batch, solve and download of the previous one overlapped on three streams (batch.StreamedSolver)
     pcie = None
-    if rank == 0 and not args.no_pcie:
+    if world == 1 and not args.no_pcie:
         pipe = batch.StreamedSolver(packed, device, slots=2, use_envelope=not args.dense)
         src = pipe.host_in[0]
         for _ in range(3):          # warm-up: first use of the page-locked buffers, allocator, clocks
@@ -480,7 +481,7 @@ def main():
         }
         if pcie is not None:
             line["pcie_inclusive"] = pcie
-        if args.cube_batch > 0:
+        if args.cube_batch > 0 and world == 1:
             del dev
             torch.cuda.empty_cache()
             try:
@@ -493,7 +494,7 @@ def main():
                 "achieved_tflops": dense_flops * args.batch / (dense_ms * 1e-3) / 1e12,
                 "frac_of_peak": dense_flops * args.batch / (dense_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                 "note": "same kernel with the envelope off: n^3/3 + n^2 FLOP per truss (SURVEY 8d)"}
-        if not args.no_cpu_baseline:  # the oracle leg: CPU baseline + check of the GPU result against it
+        if not args.no_cpu_baseline and world == 1:  # the oracle leg (rank 0 at N = 1 only): CPU baseline + check
             line["cpu_baseline"], ref = cpu_baseline(data, args.cpu_seconds)
             if cpu_all is not None:
                 line["cpu_baseline_all_cores"] = cpu_all
