@@ -955,8 +955,9 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
         for (int c0 = 4 * panel + CT; c0 <= lastq;) {
             const int ks = 16 * env.ft[c0];
             const int left = lastq - c0 + 1;
-            if (RSN >= 4 && left >= 4) {
-                narrow_item<(RSN >= 4 ? 4 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
+            constexpr int RSK = FUSED && RSN > 2 ? 2 : RSN;  // the fused form's image holds an item of two chunks
+            if (RSK >= 4 && left >= 4) {
+                narrow_item<(RSK >= 4 ? 4 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
                 c0 += 4;
             } else if (RSN >= 2 && left >= 2) {
                 narrow_item<(RSN >= 2 ? 2 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
