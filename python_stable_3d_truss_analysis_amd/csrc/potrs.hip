@@ -36,11 +36,13 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
                                                         const size_t slab_stride,
                                                         double* __restrict__ uf, const int ld_uf,
                                                         const int* __restrict__ env_all,
-                                                        const int n_pad_max) {
+                                                        const int n_pad_max, const int skip_narrow) {
     extern __shared__ double sh[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npad = trs_round_up(n_free[b], TRS_NB);
     if (npad == 0) return;
+    // narrow envelopes are substituted by trs_potrs_narrow_kernel (one wave per matrix)
+    if (skip_narrow && env_all != nullptr && trs_env_is_narrow(trs_env_of(env_all, b, n_pad_max))) return;
     double* us = sh;                  // [npad] solution
     double* Ub = sh + npad;           // [64][65] diagonal block
     double* tb = Ub + BS * (BS + 1);  // [64] right-hand side of the block
@@ -79,7 +81,12 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
                 const int c0 = cb + BS * (p + 1) + 16 * k;
                 if (c0 < col_end) {  // uniform: the envelope ends on a 16-column boundary
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) ov[p][4 * q + k] = rows[(size_t)q * ld + c0 + l];
+                    for (int q = 0; q < 4; ++q)
+#ifdef TRS_EXP_POTRS_NOLOAD   // timing experiment only (wrong results): no off-diagonal streaming
+                        ov[p][4 * q + k] = 1e-30 * (double)(c0 + q);
+#else
+                        ov[p][4 * q + k] = rows[(size_t)q * ld + c0 + l];
+#endif
                 }
             }
     };
@@ -125,7 +132,12 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
         }
         if (cb >= BS) request(cb - BS);  // in flight during the triangle solve
         __syncthreads();
+#ifdef TRS_EXP_POTRS_NOTRI   // timing experiment only (wrong results): no triangle solve
+        if (wave == 0) us[cb + lane] = tb[lane];
+        if (false) {
+#else
         if (wave == 0 && TILESTEP) {
+#endif
             // Back substitution inside the 64 x 64 triangle in four 16 x 16 steps.  trs_potrf left the
             // strictly-lower part of inv(L_ss) below the diagonal of every diagonal tile, so a step is
             // u_s = inv(L_ss)^T t_s (a 16 x 16 product spread over the four quarter-waves) followed by
@@ -180,6 +192,90 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
     for (int c = tid; c < npad && c < ld_uf; c += 256) out[c] = us[c];
 }
 
+// ======================================================================================================
+// Narrow envelopes: one WAVE per matrix, four matrices per work-group, no work-group barriers.
+// With an envelope of a few tiles per 16-row chunk the work-group kernel above spends its time in
+// barriers and in the serial triangle solve of one wave while three wait; here 12 matrices per CU run
+// independently, each streaming its own tiles: chunk s (16 rows, from the bottom) is
+//   t_s = y_s - sum_{q > s} U[s, q] u_q      tiles (s, q) as D-form registers (lane li = column), the
+//                                            products accumulated per lane, ONE 16-lane reduction per chunk
+//   u_s = inv(L_ss)^T t_s                    with the inverse trs_potrf left below the diagonal of the tile
+// The solution lives in the wave's LDS strip (it starts as y).
+// ======================================================================================================
+constexpr int PMW = 4;    // matrices (waves) per work-group
+constexpr int PTG = 4;    // tiles in flight per group of loads
+__global__ __launch_bounds__(64 * PMW, 3) void trs_potrs_narrow_kernel(
+    const double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
+    double* __restrict__ uf, const int ld_uf, const int* __restrict__ env_all, const int n_pad_max, const int B) {
+    extern __shared__ double sh[];  // [PMW][n_pad_max]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.x * PMW + wave;
+    if (b >= B) return;
+    const int npad = trs_round_up(n_free[b], TRS_NB);
+    if (npad == 0) return;
+    const TrsEnv env = trs_env_of(env_all, b, n_pad_max);
+    if (!trs_env_is_narrow(env)) return;  // trs_potrs_kernel's matrix
+    double* us = sh + (size_t)wave * n_pad_max;
+    double* ub = uf + (size_t)b * ld_uf;
+    for (int c = lane; c < npad; c += 64) us[c] = ub[c];  // y = L^-1 f
+    __builtin_amdgcn_wave_barrier();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(S_all) + (size_t)b * slab_stride, 0, (int)(slab_stride * sizeof(double)), 0x00020000);
+    const unsigned loff = ((unsigned)lq * (unsigned)ld + (unsigned)li) * 8u;
+    const int rstep = ld * 32;  // four slab rows, bytes
+    auto tile = [&](d4& a, int c0, int i0, bool exists) {  // D-form tile; outside the envelope: zeros, no traffic
+        const unsigned vo = exists ? loff : 0x80000000u;
+        const int o = (c0 * ld + i0) * 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            a[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, o + r * rstep, 0));
+    };
+    // does this lane hold the diagonal entry of its column (row lq + 4 r == li), and in which register
+    const bool has_diag = li >= lq && ((li - lq) & 3) == 0;
+    const int rdiag = (li - lq) >> 2;
+    for (int s = npad / 16 - 1; s >= 0; --s) {
+        const int ce = env.cend[s];
+        d4 dg;
+        tile(dg, 16 * s, 16 * s, true);
+        d4 part = {0.0, 0.0, 0.0, 0.0};
+        for (int q0 = s + 1; q0 < ce; q0 += PTG) {
+            d4 a[PTG];
+#pragma unroll
+            for (int g = 0; g < PTG; ++g) tile(a[g], 16 * s, 16 * (q0 + g), q0 + g < ce);
+#pragma unroll
+            for (int g = 0; g < PTG; ++g) {
+                const double uq = q0 + g < ce ? us[16 * (q0 + g) + li] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[r] += a[g][r] * uq;
+            }
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[r] += __shfl_xor(part[r], off);
+        // t[c] for the rows c = lq + 4 r; u_s[li] = t[li] / U[li][li] + sum_{c > li} inv(L)[c][li] t[c]
+        double val = 0.0;
+        double ddiag = 1.0, tdiag = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double t = us[16 * s + lq + 4 * r] - part[r];
+            val += (lq + 4 * r > li ? dg[r] : 0.0) * t;
+            if (has_diag && rdiag == r) {
+                ddiag = dg[r];
+                tdiag = t;
+            }
+        }
+        val += tdiag / ddiag;  // (lanes without the diagonal entry add 0 / 1)
+        val += __shfl_xor(val, 16);
+        val += __shfl_xor(val, 32);
+        __builtin_amdgcn_wave_barrier();
+        if (lq == 0) us[16 * s + li] = val;
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int c = lane; c < npad && c < ld_uf; c += 64) ub[c] = us[c];
+}
+
 }  // namespace
 
 extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
@@ -192,13 +288,25 @@ extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_st
         (int)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) |
         (int)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) |
+        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrs_narrow_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)lds_limit_set;
+    // narrow envelopes: one wave per matrix, while the solution strips of four matrices fit 64 KB of LDS
+    // (and the slab fits the 31-bit offsets of a buffer descriptor, as in trs_potrf_batched)
+    const size_t lds_narrow = (size_t)PMW * n_pad_max * sizeof(double);
+    const int narrow = env != nullptr && lds_narrow <= 64 * 1024 && slab_stride * sizeof(double) < ((size_t)1 << 31);
+    if (narrow) {
+        hipLaunchKernelGGL(trs_potrs_narrow_kernel, dim3((B + PMW - 1) / PMW), dim3(64 * PMW), lds_narrow, stream, S,
+                           n_free, ld, slab_stride, uf, ld_uf, env, n_pad_max, B);
+        const int rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
     if (env != nullptr)
         hipLaunchKernelGGL(trs_potrs_kernel<true>, dim3(B), dim3(256), lds, stream, S, n_free, ld,
-                           slab_stride, uf, ld_uf, env, n_pad_max);
+                           slab_stride, uf, ld_uf, env, n_pad_max, narrow);
     else
         hipLaunchKernelGGL(trs_potrs_kernel<false>, dim3(B), dim3(256), lds, stream, S, n_free, ld,
-                           slab_stride, uf, ld_uf, env, n_pad_max);
+                           slab_stride, uf, ld_uf, env, n_pad_max, 0);
     return (int)hipGetLastError();
 }
