@@ -423,6 +423,9 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         return;
     }
 
+#ifdef TRS_EXP_ASM_NOPHASE1  // timing experiment only (wrong results): phase 0 and the envelope only
+    return;
+#endif
     // ---- phase 1 ---------------------------------------------------------------------------------------
     const bool with_col = !(has_env && wgflag[1] != 0);  // the 16-wide load-column chunk rides in the slab
     if (!with_col) {
@@ -462,6 +465,9 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         pdeg = 0;
         const int c = c0 + rr;
         if (c >= n) return;
+#ifdef TRS_EXP_ASM_NOWALK   // timing experiment only (wrong results): no adjacency walk in the row loop
+        return;
+#endif
         const int dof = rowdof[c];
         const int a = dof / 3, r = dof - 3 * a;
         if (e_first == TPR - 1) {
