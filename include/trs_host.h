@@ -33,7 +33,9 @@ int trs_cubegen(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num
                 const double *force_range /* [3][2] */, int nforce_lo, int nforce_hi,
                 const double *mtypes /* [n_types][3] = (a, e, density) */, int n_types, int nJ_max,
                 int nM_max, double *xyz, int32_t *conn, double *E, double *A, double *rho,
-                uint8_t *cbits, double *loads, int32_t *nJ, int32_t *nM, int64_t *retries_out);
+                uint8_t *cbits, double *loads, int32_t *nJ, int32_t *nM, int64_t *retries_out,
+                int64_t first_index /* global index of truss 0: the stream of truss b is keyed by
+                                       (seed, first_index + b), so chunks / shards of one dataset agree */);
 
 /* Reverse Cuthill-McKee order of the joints of every truss: perm[b][k] = old id of the joint that
  * becomes joint k (identity on the padding).  Returns 0 or -2 on allocation failure. */

@@ -226,7 +226,8 @@ int trs_cubegen(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num
                 const double *force_range /* [3][2] */, int nforce_lo, int nforce_hi,
                 const double *mtypes /* [n_types][3] = (a, e, density) */, int n_types, int nJ_max,
                 int nM_max, double *xyz, int32_t *conn, double *E, double *A, double *rho,
-                uint8_t *cbits, double *loads, int32_t *nJ, int32_t *nM, int64_t *retries_out) {
+                uint8_t *cbits, double *loads, int32_t *nJ, int32_t *nM, int64_t *retries_out,
+                int64_t first_index) {
     const int ncell = gx * gy * gz, nvert = (gx + 1) * (gy + 1) * (gz + 1);
     int cap = 64;
     while (cap < 64 * ncell) cap <<= 1; /* >= 2x the 24 pairs per cube */
@@ -267,10 +268,11 @@ int trs_cubegen(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num
         for (int b = 0; b < B; ++b) {
             if (!ok || rc != 0) continue;
             rng_t rng;
-            /* Per-truss stream: the initial state is a HASH of (seed, b).  (An affine function of b with
+            /* Per-truss stream: the initial state is a HASH of (seed, global index of the truss = first_index + b),
+             * so a dataset generated in chunks or shards is the same dataset.  (An affine function of b with
              * the generator's own increment as the factor would make truss b+1's stream truss b's
              * shifted by one draw.) */
-            rng.s = mix64(mix64(seed + 0x632be59bd9b4e019ULL) ^ mix64((uint64_t)b + 1));
+            rng.s = mix64(mix64(seed + 0x632be59bd9b4e019ULL) ^ mix64((uint64_t)first_index + (uint64_t)b + 1));
             for (;;) {
                 double len[3];
                 for (int a = 0; a < 3; ++a) len[a] = rng_uniform(&rng, len_lo, len_hi);

@@ -371,6 +371,27 @@ def _dense_from_truss(truss):
     return BatchResult(u, f, n, np.zeros([1], dtype=np.int32))
 
 
+def dataset_chunks(n_samples, rank=0, world=1, chunk=16384, seed=0, numCubeRange=(8, 190), gridRange=(6, 6, 6),
+                   fixedMemberType=None, taskType=TaskType.OPTIMIZATION, forceScale=1., displaceScale=1.,
+                   positionScale=1., device=None, reorder=True, **generator_args):
+    """BASELINE config 5 as a generator: this rank's share of a dataset of `n_samples` random cube trusses,
+    chunk by chunk - native generation (`generate_cube_batch`), both solves and the feature kernel on
+    `device` (`feature_tensors_device`).  Yields `(first_index, packed, tensors)`; nothing larger than one
+    chunk is ever held on the host.  The dataset is DEFINED by (seed, global sample index): any split into
+    ranks and chunks produces the same samples (rank r owns the chunks r, r + world, ...).  One process per
+    GPU, no communication: run it under `torchrun` with rank / world from the environment, or in a loop."""
+    from .generate import generate_cube_batch
+    n_chunks = (int(n_samples) + chunk - 1) // chunk
+    for k in range(rank, n_chunks, world):
+        first = k * chunk
+        count = min(chunk, int(n_samples) - first)
+        sizes = np.random.default_rng([int(seed), k]).integers(numCubeRange[0], numCubeRange[1] + 1, size=chunk)[:count]
+        packed = generate_cube_batch(sizes, gridRange=gridRange, seed=seed, first_index=first, **generator_args)
+        tensors = feature_tensors_device(packed, fixedMemberType, taskType, forceScale, displaceScale,
+                                         positionScale, device, reorder)
+        yield first, packed, tensors
+
+
 class TrussHeteroDataCreator:
     """Reference-compatible front end (`data.py:11-44`)."""
 

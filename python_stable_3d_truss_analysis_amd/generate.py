@@ -32,7 +32,7 @@ def _load():
         P, I, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
         lib.trs_cubegen.restype = I
         lib.trs_cubegen.argtypes = [I, ctypes.c_uint64, I, I, I, P, I, I, I, D, D, P, I, I, P, I, I, I,
-                                    P, P, P, P, P, P, P, P, P, P]
+                                    P, P, P, P, P, P, P, P, P, P, ctypes.c_int64]
         lib.trs_cubegen_bounds.restype = I
         lib.trs_cubegen_bounds.argtypes = [I, I, I, I, I, P, P]
         _gen = lib
@@ -57,11 +57,13 @@ def generate_cube_batch(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 150),
                         forceRange=((-30000, 30000), (-30000, 30000), (-30000, 30000)),
                         nForceRange=None, method=GenerateMethod.Random, linkType=LinkType.Random,
                         memberTypes=((1., 1e7, 0.1),), isAllowParallel=False, seed=0,
-                        return_retries=False, isAddPinSupport=True):
+                        return_retries=False, isAddPinSupport=True, first_index=0):
     """One cube truss per entry of `num_cubes` (polycube sizes), as a `PackedBatch`.
 
     Arguments as the reference's `GenerateRandomCubeTrusses` (`generate.py:314-316`).  With
-    `isAddPinSupport=False` no joint is supported (an augmenter is expected to add supports)."""
+    `isAddPinSupport=False` no joint is supported (an augmenter is expected to add supports).
+    Truss b draws from a stream keyed by (seed, first_index + b): generating a dataset in chunks or
+    shards (`first_index` = global index of the chunk's first truss) gives the same trusses."""
     lib = _load()
     num_cubes = np.ascontiguousarray(num_cubes, dtype=np.int32).ravel()
     B = len(num_cubes)
@@ -83,7 +85,8 @@ def generate_cube_batch(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 150),
                              float(lengthRange[0]),
                              float(lengthRange[1]), ptr(frange), lo, hi, ptr(table), len(table), nJ_max,
                              nM_max, ptr(xyz), ptr(conn), ptr(E), ptr(A), ptr(rho), ptr(cbits), ptr(loads),
-                             ptr(nJ), ptr(nM), ctypes.cast(ctypes.byref(retries), ctypes.c_void_p))
+                             ptr(nJ), ptr(nM), ctypes.cast(ctypes.byref(retries), ctypes.c_void_p),
+                             int(first_index))
         if rc != 0:
             raise RuntimeError(f"trs_cubegen failed ({rc})")
 

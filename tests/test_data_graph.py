@@ -196,3 +196,31 @@ def test_bar25_through_the_device_feature_path_matches_the_reference_capture(gol
             np.testing.assert_allclose(t["joint_y"][0].cpu().numpy(), z[f"{tag}_noimp/joint/y"], rtol=1e-6, atol=1e-7)
             np.testing.assert_allclose(t["member_y"][0].cpu().numpy(), z[f"{tag}_noimp/member/y"], rtol=1e-6, atol=1e-7)
         assert float(t["weight"][0]) == pytest.approx(float(z[f"{tag}_noimp/originWeight"]), rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_dataset_chunks_sharding_is_invariant():
+    """`data.dataset_chunks` (config 5 as a per-rank generator): the samples of two ranks interleaved are
+    the samples of one rank, bit for bit (features included), whatever the chunking."""
+    import torch
+    kw = dict(seed=5, numCubeRange=(3, 12), gridRange=(4, 4, 4), fixedMemberType=FIXED,
+              taskType=TaskType.REGRESSION, memberTypes=[[1., 1e7, 0.1], [2., 2e7, 0.2]], **SCALES)
+    single = {first: (p, t) for first, p, t in data.dataset_chunks(700, chunk=256, **kw)}
+    assert sorted(single) == [0, 256, 512] and single[512][0].B == 700 - 512
+    seen = {}
+    for rank in range(2):
+        for first, p, t in data.dataset_chunks(700, rank=rank, world=2, chunk=256, **kw):
+            seen[first] = (p, t)
+    assert sorted(seen) == sorted(single)
+    for first in single:
+        p0, t0 = single[first]
+        p1, t1 = seen[first]
+        np.testing.assert_array_equal(p0.xyz, p1.xyz)
+        assert not t0["info"].any()
+        for key in ("joint_x", "member_x", "joint_y", "member_y"):
+            assert torch.equal(t0[key], t1[key])
+    # other chunk size: same samples (compare the first 128 of the dataset)
+    first, p, t = next(iter(data.dataset_chunks(700, chunk=128, **kw)))
+    np.testing.assert_array_equal(p.nM, single[0][0].nM[:128])
+    nJ = int(p.nJ.max())
+    np.testing.assert_array_equal(p.xyz[:, :nJ], single[0][0].xyz[:128, :nJ])

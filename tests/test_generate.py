@@ -219,3 +219,17 @@ def test_truss_whose_assembly_tables_exceed_the_lds_on_gpu():
         assert H.max_scaled_err(res.displace[0, :nJ], ref["u"]) <= 1e-8
         assert H.max_scaled_err(res.internal[0, :nM], ref["N"]) <= 1e-8
         assert H.max_scaled_err(res.external[0, :nJ], ref["f_ext"]) <= 1e-8
+
+
+def test_chunks_and_shards_of_a_dataset_are_the_same_dataset():
+    """Truss b's stream is keyed by (seed, first_index + b): one call for 40 trusses equals four calls for
+    10 with the matching offsets (the basis of data.dataset_chunks: config 5 sharded over GPUs)."""
+    sizes = np.random.default_rng(1).integers(3, 30, size=40)
+    whole = gen.generate_cube_batch(sizes, gridRange=(4, 4, 4), seed=21)
+    for k in range(4):
+        part = gen.generate_cube_batch(sizes[10 * k: 10 * k + 10], gridRange=(4, 4, 4), seed=21, first_index=10 * k)
+        ref = whole.take(np.arange(10 * k, 10 * k + 10)).trimmed()
+        for f in part.__dataclass_fields__:
+            np.testing.assert_array_equal(getattr(part, f), getattr(ref, f), err_msg=f)
+    other = gen.generate_cube_batch(sizes[:10], gridRange=(4, 4, 4), seed=21, first_index=10)
+    assert not np.array_equal(other.xyz, whole.take(np.arange(10)).trimmed().xyz)
