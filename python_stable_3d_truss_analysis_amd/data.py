@@ -233,7 +233,7 @@ def feature_tensors_device(packed: PackedBatch, fixedMemberType, taskType, force
             torch.cuda.current_stream(dev).cuda_stream), "trs_graph_features_dev")
     info = torch.stack([actual.info, prior.info if prior is not None else torch.zeros_like(actual.info)])
     return {"joint_x": joint_x, "member_x": member_x, "joint_y": joint_y, "member_y": member_y,
-            "weight": weight, "conn": inp["conn"].long(), "info": info}
+            "weight": weight, "conn": inp["conn"], "info": info}
 
 
 class GraphList:
@@ -245,7 +245,7 @@ class GraphList:
     def __init__(self, packed, tensors, metapathType, sources):
         import torch
         self.packed, self.tensors, self.metapathType, self.sources = packed, tensors, metapathType, sources
-        conn = tensors["conn"]
+        conn = tensors["conn"].long()   # (int32 in the device tensors: a third of their download)
         B, nMm = packed.B, packed.nM_max
         member_ids = torch.arange(nMm, device=conn.device).repeat_interleave(2).expand(B, -1)
         self._j2m = torch.stack([conn.reshape(B, -1), member_ids], dim=1)

@@ -173,7 +173,7 @@ def test_device_feature_kernel_is_bit_identical_to_the_host_path():
                         continue
                     assert torch.equal(dev[key].cpu().view(torch.int32), host[key].view(torch.int32)), (key, task)
                 np.testing.assert_array_equal(dev["weight"].cpu().numpy(), host["weight"])
-                assert torch.equal(dev["conn"].cpu(), host["conn"])
+                assert torch.equal(dev["conn"].cpu().long(), host["conn"])
     graphs = data.dataset_graphs(batches[0], fixed, TaskType.REGRESSION, forceScale=1e3, reorder=True)
     g = graphs[3]
     assert g["joint"].x.is_cuda and tuple(g["member"].x.shape) == (int(batches[0].nM[3]), 10)
