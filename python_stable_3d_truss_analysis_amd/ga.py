@@ -142,7 +142,7 @@ class GA:
         dev = self._population_device(len(genes))
         count = len(genes)
         loci = torch.zeros([dev.B, dev.nM_max], dtype=torch.int64, device=dev.device)
-        loci[:count, :self.nMember] = torch.from_numpy(np.asarray(genes, dtype=np.int64)).to(dev.device)
+        loci[:count, :self.nMember] = torch.from_numpy(self._gene_matrix(genes)).to(dev.device)
         sections = self._typeTable[loci]                    # [B, nM, 3] = (a, e, density)
         dev.A.copy_(sections[..., 0]); dev.E.copy_(sections[..., 1]); dev.rho.copy_(sections[..., 2])
         # one kernel for solve + reductions on the fused small path; one download for everything
@@ -151,6 +151,19 @@ class GA:
         if terms[3].any():
             raise np.linalg.LinAlgError("Singular matrix")
         return self._compose_many(terms[0], terms[1], terms[2])
+
+    def _gene_matrix(self, genes):
+        """The population (list of lists of type indices, the reference's representation) as an int64
+        array [count, nMember].  `bytes()` of a gene is 8x faster than numpy's list-of-lists conversion,
+        which was three quarters of the wall time of a generation."""
+        if self.nType <= 256:
+            try:
+                flat = np.frombuffer(b"".join(map(bytes, genes)), dtype=np.uint8)
+                if flat.size == len(genes) * self.nMember:
+                    return flat.reshape(len(genes), self.nMember).astype(np.int64)
+            except (TypeError, ValueError):   # a gene that is not a list of small non-negative ints
+                pass
+        return np.asarray(genes, dtype=np.int64)
 
     def _compose_many(self, weight, stressViolation, displaceViolation):
         """`_compose` over arrays (same arithmetic, element by element)."""
@@ -170,7 +183,7 @@ class GA:
             self._table = np.array([[t.a, t.e, t.density] for t in self.typeList], dtype=np.float64)
         count = len(genes)
         pop = self._base.replicate(count)
-        sec = self._table[np.asarray(genes, dtype=np.int64)]          # [count, nMember, 3]
+        sec = self._table[self._gene_matrix(genes)]                    # [count, nMember, 3]
         pop.A[:, :self.nMember], pop.E[:, :self.nMember] = sec[..., 0], sec[..., 1]
         pop.rho[:, :self.nMember] = sec[..., 2]
         fit, info = self._pool.fitness(pop, self.allowStress, self.allowDisplace, geometry_key=id(self))
