@@ -590,7 +590,7 @@ __device__ __forceinline__ void krange_unscatter(const KLists& K, const RangeFet
 #define TRS_NARROW_DEPTH 2
 #endif
 #ifndef TRS_NARROW_WAVES_PER_SIMD
-#define TRS_NARROW_WAVES_PER_SIMD 2
+#define TRS_NARROW_WAVES_PER_SIMD 3   // 168 VGPRs: the slab form fits with two registers spilled
 #endif
 constexpr int RSN = TRS_NARROW_RS;      // row chunks per item in the narrow kernel (1, 2 or 4)
 constexpr int DEPTHN = TRS_NARROW_DEPTH;  // k-steps of fragments in flight (divides 4 k-steps = 16 columns)
@@ -746,8 +746,6 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
     const unsigned char* __restrict__ work, double* __restrict__ uf_all, const int ld_uf) {
     __shared__ ChScratch scratch[MPW];
     __shared__ double wlds[MPW][CT][256];  // per wave: inv(L_ss), s = 0..3, as A-fragments (PanelLds::W layout)
-    __shared__ double ylds[MPW][CT][4][4];  // per wave: the load column (lanes li == 0 of its tiles), parked
-                                          // during the factorisation
     __shared__ double kimg[FUSED ? MPW : 1][FUSED ? 512 : 1];  // per wave: image of an item's (up to two) stiffness
                                                                // tiles; the diagonal block's images use wlds
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -766,9 +764,15 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
                                              (int)(slab_stride * sizeof(double)), 0x00020000);
     S.ld = ld;
     S.loff = ((unsigned)(lane >> 4) * (unsigned)ld + (unsigned)(lane & 15)) * 8u;
-    LoadVec Y;
-    Y.rs = __builtin_amdgcn_make_buffer_rsrc(uf_all + (size_t)b * ld_uf, 0, ld_uf * (int)sizeof(double), 0x00020000);
-    Y.voff = (lane & 15) == 0 ? (unsigned)(lane >> 4) * 8u : Slab::gone;
+    // the load vector in uf: YR reads 16 consecutive entries (lane li, replicated over the quarter-waves),
+    // YRS stores them (quarter-wave 0 only), YK reads 4 consecutive entries (lane lq, replicated over li)
+    const int li = lane & 15, lq = lane >> 4;
+    LoadVec YR, YRS, YK;
+    YR.rs = YRS.rs = YK.rs =
+        __builtin_amdgcn_make_buffer_rsrc(uf_all + (size_t)b * ld_uf, 0, ld_uf * (int)sizeof(double), 0x00020000);
+    YR.voff = (unsigned)li * 8u;
+    YRS.voff = lq == 0 ? (unsigned)li * 8u : Slab::gone;
+    YK.voff = (unsigned)lq * 8u;
     KLists K{};
     if constexpr (FUSED) {
         const int* meta = env.last + n_pad_max / 64;  // slack | list offsets / 16 (written by trs_assemble)
@@ -795,13 +799,18 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
                              16 * env.ft[4 * panel + 3]};
         // D: the ten lower tiles of the diagonal block, and the load column's four tiles (L y = f rides
         // along as row n_pad: same k range and B-side fragments as the block, which are read once)
-        d4 t[CT][CT], y[CT];
+        // The load vector is ONE column: carried as four scalars per lane (yr[u] = entry of row li of block
+        // chunk u, replicated over the quarter-waves) and advanced with plain FMAs and lane reductions.
+        // As a 16-wide MFMA operand chunk (round 1) it cost 104 of the ~240 MFMAs of a panel, 15/16 of
+        // them on zero columns, on the FP64 datapath that the matrix core and the VALU share.
+        d4 t[CT][CT];
+        double yr[CT];
         int tb[CT] = {0, 0, 0, 0};  // first tile id of the panel's four slab chunks (FUSED)
         if constexpr (FUSED) {
 #pragma unroll
             for (int s = 0; s < CT; ++s) tb[s] = K.tbase[4 * panel + s];
 #pragma unroll
-            for (int s = 0; s < CT; ++s) ytile_load(y[s], Y, r0 + 16 * s);
+            for (int s = 0; s < CT; ++s) yr[s] = YR.load((r0 + 16 * s) * 8);
             // Column s of the diagonal block = tiles (slab chunk 4 panel + s, matrix rows chunk 4 panel + u),
             // u = s .. 3: ids tb[s] .. tb[s] + 3 - s, one entry range.  All four ranges are in flight before
             // the first image is formed.  (Requesting them a whole panel ahead was measured: no gain, 38
@@ -837,17 +846,18 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
                     tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
 #endif
 #pragma unroll
-            for (int s = 0; s < CT; ++s) ytile_load(y[s], Y, r0 + 16 * s);
+            for (int s = 0; s < CT; ++s) yr[s] = YR.load((r0 + 16 * s) * 8);
         }
         st.drain();
         st.mark(0);
         if (r0 > kd) {
             const int step = S.ld * 32;
             int ok = S.at(kd, r0);
-            int oy = kd * 8;   // rows kd .. of uf (32 bytes per k-step)
+            int oy = kd * 8;   // rows kd .. of uf (32 bytes per k-step): y of the earlier panels
             const int ystep = 32;
-            auto yload = [&](int off) { return Y.load(off); };
+            auto yload = [&](int off) { return YK.load(off); };   // lane (lq, *) <- y[k + lq]
             double fb[DEPTHN][CT], fy[DEPTHN];
+            double ys[CT] = {0.0, 0.0, 0.0, 0.0};  // sum_k L[row][k] y[k], partial over this lane's k = k0 + lq
             auto bload = [&](int off, int c, int k) {  // zero where chunk c is left of its envelope
 #ifdef TRS_EXP_NO_DLOADS   // timing experiment only (wrong results): what the block update's re-reads cost
                 return 0.0 * (double)(off + c + k);
@@ -877,20 +887,20 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
                         if (kk >= bks[u]) {
 #pragma unroll
                             for (int s = 0; s <= u; ++s) t[u][s] = mfma_f64_negA(fb[d][s], fb[d][u], t[u][s]);
-                            y[u] = mfma_f64_negA(fb[d][u], fy[d], y[u]);
+                            ys[u] = fma(fb[d][u], fy[d], ys[u]);
                         }
                 }
                 ok += DEPTHN * step;
                 oy += DEPTHN * ystep;
             }
+#pragma unroll
+            for (int u = 0; u < CT; ++u) {  // sum over the four quarter-waves (k = k0 + lq)
+                ys[u] += __shfl_xor(ys[u], 16);
+                ys[u] += __shfl_xor(ys[u], 32);
+                yr[u] -= ys[u];
+            }
         }
         st.mark(1);
-        // the load column's tiles wait in LDS while the block is factored (32 VGPRs less at the peak)
-#pragma unroll
-        for (int s = 0; s < CT; ++s)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)  // only column 0 of the 16-wide load chunk is not zero
-                if ((lane & 15) == 0) ylds[wave][s][r][lane >> 4] = y[s][r];
         // F: factor the block in registers; inv(L_ss) stays in LDS (operand fragments, read where used)
 #pragma unroll
         for (int s = 0; s < CT; ++s) {
@@ -932,22 +942,35 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
         for (int u = 0; u < CT; ++u)
 #pragma unroll
             for (int s = 0; s <= u; ++s) tile_store(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
-        // the load column against the factored block: y_s = inv(L_ss) (y_s - sum_{s'<s} L_{s,s'} y_s')
-#pragma unroll
-        for (int s = 0; s < CT; ++s)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[s][r] = (lane & 15) == 0 ? ylds[wave][s][r][lane >> 4] : 0.0;
+        // the load vector against the factored block: y_s = inv(L_ss) (y_s - sum_{s'<s} L_{s,s'} y_s').
+        // Both operands are A-fragments as they stand (lane (lq, li), k-step r <-> entry [row li][col 4 r + lq]):
+        // the vector goes into "column order" with four lane permutes, the products are per-lane FMAs and
+        // the sum over a row's four quarter-waves two lane reductions.
+        const int src0 = (lane & 48) | lq;  // lane holding the entry of row 4 r + lq: src0 + 4 r
 #pragma unroll
         for (int s = 0; s < CT; ++s) {
-            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+            double yk[4], acc = 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x = mfma_f64(Wl[s * 256 + wfrag_lane(r, lane)], y[s][r], x);
-            y[s] = x;
+            for (int r = 0; r < 4; ++r) yk[r] = __shfl(yr[s], src0 + 4 * r);
 #pragma unroll
-            for (int s2 = s + 1; s2 < CT; ++s2)
+            for (int r = 0; r < 4; ++r) acc = fma(Wl[s * 256 + wfrag_lane(r, lane)], yk[r], acc);
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            yr[s] = acc;
+            YRS.store((r0 + 16 * s) * 8, acc);  // later panels and trs_potrs read y from uf
+            if (s + 1 < CT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[s2] = mfma_f64_negA(t[s2][s][r], y[s][r], y[s2]);
-            ytile_store(y[s], Y, r0 + 16 * s);  // later panels and trs_potrs read y from uf
+                for (int r = 0; r < 4; ++r) yk[r] = __shfl(acc, src0 + 4 * r);
+#pragma unroll
+                for (int s2 = s + 1; s2 < CT; ++s2) {
+                    double part = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part = fma(t[s2][s][r], yk[r], part);
+                    part += __shfl_xor(part, 16);
+                    part += __shfl_xor(part, 32);
+                    yr[s2] -= part;
+                }
+            }
         }
         st.mark(3);
         // items: the chunks below the block that reach into this panel
