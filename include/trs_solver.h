@@ -107,7 +107,8 @@ int trs_assemble(int B, int nJ_max, int nM_max,
                  int ld, int slab_rows, double *S /* [B][slab_rows][ld] */, int flags,
                  void *work /* B * trs_assemble_work_bytes(...) */,
                  int32_t *env /* out, B * trs_env_ints(...), or NULL */,
-                 double *uf /* out [B][ld_uf]: the load vector of the trusses in compact form; NULL = slab form only */,
+                 double *uf /* out [B][ld_uf]: the load vector of every truss routed to a wave-per-matrix
+                               factorisation (narrow envelope); required with env, may be NULL without */,
                  int ld_uf, void *stream);
 
 /* Batched Cholesky factorisation with fused forward substitution of the right-hand-side

@@ -91,6 +91,8 @@ int trs_assemble(int B, int nJ_max, int nM_max, const double* xyz, const int32_t
     if (B < 0 || nJ_max <= 0 || nM_max < 0 || bad_slab(ld, slab_rows) || (B > 0 && !work))
         return (int)hipErrorInvalidValue;
     if (uf != nullptr && ld_uf < slab_rows) return (int)hipErrorInvalidValue;
+    // with envelope metadata the wave-per-matrix factorisation reads the load vector from uf
+    if (env != nullptr && uf == nullptr && B > 0) return (int)hipErrorInvalidValue;
     if (!g_compact) flags |= TRS_ASM_NO_COMPACT;
     return trs_assemble_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM,
                                ld, (size_t)slab_rows * ld, slab_rows, S, flags, work, env, uf, ld_uf,
