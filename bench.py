@@ -386,7 +386,8 @@ def main():
             slack = int(env[nchm + dev.rows // 64])
             narrow = (slack & 0xff) == 1   # the kernel choice recorded by trs_assemble (csrc/trs_common.h)
             compact = bool(slack & 0x100)  # K_ff as compact entry lists, tiles formed in the factorisation
-            potrf_kernel = ("trs_potrf_narrow_kernel<true>" if compact else "trs_potrf_narrow_kernel<false>") \
+            rs = 4 if slack & 0x200 else 2  # items of four chunks for the wider ones of the narrow envelopes
+            potrf_kernel = ("trs_potrf_narrow_kernel<true, 2>" if compact else f"trs_potrf_narrow_kernel<false, {rs}>") \
                 if narrow else "trs_potrf_kernel"
             env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nchm]
             tile_flops = potrf_tile_flops(n, env_ft, env_last, env_cend, narrow)

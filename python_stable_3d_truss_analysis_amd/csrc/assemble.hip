@@ -263,7 +263,8 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                                  (flags & TRS_ASM_NO_COMPACT) == 0;
             if (tid == 0) {
                 int* meta = env + n_pad_max / 16 + n_pad_max / 64;
-                meta[0] = ((narrow ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1) | (compact ? TRS_ENV_COMPACT : 0);
+                meta[0] = ((narrow ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1) | (compact ? TRS_ENV_COMPACT : 0) |
+                          (narrow && widest > TRS_NARROW_RS4_ABOVE ? TRS_ENV_RS4 : 0);
                 if (compact) {  // where the factorisation finds the lists: byte offsets / 16 from `work`
                     const TrsCompactLayout ck = trs_compact_layout(nJ_max, nM_max, n_pad_max);
                     const size_t base = (size_t)b * work_stride + ck_off;

@@ -10,7 +10,7 @@ int trs_assemble_launch(int, int, int, const double*, const int*, const double*,
                         const double*, const int*, const int*, const int*, const int*, int, size_t,
                         int, double*, int, void*, int*, double*, int, hipStream_t);
 size_t trs_assemble_work_bytes(int, int, int);
-int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int*, const void*, double*, int,
+int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int*, const void*, double*, int, int,
                      hipStream_t);
 int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, const int*, hipStream_t);
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
@@ -104,7 +104,7 @@ int trs_potrf_batched(int B, const int32_t* n_free, int ld, int slab_rows, doubl
     if (B < 0 || bad_slab(ld, slab_rows) || (B > 0 && (uf == nullptr || ld_uf < slab_rows)))
         return (int)hipErrorInvalidValue;
     return trs_potrf_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, info, env, work, uf, ld_uf,
-                            (hipStream_t)stream);
+                            g_compact, (hipStream_t)stream);
 }
 
 int trs_potrs_batched(int B, const int32_t* n_free, int ld, int slab_rows, const double* S, double* uf,

@@ -584,7 +584,7 @@ __device__ __forceinline__ void krange_unscatter(const KLists& K, const RangeFet
 // out-of-range lane offset (Slab::gone), and no MFMA is issued for an all-zero operand tile.
 // ======================================================================================================
 #ifndef TRS_NARROW_RS
-#define TRS_NARROW_RS TRS_NARROW_ITEM
+#define TRS_NARROW_RS TRS_NARROW_ITEM   // (kept for the comment below; the item size is a template argument now)
 #endif
 #ifndef TRS_NARROW_DEPTH
 #define TRS_NARROW_DEPTH 2
@@ -739,8 +739,10 @@ constexpr int MPW = TRS_NARROW_MATRICES_PER_WG;  // waves (= matrices) per work-
 // FUSED = false: the stiffness tiles are read from the slab (trs_assemble wrote them);
 // FUSED = true : the stiffness tiles are formed from the compact entry lists - K_ff never existed in HBM in
 //                dense form.  Both read the load vector from uf, leave y there and L in the slab.
-template <bool FUSED>
-__global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NARROW_WAVES_PER_SIMD) void trs_potrf_narrow_kernel(
+// RSV = row chunks per item: 2 (three waves per SIMD) or 4 (two waves per SIMD; the matrices whose envelope
+// reaches further below the diagonal blocks, routing bit TRS_ENV_RS4; slab form only).
+template <bool FUSED, int RSV>
+__global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV > 2 ? 2 : TRS_NARROW_WAVES_PER_SIMD)) void trs_potrf_narrow_kernel(
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
     int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max, const int B,
     const unsigned char* __restrict__ work, double* __restrict__ uf_all, const int ld_uf) {
@@ -759,6 +761,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
     }
     const TrsEnv env = trs_env_of(env_all, b, n_pad_max);
     if (!trs_env_is_narrow(env) || trs_env_is_compact(env) != FUSED) return;  // another kernel's matrix
+    if (!FUSED && trs_env_is_rs4(env) != (RSV > 2)) return;                   // the other item size's matrix
     Slab S;
     S.rs = __builtin_amdgcn_make_buffer_rsrc(S_all + (size_t)b * slab_stride, 0,
                                              (int)(slab_stride * sizeof(double)), 0x00020000);
@@ -978,12 +981,11 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : TRS_NA
         for (int c0 = 4 * panel + CT; c0 <= lastq;) {
             const int ks = 16 * env.ft[c0];
             const int left = lastq - c0 + 1;
-            constexpr int RSK = FUSED && RSN > 2 ? 2 : RSN;  // the fused form's image holds an item of two chunks
-            if (RSK >= 4 && left >= 4) {
-                narrow_item<(RSK >= 4 ? 4 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
+            if (RSV >= 4 && left >= 4) {
+                narrow_item<(RSV >= 4 ? 4 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
                 c0 += 4;
-            } else if (RSN >= 2 && left >= 2) {
-                narrow_item<(RSN >= 2 ? 2 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
+            } else if (RSV >= 2 && left >= 2) {
+                narrow_item<(RSV >= 2 ? 2 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
                 c0 += 2;
             } else {
                 narrow_item<1, FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
@@ -1014,24 +1016,28 @@ extern "C" int trs_debug_stamps(unsigned long long* host_out, int reset) {
 
 extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
                                 double* S, int* info, const int* env, const void* work, double* uf,
-                                int ld_uf, hipStream_t stream) {
+                                int ld_uf, int compact_possible, hipStream_t stream) {
     if (B <= 0) return 0;
     // a slab is addressed through one buffer descriptor with 32-bit byte offsets, the upper half of
     // the offset range being the "tile not stored" marker (Slab::gone)
     if (slab_stride * sizeof(double) >= (size_t)1 << 31) return (int)hipErrorInvalidValue;
     if (uf == nullptr || ld_uf < n_pad_max) return (int)hipErrorInvalidValue;
     if (env != nullptr) {
-        // both wave-per-matrix kernels are launched; each takes the matrices trs_assemble routed to it
-        hipLaunchKernelGGL(trs_potrf_narrow_kernel<true>, dim3((B + MPW - 1) / MPW), dim3(64 * MPW), 0, stream, S,
-                           n_free, ld, slab_stride, info, env, n_pad_max, B,
-                           static_cast<const unsigned char*>(work), uf, ld_uf);
-        int rc = (int)hipGetLastError();
-        if (rc) return rc;
-        hipLaunchKernelGGL(trs_potrf_narrow_kernel<false>, dim3((B + MPW - 1) / MPW), dim3(64 * MPW), 0, stream, S,
-                           n_free, ld, slab_stride, info, env, n_pad_max, B,
-                           static_cast<const unsigned char*>(work), uf, ld_uf);
-        rc = (int)hipGetLastError();
-        if (rc) return rc;
+        // the wave-per-matrix kernels: each takes the matrices trs_assemble routed to it (csrc/trs_common.h)
+        const dim3 grid((B + MPW - 1) / MPW), block(64 * MPW);
+        const unsigned char* wk = static_cast<const unsigned char*>(work);
+        int rc = 0;
+        if (compact_possible) {  // (the compact form is opt-in: no launch while it is switched off)
+            hipLaunchKernelGGL((trs_potrf_narrow_kernel<true, 2>), grid, block, 0, stream, S, n_free, ld, slab_stride,
+                               info, env, n_pad_max, B, wk, uf, ld_uf);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
+        hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 2>), grid, block, 0, stream, S, n_free, ld, slab_stride,
+                           info, env, n_pad_max, B, wk, uf, ld_uf);
+        if ((rc = (int)hipGetLastError())) return rc;
+        hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 4>), grid, block, 0, stream, S, n_free, ld, slab_stride,
+                           info, env, n_pad_max, B, wk, uf, ld_uf);
+        if ((rc = (int)hipGetLastError())) return rc;
     }
     hipLaunchKernelGGL(trs_potrf_kernel, dim3(B), dim3(NW * 64), 0, stream, S, n_free, ld,
                        slab_stride, info, env, n_pad_max, uf, ld_uf);

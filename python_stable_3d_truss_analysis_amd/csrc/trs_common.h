@@ -73,8 +73,16 @@ __host__ __device__ static inline TrsEnv trs_env_of(const int* env, int b, int n
 // matrix was NOT written to the slab but as compact per-tile entry lists (below) for the fused
 // wave-per-matrix kernel, which forms the tiles where it consumes them.
 #define TRS_ENV_COMPACT 0x100
+// bit 9 set = a narrow envelope that still reaches more than TRS_NARROW_RS4_ABOVE chunks below a diagonal
+// block: the wave-per-matrix kernel instance with four-chunk items takes it (fewer block-side fragment
+// loads per item, two waves per SIMD); measured on 65 536 mixed cube trusses: +4 %, bar-942 (reach 4): -3 %.
+#define TRS_ENV_RS4 0x200
+#ifndef TRS_NARROW_RS4_ABOVE
+#define TRS_NARROW_RS4_ABOVE 8
+#endif
 __host__ __device__ static inline bool trs_env_is_narrow(const TrsEnv& e) { return (e.slack & 0xff) == TRS_NARROW_ITEM - 1; }
 __host__ __device__ static inline bool trs_env_is_compact(const TrsEnv& e) { return (e.slack & TRS_ENV_COMPACT) != 0; }
+__host__ __device__ static inline bool trs_env_is_rs4(const TrsEnv& e) { return (e.slack & TRS_ENV_RS4) != 0; }
 
 // ---- compact stiffness matrix of a narrow-envelope truss (per truss, in the assembly workspace) --------
 // K_ff as per-TILE entry lists instead of slab tiles: the factorisation reads ~10 bytes per non-zero
