@@ -1035,9 +1035,11 @@ extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_st
         hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 2>), grid, block, 0, stream, S, n_free, ld, slab_stride,
                            info, env, n_pad_max, B, wk, uf, ld_uf);
         if ((rc = (int)hipGetLastError())) return rc;
-        hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 4>), grid, block, 0, stream, S, n_free, ld, slab_stride,
-                           info, env, n_pad_max, B, wk, uf, ld_uf);
-        if ((rc = (int)hipGetLastError())) return rc;
+        if (TRS_NARROW_RS4_ABOVE <= TRS_NARROW_MAX_BELOW) {  // (compile-time: see trs_common.h)
+            hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 4>), grid, block, 0, stream, S, n_free, ld, slab_stride,
+                               info, env, n_pad_max, B, wk, uf, ld_uf);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
     }
     hipLaunchKernelGGL(trs_potrf_kernel, dim3(B), dim3(NW * 64), 0, stream, S, n_free, ld,
                        slab_stride, info, env, n_pad_max, uf, ld_uf);

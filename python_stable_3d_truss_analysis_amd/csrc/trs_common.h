@@ -75,10 +75,13 @@ __host__ __device__ static inline TrsEnv trs_env_of(const int* env, int b, int n
 #define TRS_ENV_COMPACT 0x100
 // bit 9 set = a narrow envelope that still reaches more than TRS_NARROW_RS4_ABOVE chunks below a diagonal
 // block: the wave-per-matrix kernel instance with four-chunk items takes it (fewer block-side fragment
-// loads per item, two waves per SIMD); measured on 65 536 mixed cube trusses: +4 %, bar-942 (reach 4): -3 %.
+// loads per item, two waves per SIMD).  OFF by default (threshold beyond any narrow envelope, the second
+// instance is then not launched): with every matrix on four-chunk items 65 536 mixed cube trusses gain 3-4 %
+// and bar-942 loses 3 %, but routing PART of a batch to a second kernel costs more than it gains (two
+// launches that each fill the chip only partly: threshold 12: -8 %, threshold 5: +1 %).
 #define TRS_ENV_RS4 0x200
 #ifndef TRS_NARROW_RS4_ABOVE
-#define TRS_NARROW_RS4_ABOVE 8
+#define TRS_NARROW_RS4_ABOVE 1000000
 #endif
 __host__ __device__ static inline bool trs_env_is_narrow(const TrsEnv& e) { return (e.slack & 0xff) == TRS_NARROW_ITEM - 1; }
 __host__ __device__ static inline bool trs_env_is_compact(const TrsEnv& e) { return (e.slack & TRS_ENV_COMPACT) != 0; }

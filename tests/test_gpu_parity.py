@@ -103,8 +103,7 @@ def test_stages_against_oracle(gpu, name, compact_mode):
     nchm = dev.rows // 16
     slack = int(env[nchm + dev.rows // 64]) & 0xff
     assert not int(env[nchm + dev.rows // 64]) & 0x100     # TRS_ASM_FULL_SYMMETRIC implies the slab form
-    reach = max(int(env_last[j]) - (4 * j + 3) for j in range(nch // 4))
-    assert bool(int(env[nchm + dev.rows // 64]) & 0x200) == (slack == 1 and reach > 8)   # four-chunk items
+    assert not int(env[nchm + dev.rows // 64]) & 0x200     # four-chunk items: off by default (trs_common.h)
     env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nch]
     lastc = [max(q for q in range(nch) if env_ft[q] <= t) for t in range(nch)]
     if slack == 1:
