@@ -21,6 +21,8 @@ Written files:
   edge_cases.json        synthetic edge cases (inputs + dense outputs or expected exception)
   ga_trace.json          seeded GA run on bar-120 (generation-0 fitness triples, history)
   hetero_bar25.npz       HeteroData tensors of bar-25 for the four (task, metapath) combinations
+  augment.json           the reference's data augmenters (generate.py:13-148) applied to bar-25 with
+                         seeded `random`: expected joint lists per augmenter
 """
 import glob
 import json
@@ -249,9 +251,38 @@ def capture_hetero(rt, rty):
     print("  hetero:", len(out), "arrays;", {k: v.shape for k, v in out.items() if k.startswith("reg_imp")})
 
 
+def capture_augmenters(rg):
+    """Seeded runs of every augmenter of the reference on the bar-25 JSON dict (the form in which
+    GenerateRandomCubeTrusses applies them, generate.py:357)."""
+    with open(os.path.join(REF, "data", "bar-25_input_0.json")) as fh:
+        base = json.load(fh)
+    cases = {
+        "NoChange": (lambda: rg.NoChange(), 1),
+        "AddJointNoise": (lambda: rg.AddJointNoise([0.5, -1.0, 0.0], [0.1, 2.0, 0.5]), 7),
+        "MoveToCentroid": (lambda: rg.MoveToCentroid(), 1),
+        "Translation": (lambda: rg.Translation([1.5, -2.0, 10.0]), 1),
+        "RandomTranslation": (lambda: rg.RandomTranslation([-3.0, 8.0]), 11),
+        "RandomResetPin": (lambda: rg.RandomResetPin(3, 0.7), 13),
+        "RandomResetPin_default": (lambda: rg.RandomResetPin(), 17),
+        "List": (lambda: rg.TrussDataAugmenterList(rg.MoveToCentroid(), rg.AddJointNoise(),
+                                                   rg.RandomResetPin(4, None), rg.RandomTranslation()), 19),
+    }
+    out = {}
+    for name, (make, seed) in cases.items():
+        random.seed(seed)
+        res = make()(json.loads(json.dumps(base)))
+        out[name] = {"seed": seed, "joint": res["joint"], "member_unchanged": res["member"] == base["member"],
+                     "force_unchanged": res["force"] == base["force"]}
+    with open(os.path.join(HERE, "augment.json"), "w") as fh:
+        json.dump(out, fh)
+    print("augment.json:", sorted(out))
+
+
 def main():
     rt, rty, rg, rga = import_reference()
-    which = sys.argv[1:] or ["data", "cube", "edge", "ga", "hetero"]
+    which = sys.argv[1:] or ["data", "cube", "edge", "ga", "hetero", "augment"]
+    if "augment" in which:
+        capture_augmenters(rg)
     if "data" in which:
         capture_data_cases(rt)
     if "cube" in which:

@@ -233,3 +233,33 @@ def test_chunks_and_shards_of_a_dataset_are_the_same_dataset():
             np.testing.assert_array_equal(getattr(part, f), getattr(ref, f), err_msg=f)
     other = gen.generate_cube_batch(sizes[:10], gridRange=(4, 4, 4), seed=21, first_index=10)
     assert not np.array_equal(other.xyz, whole.take(np.arange(10)).trimmed().xyz)
+
+
+def test_augmenters_reproduce_the_reference_with_seeded_random():
+    """tests/golden/augment.json: every augmenter of the reference (generate.py:13-148) applied to the
+    bar-25 JSON dict under a seeded `random` (captured by importing the real reference,
+    tests/golden/make_golden.py) - same coordinates, same pins, same `random` call order."""
+    import random
+    with open(os.path.join(H.GOLDEN, "augment.json")) as fh:
+        gold = json.load(fh)
+    make = {
+        "NoChange": lambda: gen.NoChange(),
+        "AddJointNoise": lambda: gen.AddJointNoise([0.5, -1.0, 0.0], [0.1, 2.0, 0.5]),
+        "MoveToCentroid": lambda: gen.MoveToCentroid(),
+        "Translation": lambda: gen.Translation([1.5, -2.0, 10.0]),
+        "RandomTranslation": lambda: gen.RandomTranslation([-3.0, 8.0]),
+        "RandomResetPin": lambda: gen.RandomResetPin(3, 0.7),
+        "RandomResetPin_default": lambda: gen.RandomResetPin(),
+        "List": lambda: gen.TrussDataAugmenterList(gen.MoveToCentroid(), gen.AddJointNoise(),
+                                                   gen.RandomResetPin(4, None), gen.RandomTranslation()),
+    }
+    assert sorted(make) == sorted(gold)
+    base = H.load_json("bar-25_input_0")
+    for name, want in gold.items():
+        random.seed(want["seed"])
+        got = make[name]()(json.loads(json.dumps(base)))
+        assert [s for _, s in got["joint"]] == [s for _, s in want["joint"]], name
+        np.testing.assert_allclose(np.array([p for p, _ in got["joint"]]),
+                                   np.array([p for p, _ in want["joint"]]), rtol=1e-13, atol=1e-12, err_msg=name)
+        assert (got["member"] == base["member"]) == want["member_unchanged"]
+        assert (got["force"] == base["force"]) == want["force_unchanged"]
