@@ -62,7 +62,6 @@ int trs_abi_version(void);
 
 /* Process-wide switches for tests and diagnostics (no effect on results):
  *   "recover_unstaged" 0/1  force trs_recover's path for trusses whose tables exceed a CU's LDS;
- *   "recover_workgroup" 0/1 force trs_recover's work-group kernel where the wave-per-truss kernel would run;
  *   "small_path"       1/0  let trs_solve take the fused small-system kernel (default 1);
  *   "compact"          0/1  1: trs_assemble leaves narrow-envelope matrices as compact entry lists and
  *                           trs_potrf_batched forms the tiles from them (see "Compact form" above);

@@ -17,7 +17,6 @@ int trs_recover_launch(int, int, int, const double*, const int*, const double*, 
                        const double*, const int*, const int*, const int*, const double*, int, double*,
                        double*, double*, hipStream_t);
 void trs_recover_set_unstaged(int);
-void trs_recover_set_workgroup(int);
 int trs_solve_small_fits(int, int, int);
 int trs_solve_small_launch(int, int, int, int, const double*, const int*, const double*, const double*,
                            const uint8_t*, const double*, const int*, const int*, double*, double*, double*,
@@ -48,10 +47,6 @@ static int g_compact = 0;
 int trs_set_option(const char* name, int value) {
     if (name != nullptr && strcmp(name, "recover_unstaged") == 0) {
         trs_recover_set_unstaged(value != 0);
-        return 0;
-    }
-    if (name != nullptr && strcmp(name, "recover_workgroup") == 0) {
-        trs_recover_set_workgroup(value != 0);
         return 0;
     }
     if (name != nullptr && strcmp(name, "small_path") == 0) {

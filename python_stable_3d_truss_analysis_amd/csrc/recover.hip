@@ -162,75 +162,6 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     }
 }
 
-// One WAVE per truss (WPW trusses per work-group), no work-group barriers, no sorting: u and f_ext in the
-// wave's LDS strip; the members are taken 64 at a time in member order and the lanes whose member ends at a
-// constrained joint add their end forces ONE LANE AFTER THE OTHER (ballot + serial loop over the set bits),
-// i.e. in increasing member id - the same order, hence the same bits, as the sorted lists of the
-// work-group kernel above, without its counting sort, its second geometry pass and its seven barriers.
-template <int WPW>
-__global__ __launch_bounds__(64 * WPW) void trs_recover_wave_kernel(
-    const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
-    const double* __restrict__ A, const double* __restrict__ loads,
-    const int* __restrict__ free_index, const int* __restrict__ nJ, const int* __restrict__ nM,
-    const int nJ_max, const int nM_max, const double* __restrict__ uf, const int ld_uf,
-    double* __restrict__ u_out, double* __restrict__ f_out, double* __restrict__ N_out, const int B) {
-    extern __shared__ double sh[];  // [WPW][2][3 nJ_max]
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b = blockIdx.x * WPW + wave;
-    if (b >= B) return;
-    const int ndof = 3 * nJ[b], ndof_max = 3 * nJ_max;
-    double* u = sh + (size_t)wave * 2 * ndof_max;
-    double* f = u + ndof_max;
-    const int* fi = free_index + (size_t)b * ndof_max;
-    const double* F = loads + (size_t)b * ndof_max;
-    const double* ufb = uf + (size_t)b * ld_uf;
-    for (int d = lane; d < ndof_max; d += 64) {
-        const int r = d < ndof ? fi[d] : -1;
-        u[d] = r >= 0 ? ufb[r] : 0.0;
-        f[d] = r >= 0 ? F[d] : 0.0;  // constrained: reaction accumulated below (load ignored)
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double* X = xyz + (size_t)b * ndof_max;
-    const int members = nM[b];
-    for (int m0 = 0; m0 < nM_max; m0 += 64) {
-        const int m = m0 + lane;
-        const size_t mm = (size_t)b * nM_max + m;
-        double axial = 0.0, fc[3] = {0.0, 0.0, 0.0};
-        int j0 = 0, j1 = 0;
-        bool touches = false;
-        if (m < members) {
-            j0 = conn[2 * mm];
-            j1 = conn[2 * mm + 1];
-            const MemberGeom g = member_geom(X, j0, j1);
-            axial = member_axial(g, E[mm] * A[mm], u, j0, j1);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                fc[a] = axial * g.c[a];
-                touches |= (fi[3 * j0 + a] < 0) | (fi[3 * j1 + a] < 0);
-            }
-        }
-        if (m < nM_max) N_out[mm] = axial;
-        unsigned long long todo = __ballot(touches);
-        while (todo != 0) {  // in lane = member order: a fixed summation order per constrained DOF
-            const int turn = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            if (lane == turn) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    if (fi[3 * j1 + a] < 0) f[3 * j1 + a] += fc[a];
-                    if (fi[3 * j0 + a] < 0) f[3 * j0 + a] += -fc[a];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int d = lane; d < ndof_max; d += 64) {
-        u_out[(size_t)b * ndof_max + d] = u[d];
-        f_out[(size_t)b * ndof_max + d] = d < ndof ? f[d] : 0.0;
-    }
-}
-
 // Deterministic block sum of one double per thread (256 threads).
 __device__ __forceinline__ double block_sum(double v, double* red) {
 #pragma unroll
@@ -282,10 +213,8 @@ __global__ __launch_bounds__(256) void trs_fitness_kernel(
 
 }  // namespace
 
-static int g_recover_unstaged = 0;   // trs_set_option("recover_unstaged", 1): tests force the large-truss path
-static int g_recover_workgroup = 0;  // trs_set_option("recover_workgroup", 1): tests force the work-group kernel
+static int g_recover_unstaged = 0;  // trs_set_option("recover_unstaged", 1): tests force the large-truss path
 extern "C" void trs_recover_set_unstaged(int on) { g_recover_unstaged = on; }
-extern "C" void trs_recover_set_workgroup(int on) { g_recover_workgroup = on; }
 
 extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
                                   const double* E, const double* A, const double* loads,
@@ -293,18 +222,6 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
                                   const double* uf, int ld_uf, double* u, double* f_ext, double* N,
                                   hipStream_t stream) {
     if (B <= 0) return 0;
-    // one wave per truss while the u / f_ext strips of a work-group's waves fit 40 KB (>= 4 work-groups per CU)
-    const size_t strip = (size_t)6 * nJ_max * sizeof(double);
-    if (!g_recover_unstaged && !g_recover_workgroup && 2 * strip <= 40 * 1024) {
-        if (4 * strip <= 40 * 1024) {
-            hipLaunchKernelGGL(trs_recover_wave_kernel<4>, dim3((B + 3) / 4), dim3(256), 4 * strip, stream, xyz, conn,
-                               E, A, loads, free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, B);
-        } else {
-            hipLaunchKernelGGL(trs_recover_wave_kernel<2>, dim3((B + 1) / 2), dim3(128), 2 * strip, stream, xyz, conn,
-                               E, A, loads, free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, B);
-        }
-        return (int)hipGetLastError();
-    }
     // u, f_ext (doubles) + member-end tables (ints)
     const size_t lds = ((size_t)6 * nJ_max * sizeof(double) +
                         ((size_t)2 * nJ_max + 1 + 2 * (size_t)nM_max) * sizeof(int) + 15) / 16 * 16;

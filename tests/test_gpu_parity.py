@@ -460,28 +460,6 @@ def test_recover_without_lds_staging_matches(gpu):
     assert np.abs(got.external - ref.external).max() <= 1e-12 * np.abs(ref.external).max()
 
 
-def test_recover_wave_kernel_equals_workgroup_kernel_bitwise(gpu):
-    """trs_recover runs one wave per truss where the strips fit; the work-group kernel (forced with
-    trs_set_option) sums the reactions in the same member order: identical bits, on bar-942 copies and on
-    the ragged cube fixtures (more supports, up to 343 joints: two waves per work-group)."""
-    for datas in ([H.load_json("bar-942_input_0")] * 5, [d for _, d, _ in H.ragged_cube_cases()][:6],
-                  [H.load_json("bar-47_input_0"), H.load_json("bar-120_input_0")]):
-        dev = gpu.DeviceBatch(gpu.pack_json(datas), use_small=False)
-        dev.dofmap(); dev.assemble(); dev.potrf(); dev.potrs()
-        dev.recover()
-        wave = dev.result()
-        assert dev.lib.trs_set_option(b"recover_workgroup", 1) == 0
-        try:
-            dev.recover()
-            wg = dev.result()
-        finally:
-            dev.lib.trs_set_option(b"recover_workgroup", 0)
-        np.testing.assert_array_equal(wave.displace, wg.displace)
-        np.testing.assert_array_equal(wave.internal, wg.internal)
-        np.testing.assert_array_equal(wave.external, wg.external)
-        assert np.abs(wave.external).max() > 0
-
-
 def test_empty_batch_and_fully_constrained_truss(gpu):
     """Degenerate inputs: a batch of zero trusses, and a truss without free DOFs next to a normal one
     (the reference's solve of a 0 x 0 system gives zero displacements, forces and reactions)."""
