@@ -6,7 +6,7 @@
 Workload (BASELINE.json configs[1]): the 942-bar truss (tests/golden/data/bar-942_input_0.json,
 n_free = 696) packed once and replicated to `--batch` (default 4096) INDEPENDENT problems per GPU,
 inputs resident in HBM before the timed region.  One step = one pass of the whole pipeline over
-the batch: dofmap -> assemble -> potrf -> potrs -> recover (five kernel launches through the C ABI).
+the batch: dofmap -> assemble -> potrf -> potrs -> recover (five stages through the C ABI).
 Weak scaling: every rank solves its own batch; no collective on the data path.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
@@ -96,9 +96,8 @@ def potrf_tile_flops(n, env_ft=None, env_last=None, env_cend=None, narrow=False)
         kd = 16 * int(env_ft[4 * j]) if env_ft is not None else 0
         if narrow:
             bks = [16 * int(env_ft[4 * j + u]) for u in range(4)]
-            for kk in range(kd, r0, 4):                      # block update + load column, per k-step
-                mfma += sum(u + 2 for u in range(4) if kk >= bks[u])
-            mfma += 40                                         # load column against the factored block
+            for kk in range(kd, r0, 4):                      # block update, per k-step (the load vector
+                mfma += sum(u + 1 for u in range(4) if kk >= bks[u])   # is advanced with VALU FMAs)
         else:
             mfma += (10 + 4) * (r0 - kd) // 4 + 40            # ten block tiles + load-column chunk
         mfma += 64 + 40                                        # F

@@ -578,21 +578,17 @@ __device__ __forceinline__ void krange_unscatter(const KLists& K, const RangeFet
 // Narrow-envelope variant: one WAVE per matrix, four matrices per work-group, no barriers, no
 // hand-offs between waves.  The wave keeps the panel's ten diagonal-block tiles (the six L_{u,s}
 // among them are MFMA operand fragments as they stand) in registers; its private LDS slice holds the
-// four inv(L_ss) as operand fragments, the load column parked during the factorisation and the
-// scratch of chol16_invert.  152 VGPRs: three waves per SIMD.  The load column rides in the
-// diagonal-block pass; every access to a tile outside the stored envelope goes through the
-// out-of-range lane offset (Slab::gone), and no MFMA is issued for an all-zero operand tile.
+// four inv(L_ss) as operand fragments (swizzled, trs_chol16.h) and the scratch of chol16_invert.
+// 168 VGPRs: three waves per SIMD.  The load vector (L y = f) rides in the diagonal-block pass as four
+// scalars per lane; every access to a tile outside the stored envelope goes through the out-of-range
+// lane offset (Slab::gone), and no MFMA is issued for an all-zero operand tile.
 // ======================================================================================================
-#ifndef TRS_NARROW_RS
-#define TRS_NARROW_RS TRS_NARROW_ITEM   // (kept for the comment below; the item size is a template argument now)
-#endif
 #ifndef TRS_NARROW_DEPTH
 #define TRS_NARROW_DEPTH 2
 #endif
 #ifndef TRS_NARROW_WAVES_PER_SIMD
 #define TRS_NARROW_WAVES_PER_SIMD 3   // 168 VGPRs: the slab form fits with two registers spilled
 #endif
-constexpr int RSN = TRS_NARROW_RS;      // row chunks per item in the narrow kernel (1, 2 or 4)
 constexpr int DEPTHN = TRS_NARROW_DEPTH;  // k-steps of fragments in flight (divides 4 k-steps = 16 columns)
 
 // One item of the narrow kernel: NV row chunks c0, c0+1 below the diagonal block of panel r0 / 64.
@@ -800,8 +796,8 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
         // first written column of each of the block's four row chunks (their envelope)
         const int bks[CT] = {16 * env.ft[4 * panel], 16 * env.ft[4 * panel + 1], 16 * env.ft[4 * panel + 2],
                              16 * env.ft[4 * panel + 3]};
-        // D: the ten lower tiles of the diagonal block, and the load column's four tiles (L y = f rides
-        // along as row n_pad: same k range and B-side fragments as the block, which are read once)
+        // D: the ten lower tiles of the diagonal block and the load vector's 64 entries (L y = f rides along:
+        // same k range and the same block-side fragments, which are read once).
         // The load vector is ONE column: carried as four scalars per lane (yr[u] = entry of row li of block
         // chunk u, replicated over the quarter-waves) and advanced with plain FMAs and lane reductions.
         // As a 16-wide MFMA operand chunk (round 1) it cost 104 of the ~240 MFMAs of a panel, 15/16 of
