@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
 // The solution lives in the wave's LDS strip (it starts as y).
 // ======================================================================================================
 constexpr int PMW = 4;    // matrices (waves) per work-group
-constexpr int PTG = 4;    // tiles in flight per group of loads
+#ifndef TRS_POTRS_PTG
+#define TRS_POTRS_PTG 4
+#endif
+constexpr int PTG = TRS_POTRS_PTG;  // tiles in flight per group of loads
 __global__ __launch_bounds__(64 * PMW, 3) void trs_potrs_narrow_kernel(
     const double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
     double* __restrict__ uf, const int ld_uf, const int* __restrict__ env_all, const int n_pad_max, const int B) {
