@@ -283,7 +283,10 @@ class ShardedSolver:
                 busy.append(conn)
             errors = []
             for conn in busy:
-                kind, text = conn.recv()
+                try:
+                    kind, text = conn.recv()
+                except (EOFError, OSError):   # the worker process died (e.g. killed for memory)
+                    kind, text = "error", "shard worker exited without an answer"
                 if kind != "done":
                     errors.append(text)
             if errors:
