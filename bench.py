@@ -168,7 +168,7 @@ def cpu_baseline_all_cores(data, seconds=8.0):
 
 def cube_batch_rate(device, B, torch, batch):
     """Informational: resident-batch throughput on a mixed GenerateRandomCubeTrusses-like batch
-    (native generator, joints renumbered by RCM, bucketed by padded size; BASELINE config 3)."""
+    (native generator, joints renumbered by the profile order of csrc/reorder.c, bucketed by padded size; BASELINE config 3)."""
     import numpy as np
     from python_stable_3d_truss_analysis_amd import generate as gen
     rng = np.random.default_rng(0)
@@ -176,7 +176,7 @@ def cube_batch_rate(device, B, torch, batch):
     packed = gen.generate_cube_batch(rng.integers(8, 191, size=B), gridRange=(6, 6, 6), seed=7)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    packed = batch.permute_joints(packed, batch.rcm_permutation(packed))
+    packed = batch.permute_joints(packed, batch.profile_permutation(packed))
     t_rcm = time.perf_counter() - t0
     groups = batch.size_buckets(packed, 64 << 30)
     total, bad = 0.0, 0
@@ -193,7 +193,7 @@ def cube_batch_rate(device, B, torch, batch):
     return {"workload": f"{B} random cube trusses, {int(packed.nM.min())}..{int(packed.nM.max())} members, "
                         f"n_free {int(packed.n_free.min())}..{int(packed.n_free.max())}",
             "solves_per_s": B / total, "buckets": len(groups), "info_nonzero": bad,
-            "host_generate_s": t_gen, "host_rcm_reorder_s": t_rcm,
+            "host_generate_s": t_gen, "host_reorder_s": t_rcm,
             "note": "inputs resident, one launch pipeline per size bucket; informational, not the headline"}
 
 

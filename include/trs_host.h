@@ -42,6 +42,15 @@ int trs_cubegen(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num
 int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint8_t *cbits,
                   const int32_t *nJ, const int32_t *nM, int32_t *perm /* [B][nJ_max] */);
 
+/* The cheapest of several candidate joint orders per truss, priced by the 16x16-tile envelope the
+ * factorisation works in (csrc/reorder.c): reverse Cuthill-McKee, its reverse, and the twelve binned
+ * coordinate sweeps (six axis orders, forwards and backwards).  Never worse than trs_rcm_order; 15-35 %
+ * less factorisation work on lattice-like trusses (the reference's cube trusses, generate.py:150-340).
+ * perm as trs_rcm_order; choice [B] (may be NULL) receives the winning candidate's id. */
+int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
+                      const uint8_t *cbits, const int32_t *nJ, const int32_t *nM, int32_t *perm /* [B][nJ_max] */,
+                      int32_t *choice /* [B] or NULL */);
+
 /* Apply a joint order out of place (members keep their order, their end joints are renumbered). */
 int trs_apply_joint_order(int B, int nJ_max, int nM_max, const int32_t *perm, const int32_t *nM,
                           const double *xyz, const int32_t *conn, const uint8_t *cbits,

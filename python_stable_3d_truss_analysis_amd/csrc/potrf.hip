@@ -654,7 +654,11 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
 #endif
             }
     }
+#ifdef TRS_EXP_NO_ITEMUPDATE  // timing experiment only (wrong results): no update loop in the items
+    if (false) {
+#else
     if (r0 > kstart) {
+#endif
         int ob = S.at(kstart, r0);
         int oa = S.at(kstart, rowbase);
         const int step = S.ld * 32;
@@ -721,7 +725,11 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
             const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
             const unsigned vo = S.lane_off(s >= smin[v]);
 #pragma unroll
+#ifdef TRS_EXP_NO_ITEMSTORE   // timing experiment only (wrong results): the items' result tiles are not stored
+            for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(acc[v][s][r]), "v"(vo), "s"(o));
+#else
             for (int r = 0; r < 4; ++r) S.store_at(vo, o + r * (S.ld * 32), acc[v][s][r]);
+#endif
         }
 }
 

@@ -130,6 +130,182 @@ int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint
     return rc;
 }
 
+/* ---- profile order: the cheapest of several candidate orders ---------------------------------------
+ *
+ * What the factorisation pays for is the row envelope of K_ff at 16-row granularity (trs_common.h): per
+ * row chunk q the tiles ft[q] .. q, ft = the first coupled tile made non-decreasing from the bottom
+ * (assemble.hip, envelope metadata).  With w_q = q - ft[q] + 1 the matrix-core work of the left-looking
+ * factorisation grows like sum w_q^2 and the bytes of every stage like sum w_q; on MI355X one tile of
+ * traffic through the four stages costs about as much time as twelve tile updates, hence
+ *     cost = sum_q w_q (w_q + 12).
+ * Candidates: reverse Cuthill-McKee (above) and its reverse, and coordinate sweeps - the joints sorted
+ * lexicographically by their coordinates, binned to a quarter of the mean member length (so that the
+ * joints of one lattice plane stay together under small geometric noise), in each of the six axis
+ * orders, forwards and backwards.  A frame-like truss swept plane by plane along one axis has the
+ * cross-section as its front, which for lattice-like trusses (the reference's cube trusses,
+ * generate.py:150-340) is 15-35 % cheaper than the diagonal level sets of Cuthill-McKee.  Every candidate
+ * is priced with the same cost and the cheapest wins, so the result is never worse than RCM. */
+/* cost of the order `ord` of the nf joints that keep a free DOF (ord[k] = old joint id), over the joint
+ * adjacency rcm_one left in sc->start / sc->adj.  Scratch: newidx [nJ], c0 / c1 [nf] first and last row
+ * chunk of a joint, cmin [n/16 + 2]. */
+static double envelope_cost(const rcm_scratch_t *sc, int nf, const uint8_t *cbits, const int *ord, int *newidx,
+                            int *c0, int *c1, int *cmin) {
+    int n = 0;
+    for (int k = 0; k < nf; ++k) {
+        const int old = ord[k];
+        newidx[old] = k;
+        c0[k] = n >> 4;
+        n += 3 - ((cbits[old] & 1) + ((cbits[old] >> 1) & 1) + ((cbits[old] >> 2) & 1));
+        c1[k] = (n - 1) >> 4;
+    }
+    const int nch = (n + 15) >> 4;
+    for (int q = 0; q < nch; ++q) cmin[q] = q;
+    for (int k = 0; k < nf; ++k) {
+        const int old = ord[k];
+        int m = k; /* the joint's own rows may straddle two chunks */
+        for (int e = sc->start[old]; e < sc->start[old + 1]; ++e) {
+            const int w = newidx[sc->adj[e]];
+            m = w < m ? w : m;
+        }
+        const int col = c0[m];
+        if (cmin[c0[k]] > col) cmin[c0[k]] = col;
+        if (cmin[c1[k]] > col) cmin[c1[k]] = col;
+    }
+    double cost = 0.0;
+    int run = nch;
+    for (int q = nch - 1; q >= 0; --q) {
+        if (cmin[q] < run) run = cmin[q];
+        const double w = (double)(q - run + 1);
+        cost += w * (w + 12.0);
+    }
+    return cost;
+}
+
+/* stable counting sort of ids[0..n) by key[id] in [0, nb): out <- sorted; count: [nb + 1] */
+static void counting_pass(const int *ids, int *out, int n, const int *key, int stride, int nb, int *count) {
+    for (int i = 0; i <= nb; ++i) count[i] = 0;
+    for (int i = 0; i < n; ++i) ++count[key[stride * ids[i]] + 1];
+    for (int i = 0; i < nb; ++i) count[i + 1] += count[i];
+    for (int i = 0; i < n; ++i) out[count[key[stride * ids[i]]]++] = ids[i];
+}
+
+/* perm: [B][nJ_max] as trs_rcm_order; choice (may be NULL): [B] winning candidate - 0 RCM, 1 its reverse,
+ * 2 + 2 p + r the sweep with axis order p (0..5: xyz xzy yxz yzx zxy zyx, first axis slowest), r = 1 backwards */
+int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
+                      const uint8_t *cbits, const int32_t *nJ, const int32_t *nM, int32_t *perm,
+                      int32_t *choice) {
+    static const int axes[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    const int bin_cap = 4 * nJ_max + 64; /* bins per axis (the bin width grows on an axis that would need more) */
+    int rc = 0;
+#pragma omp parallel
+    {
+        rcm_scratch_t sc;
+        sc.start = (int *)malloc(sizeof(int) * (nJ_max + 2));
+        sc.adj = (int *)malloc(sizeof(int) * (2 * nM_max + 2));
+        sc.deg = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        sc.level = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        sc.queue = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        sc.order = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        sc.tmp = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        int *cand = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        int *ids = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        int *newidx = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        int *c0 = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        int *c1 = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        int *cmin = (int *)malloc(sizeof(int) * (3 * nJ_max / 16 + 4));
+        int32_t *rcm = (int32_t *)malloc(sizeof(int32_t) * (nJ_max + 1));
+        int *bins = (int *)malloc(sizeof(int) * 3 * (nJ_max + 1));
+        int *count = (int *)malloc(sizeof(int) * (bin_cap + 2));
+        const int ok = sc.start && sc.adj && sc.deg && sc.level && sc.queue && sc.order && sc.tmp && cand && ids &&
+                       newidx && c0 && c1 && cmin && rcm && bins && count;
+        if (!ok) {
+#pragma omp critical
+            rc = -2;
+        }
+#pragma omp for schedule(dynamic, 16)
+        for (int b = 0; b < B; ++b) {
+            if (!ok) continue;
+            const int nj = nJ[b], nm = nM[b];
+            const int32_t *cn = conn + (size_t)b * 2 * nM_max;
+            const uint8_t *cb = cbits + (size_t)b * nJ_max;
+            const double *X = xyz + (size_t)b * 3 * nJ_max;
+            int32_t *p = perm + (size_t)b * nJ_max;
+            rcm_one(&sc, nj, nm, cn, cb, rcm); /* leaves the adjacency of the free joints in sc.start / sc.adj */
+            int nf = 0; /* joints with a free DOF: they come first in every candidate, the others keep RCM's tail */
+            for (int j = 0; j < nj; ++j) nf += (cb[j] & 7) != 7;
+            for (int k = 0; k < nj; ++k) p[k] = rcm[k];
+            for (int k = 0; k < nf; ++k) cand[k] = rcm[k];
+            double best = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin);
+            int best_id = 0;
+            /* candidate 1: plain Cuthill-McKee (RCM backwards) */
+            for (int k = 0; k < nf; ++k) cand[k] = rcm[nf - 1 - k];
+            double c = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin);
+            if (c < best) {
+                best = c; best_id = 1;
+                for (int k = 0; k < nf; ++k) p[k] = cand[k];
+            }
+            /* coordinate bins: a quarter of the mean member length */
+            double len = 0.0;
+            int nlen = 0;
+            for (int m = 0; m < nm; ++m) {
+                const double *pa = X + 3 * cn[2 * m], *pb = X + 3 * cn[2 * m + 1];
+                const double dx = pb[0] - pa[0], dy = pb[1] - pa[1], dz = pb[2] - pa[2];
+                const double l2 = dx * dx + dy * dy + dz * dz;
+                if (l2 > 0.0) { len += __builtin_sqrt(l2); ++nlen; }
+            }
+            const double h = nlen ? 0.25 * len / nlen : 0.0;
+            if (h > 0.0 && h < 1e300 && nf > 1) {
+                int nb[3];
+                for (int a = 0; a < 3; ++a) {
+                    double lo = X[a], hi = X[a];
+                    for (int j = 1; j < nj; ++j) {
+                        lo = X[3 * j + a] < lo ? X[3 * j + a] : lo;
+                        hi = X[3 * j + a] > hi ? X[3 * j + a] : hi;
+                    }
+                    double ha = h;
+                    if (!((hi - lo) / ha < (double)(bin_cap - 2))) ha = (hi - lo) / (double)(bin_cap - 2);
+                    nb[a] = 1;
+                    for (int j = 0; j < nj; ++j) {
+                        double q = ha > 0.0 ? (X[3 * j + a] - lo) / ha + 0.5 : 0.0;
+                        if (!(q >= 0.0)) q = 0.0; /* NaN coordinates: any bin */
+                        if (q > (double)(bin_cap - 1)) q = (double)(bin_cap - 1);
+                        bins[3 * j + a] = (int)q;
+                        if ((int)q + 1 > nb[a]) nb[a] = (int)q + 1;
+                    }
+                }
+                int nk = 0;
+                for (int j = 0; j < nj; ++j)
+                    if ((cb[j] & 7) != 7) ids[nk++] = j;
+                for (int ax = 0; ax < 6; ++ax) {
+                    /* lexicographic by (axis 0, axis 1, axis 2, joint id): three stable passes, last key first */
+                    const int *A = axes[ax];
+                    counting_pass(ids, cand, nk, bins + A[2], 3, nb[A[2]], count);
+                    counting_pass(cand, sc.order, nk, bins + A[1], 3, nb[A[1]], count);
+                    counting_pass(sc.order, cand, nk, bins + A[0], 3, nb[A[0]], count);
+                    for (int rev = 0; rev < 2; ++rev) {
+                        if (rev)
+                            for (int k = 0; k < nk / 2; ++k) {
+                                const int t = cand[k];
+                                cand[k] = cand[nk - 1 - k];
+                                cand[nk - 1 - k] = t;
+                            }
+                        c = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin);
+                        if (c < best) {
+                            best = c; best_id = 2 + 2 * ax + rev;
+                            for (int k = 0; k < nf; ++k) p[k] = cand[k];
+                        }
+                    }
+                }
+            }
+            for (int k = nj; k < nJ_max; ++k) p[k] = k;
+            if (choice) choice[b] = best_id;
+        }
+        free(sc.start); free(sc.adj); free(sc.deg); free(sc.level); free(sc.queue); free(sc.order); free(sc.tmp);
+        free(cand); free(ids); free(newidx); free(c0); free(c1); free(cmin); free(rcm); free(bins); free(count);
+    }
+    return rc;
+}
+
 /* Apply a joint order: joint k of the output is joint perm[b][k] of the input (members keep their
  * order, their end joints are renumbered; padding members stay (0, 0)).  Out-of-place. */
 int trs_apply_joint_order(int B, int nJ_max, int nM_max, const int32_t *perm, const int32_t *nM,

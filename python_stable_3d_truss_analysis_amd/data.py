@@ -329,7 +329,7 @@ def solve_actual_and_prior(packed: PackedBatch, fixedMemberType=None, device=Non
                            devices=None, pool=None, need_actual=True):
     """The two batched GPU solves behind a dataset: real sections, then every member set to
     `fixedMemberType` (reference `data.py:107-114`).  The two solves differ only in A and E, so the
-    geometry is uploaded, RCM-reordered and bucketed ONCE (`solve_batch(..., sections=[...])`).
+    geometry is uploaded, reordered (`batch.joint_order`) and bucketed ONCE (`solve_batch(..., sections=[...])`).
 
     With more than one GPU (`devices` = list of device names, `pool` = a running
     `shard.ShardedSolver`, or - when neither `device` nor `devices` is given - every visible GPU) the

@@ -133,10 +133,13 @@ def test_config3_full_batch_65536_random_cube_trusses():
         data = gen.packed_to_json(packed, b)
         ref = orc.solve(data)
         _check_against(res, b, data, ref, 1e-8, ("config3", b, int(packed.n_free[b])))
-    # the generator order (no RCM) gives the same answers on a slice
+    # the generator order (no reordering) and plain RCM give the same answers on a slice
     part = packed.take(np.arange(0, B, 64))
-    plain = batch.solve_batch(part, reorder=False)
-    assert H.max_scaled_err(plain.displace, res.displace[::64, :plain.displace.shape[1]]) <= 1e-7
+    for order in (False, "rcm"):
+        other = batch.solve_batch(part, reorder=order)
+        assert not other.info.any()
+        assert H.max_scaled_err(other.displace, res.displace[::64, :other.displace.shape[1]]) <= 1e-7, order
+        assert H.max_scaled_err(other.internal, res.internal[::64, :other.internal.shape[1]]) <= 1e-7, order
 
 
 # ---- config 5: dataset generation sharded over worker processes, HeteroData-shaped tensors -------------

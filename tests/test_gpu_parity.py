@@ -428,7 +428,7 @@ def test_every_system_size_around_the_tile_and_panel_boundaries(gpu):
     packed = batch.pack_json(cases)
     sizes = sorted(set(int(v) for v in packed.n_free))
     assert sizes[0] <= 3 and sizes[-1] >= 200 and len(sizes) >= 90 and {15, 16, 17, 63, 64, 65} & set(sizes)
-    for reorder in (False, True):
+    for reorder in (False, True, "rcm"):
         res = batch.solve_batch(packed, reorder=reorder)
         assert not res.info.any()
         for b, data in enumerate(cases):

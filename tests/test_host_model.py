@@ -229,3 +229,79 @@ def test_rcm_permutation_is_valid_and_shrinks_the_cube_envelope():
     r0, r1 = orc.solve(packed_to_json(p, 0)), orc.solve(packed_to_json(q, 0))
     np.testing.assert_allclose(r1["u"], r0["u"][perm[0, :int(p.nJ[0])]], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(r1["N"], r0["N"], rtol=1e-9, atol=1e-9)
+
+
+def _envelope_cost(pk, b, perm):
+    """Independent (numpy) restatement of the cost `trs_profile_order` minimises: per 16-row chunk q of
+    the reduced matrix w_q = q - ft[q] + 1 with ft the first coupled tile made non-decreasing from the
+    bottom (csrc/assemble.hip envelope metadata); cost = sum w (w + 12).  Returns (cost, tiles)."""
+    nJ, nM = int(pk.nJ[b]), int(pk.nM[b])
+    inv = np.empty(nJ, dtype=np.int64)
+    inv[perm[:nJ]] = np.arange(nJ)
+    cb = pk.cbits[b][perm[:nJ]].astype(np.int64)
+    nf = 3 - ((cb & 1) + ((cb >> 1) & 1) + ((cb >> 2) & 1))
+    f0 = np.concatenate([[0], np.cumsum(nf)])
+    nch = (int(f0[-1]) + 15) // 16
+    cmin = np.arange(nch)
+    for k in range(nJ):
+        if nf[k]:
+            cmin[(f0[k + 1] - 1) // 16] = min(cmin[(f0[k + 1] - 1) // 16], f0[k] // 16)
+    for a_, b_ in pk.conn[b][:nM]:
+        lo, hi = sorted((int(inv[a_]), int(inv[b_])))
+        if lo == hi or nf[lo] == 0 or nf[hi] == 0:
+            continue
+        for q in (f0[hi] // 16, (f0[hi + 1] - 1) // 16):
+            cmin[q] = min(cmin[q], f0[lo] // 16)
+    w = np.arange(nch) - np.minimum.accumulate(cmin[::-1])[::-1] + 1
+    return int((w * (w + 12)).sum()), int(w.sum())
+
+
+def test_profile_order_is_valid_never_worse_than_rcm_and_cheaper_on_cube_trusses():
+    """`trs_profile_order` (csrc/reorder.c): a permutation per truss, free joints first; its envelope cost,
+    recomputed here independently, is <= RCM's on every truss and clearly lower over a batch of cube
+    trusses; deterministic; degenerate geometry (all joints on one point, NaN coordinates) falls back to
+    RCM instead of failing; an already banded truss (bar-942) is left at least as narrow as RCM leaves it."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    rng = np.random.default_rng(5)
+    p = gen.generate_cube_batch(rng.integers(8, 191, size=48), gridRange=(6, 6, 6), seed=11)
+    perm, choice = batch.profile_permutation(p, return_choice=True)
+    again = batch.profile_permutation(p)
+    np.testing.assert_array_equal(perm, again)
+    rcm = batch.rcm_permutation(p)
+    assert choice.min() >= 0 and choice.max() <= 13 and len(set(choice.tolist())) >= 3
+    tot_p = tot_r = 0
+    for b in range(p.B):
+        nJ = int(p.nJ[b])
+        assert sorted(perm[b, :nJ].tolist()) == list(range(nJ)) and perm[b, nJ:].tolist() == list(range(nJ, p.nJ_max))
+        free = p.cbits[b, perm[b, :nJ]] != 7
+        assert not free[int(free.sum()):].any()          # fully constrained joints last
+        cp, cr = _envelope_cost(p, b, perm[b])[0], _envelope_cost(p, b, rcm[b])[0]
+        assert cp <= cr, (b, cp, cr)
+        if choice[b] == 0:
+            np.testing.assert_array_equal(perm[b], rcm[b])
+        tot_p, tot_r = tot_p + cp, tot_r + cr
+    assert tot_p < 0.85 * tot_r, (tot_p, tot_r)
+    # same physics in the new numbering
+    q = batch.permute_joints(p, perm)
+    from python_stable_3d_truss_analysis_amd.generate import packed_to_json
+    r0, r1 = orc.solve(packed_to_json(p, 3)), orc.solve(packed_to_json(q, 3))
+    np.testing.assert_allclose(r1["u"], r0["u"][perm[3, :int(p.nJ[3])]], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(r1["N"], r0["N"], rtol=1e-9, atol=1e-9)
+    # degenerate geometry: no usable coordinate sweep -> the RCM order
+    flat = p.take(np.arange(4))
+    flat.xyz[:] = 1.0
+    pf, cf = batch.profile_permutation(flat, return_choice=True)
+    assert set(cf.tolist()) <= {0, 1}
+    nanp = p.take(np.arange(4))
+    nanp.xyz[:, 0, 0] = np.nan
+    pn = batch.profile_permutation(nanp)
+    for b in range(4):
+        assert sorted(pn[b, :int(nanp.nJ[b])].tolist()) == list(range(int(nanp.nJ[b])))
+    # 2D input and an already banded truss
+    mixed = batch.pack_json([H.load_json("bar-942_input_0"), H.load_json("bar-47_input_0")])
+    pm = batch.profile_permutation(mixed)
+    rm = batch.rcm_permutation(mixed)
+    for b in range(2):
+        assert _envelope_cost(mixed, b, pm[b])[0] <= _envelope_cost(mixed, b, rm[b])[0]
+    with pytest.raises(ValueError):
+        batch.joint_order(p, "sloan")

@@ -24,7 +24,7 @@ from python_stable_3d_truss_analysis_amd import generate as gen
 from python_stable_3d_truss_analysis_amd.ga import GA
 
 
-def config3(B, out, reorder, key, slab_gb=48):
+def config3(B, out, reorder, key, slab_gb=48, granularity=64):
     rng = np.random.default_rng(0)
     t0 = time.perf_counter()
     packed = gen.generate_cube_batch(rng.integers(8, 191, size=B), gridRange=(6, 6, 6), seed=7)
@@ -32,9 +32,9 @@ def config3(B, out, reorder, key, slab_gb=48):
     t_rcm = 0.0
     if reorder:
         t0 = time.perf_counter()
-        packed = batch.permute_joints(packed, batch.rcm_permutation(packed))
+        packed = batch.permute_joints(packed, batch.joint_order(packed, reorder))
         t_rcm = time.perf_counter() - t0
-    groups = batch.size_buckets(packed, int(slab_gb) << 30)
+    groups = batch.size_buckets(packed, int(slab_gb) << 30, granularity)
     subs = [packed.take(i).trimmed() for i in groups]
     torch.cuda.synchronize()
     total_gpu = 0.0
@@ -48,7 +48,7 @@ def config3(B, out, reorder, key, slab_gb=48):
         bad += int((dev.info != 0).sum().item())
         del dev
     out[key] = {"B": B, "buckets": len(groups), "n_free_mean": float(packed.n_free.mean()),
-                      "n_free_max": int(packed.n_free.max()), "generate_s": t_gen, "rcm_reorder_s": t_rcm,
+                      "n_free_max": int(packed.n_free.max()), "generate_s": t_gen, "reorder_s": t_rcm,
                       "solve_s_resident": total_gpu, "solves_per_s": B / total_gpu, "info_nonzero": bad}
 
 
@@ -113,19 +113,22 @@ def config5(B, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cubes", type=int, default=65536)
-    ap.add_argument("--only", choices=("ga", "generator", "rcm", "dataset"), help="run one configuration only")
+    ap.add_argument("--only", choices=("ga", "generator", "rcm", "profile", "dataset"), help="run one configuration only")
     ap.add_argument("--samples", type=int, default=16384, help="dataset samples of config 5")
     ap.add_argument("--slab-gb", type=int, default=48, help="stiffness-slab memory per launch pipeline")
+    ap.add_argument("--bucket", type=int, default=64, help="size-bucket granularity (multiple of 64)")
     args = ap.parse_args()
     out = {}
     if args.only in (None, "ga"):
         config4(out)
     if args.only in (None, "generator"):
-        config3(args.cubes, out, False, "config3_generator_order", args.slab_gb)
+        config3(args.cubes, out, False, "config3_generator_order", args.slab_gb, args.bucket)
     if args.only in (None, "dataset"):
         config5(args.samples, out)
     if args.only in (None, "rcm"):
-        config3(args.cubes, out, True, "config3_rcm_order", args.slab_gb)
+        config3(args.cubes, out, "rcm", "config3_rcm_order", args.slab_gb, args.bucket)
+    if args.only in (None, "profile"):
+        config3(args.cubes, out, "profile", "config3_profile_order", args.slab_gb, args.bucket)
     print(json.dumps(out))
 
 
