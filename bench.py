@@ -154,16 +154,17 @@ def _pool_worker(args):
 
 
 def cpu_baseline_all_cores(data, seconds=8.0):
-    """The same oracle on every host core at once (one forked single-threaded process per logical CPU,
-    bounded sample).  Must run BEFORE this process touches the GPU: the workers are plain forks."""
+    """The same oracle on every host core at once (one forked single-threaded process per CPU this process may
+    use - affinity mask and container CPU quota -, bounded sample).  Must run BEFORE this process touches the GPU: the workers are plain forks."""
     import multiprocessing as mp
-    n = os.cpu_count() or 1
+    from python_stable_3d_truss_analysis_amd.generate import available_cpus
+    n = available_cpus()   # affinity mask and cgroup CPU quota, not the logical CPUs of the machine
     with mp.get_context("fork").Pool(n) as pool:
         out = pool.map(_pool_worker, [(data, seconds)] * n)
     runs = sum(r for r, _ in out)
     dt = max(t for _, t in out)
     return {"value": runs / dt, "unit": "solves/s", "cores": n, "kind": "port",
-            "sample": f"{runs} oracle.solve() calls on bar-942 by {n} single-threaded processes in {dt:.1f} s"}
+            "sample": f"{runs} oracle.solve() calls on bar-942 by {n} single-threaded processes (of {os.cpu_count()} logical CPUs) in {dt:.1f} s"}
 
 
 def cube_batch_rate(device, B, torch, batch):

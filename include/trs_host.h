@@ -37,6 +37,11 @@ int trs_cubegen(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num
                 int64_t first_index /* global index of truss 0: the stream of truss b is keyed by
                                        (seed, first_index + b), so chunks / shards of one dataset agree */);
 
+/* Team size of the OpenMP loops of this library: n > 0 sets it, the return value is the size in effect.
+ * The Python loader sets it once to the CPUs the process may actually use (affinity mask and cgroup quota;
+ * `generate.available_cpus`) unless OMP_NUM_THREADS is set. */
+int trs_host_threads(int n);
+
 /* Reverse Cuthill-McKee order of the joints of every truss: perm[b][k] = old id of the joint that
  * becomes joint k (identity on the padding).  Returns 0 or -2 on allocation failure. */
 int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint8_t *cbits,
@@ -49,7 +54,8 @@ int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint
  * perm as trs_rcm_order; choice [B] (may be NULL) receives the winning candidate's id. */
 int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
                       const uint8_t *cbits, const int32_t *nJ, const int32_t *nM, int32_t *perm /* [B][nJ_max] */,
-                      int32_t *choice /* [B] or NULL */);
+                      int32_t *choice /* [B] or NULL */,
+                      int effort /* 0: RCM and its reverse, 1: + the sweep along the longest extent, 2: all sweeps */);
 
 /* Apply a joint order out of place (members keep their order, their end joints are renumbered). */
 int trs_apply_joint_order(int B, int nJ_max, int nM_max, const int32_t *perm, const int32_t *nM,

@@ -14,8 +14,25 @@
 #include <stdlib.h>
 
 typedef struct {
-    int *start, *adj, *deg, *level, *queue, *order, *tmp;
+    int *start, *adj, *adj2, *deg, *level, *queue, *order, *tmp;
 } rcm_scratch_t;
+
+static int scratch_alloc(rcm_scratch_t *sc, int nJ_max, int nM_max) {
+    sc->start = (int *)malloc(sizeof(int) * (nJ_max + 2));
+    sc->adj = (int *)malloc(sizeof(int) * (2 * (size_t)nM_max + 2));
+    sc->adj2 = (int *)malloc(sizeof(int) * (2 * (size_t)nM_max + 2));
+    sc->deg = (int *)malloc(sizeof(int) * (nJ_max + 2));
+    sc->level = (int *)malloc(sizeof(int) * (nJ_max + 1));
+    sc->queue = (int *)malloc(sizeof(int) * (nJ_max + 2));
+    sc->order = (int *)malloc(sizeof(int) * (nJ_max + 2));
+    sc->tmp = (int *)malloc(sizeof(int) * (nJ_max + 1));
+    return sc->start && sc->adj && sc->adj2 && sc->deg && sc->level && sc->queue && sc->order && sc->tmp;
+}
+
+static void scratch_free(rcm_scratch_t *sc) {
+    free(sc->start); free(sc->adj); free(sc->adj2); free(sc->deg); free(sc->level); free(sc->queue);
+    free(sc->order); free(sc->tmp);
+}
 
 static int bfs_levels(const rcm_scratch_t *sc, int root, int stamp_base, int *last_level_begin, int *count) {
     /* level[] doubles as the visited stamp: level >= stamp_base means visited in this sweep */
@@ -42,15 +59,6 @@ static int bfs_levels(const rcm_scratch_t *sc, int root, int stamp_base, int *la
     return depth;
 }
 
-static void sort_by_degree(int *a, int n, const int *deg) { /* insertion sort: neighbour lists are short */
-    for (int i = 1; i < n; ++i) {
-        const int v = a[i];
-        int p = i - 1;
-        while (p >= 0 && (deg[a[p]] > deg[v] || (deg[a[p]] == deg[v] && a[p] > v))) { a[p + 1] = a[p]; --p; }
-        a[p + 1] = v;
-    }
-}
-
 static void rcm_one(rcm_scratch_t *sc, int nJ, int nM, const int32_t *conn, const uint8_t *cbits, int32_t *perm) {
     /* adjacency of the free joints */
     for (int j = 0; j <= nJ; ++j) sc->start[j] = 0;
@@ -65,10 +73,37 @@ static void rcm_one(rcm_scratch_t *sc, int nJ, int nM, const int32_t *conn, cons
     for (int m = 0; m < nM; ++m) {
         const int a = conn[2 * m], b = conn[2 * m + 1];
         if (a == b || (cbits[a] & 7) == 7 || (cbits[b] & 7) == 7) continue;
-        sc->adj[sc->tmp[a]++] = b;
-        sc->adj[sc->tmp[b]++] = a;
+        sc->adj2[sc->tmp[a]++] = b;
+        sc->adj2[sc->tmp[b]++] = a;
     }
-    for (int j = 0; j < nJ; ++j) sort_by_degree(sc->adj + sc->start[j], sc->start[j + 1] - sc->start[j], sc->deg);
+    /* neighbour lists by ascending (degree, id) without sorting them one by one: the joints in that order
+     * (counting sort by degree; degrees are < 2 nM + 1 but lists of trusses are short, so count over the
+     * occurring range) append themselves to their neighbours' lists */
+    {
+        int maxdeg = 0;
+        for (int j = 0; j < nJ; ++j) maxdeg = sc->deg[j] > maxdeg ? sc->deg[j] : maxdeg;
+        if (maxdeg <= nJ) { /* counters fit the [nJ + 2] scratch arrays */
+            int *cnt = sc->queue;
+            for (int d = 0; d <= maxdeg + 1; ++d) cnt[d] = 0;
+            for (int j = 0; j < nJ; ++j) ++cnt[sc->deg[j] + 1];
+            for (int d = 0; d < maxdeg; ++d) cnt[d + 1] += cnt[d];
+            for (int j = 0; j < nJ; ++j) sc->order[cnt[sc->deg[j]]++] = j;
+        } else { /* many parallel members: plain insertion sort of the joints */
+            for (int j = 0; j < nJ; ++j) {
+                int q = j - 1;
+                while (q >= 0 && sc->deg[sc->order[q]] > sc->deg[j]) { sc->order[q + 1] = sc->order[q]; --q; }
+                sc->order[q + 1] = j;
+            }
+        }
+        for (int j = 0; j < nJ; ++j) sc->tmp[j] = sc->start[j];
+        for (int i = 0; i < nJ; ++i) {
+            const int v = sc->order[i];
+            for (int e = sc->start[v]; e < sc->start[v + 1]; ++e) {
+                const int w = sc->adj2[e];
+                sc->adj[sc->tmp[w]++] = v;
+            }
+        }
+    }
 
     int n_order = 0, stamp = 1;
     for (int j = 0; j < nJ; ++j) sc->level[j] = 0;
@@ -106,14 +141,8 @@ int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint
 #pragma omp parallel
     {
         rcm_scratch_t sc;
-        sc.start = (int *)malloc(sizeof(int) * (nJ_max + 2));
-        sc.adj = (int *)malloc(sizeof(int) * (2 * nM_max + 2));
-        sc.deg = (int *)malloc(sizeof(int) * (nJ_max + 1));
-        sc.level = (int *)malloc(sizeof(int) * (nJ_max + 1));
-        sc.queue = (int *)malloc(sizeof(int) * (nJ_max + 1));
-        sc.order = (int *)malloc(sizeof(int) * (nJ_max + 1));
-        sc.tmp = (int *)malloc(sizeof(int) * (nJ_max + 1));
-        const int ok = sc.start && sc.adj && sc.deg && sc.level && sc.queue && sc.order && sc.tmp;
+        const int sc_ok = scratch_alloc(&sc, nJ_max, nM_max);
+        const int ok = sc_ok;
         if (!ok) {
 #pragma omp critical
             rc = -2;
@@ -125,7 +154,7 @@ int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint
             rcm_one(&sc, nJ[b], nM[b], conn + (size_t)b * 2 * nM_max, cbits + (size_t)b * nJ_max, p);
             for (int k = nJ[b]; k < nJ_max; ++k) p[k] = k;
         }
-        free(sc.start); free(sc.adj); free(sc.deg); free(sc.level); free(sc.queue); free(sc.order); free(sc.tmp);
+        scratch_free(&sc);
     }
     return rc;
 }
@@ -146,10 +175,11 @@ int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint
  * generate.py:150-340) is 15-35 % cheaper than the diagonal level sets of Cuthill-McKee.  Every candidate
  * is priced with the same cost and the cheapest wins, so the result is never worse than RCM. */
 /* cost of the order `ord` of the nf joints that keep a free DOF (ord[k] = old joint id), over the joint
- * adjacency rcm_one left in sc->start / sc->adj.  Scratch: newidx [nJ], c0 / c1 [nf] first and last row
+ * adjacency rcm_one left in sc->start / sc->adj; gives up (returning a value >= bound) as soon as the cost
+ * accumulated from the bottom rows reaches `bound`.  Scratch: newidx [nJ], c0 / c1 [nf] first and last row
  * chunk of a joint, cmin [n/16 + 2]. */
 static double envelope_cost(const rcm_scratch_t *sc, int nf, const uint8_t *cbits, const int *ord, int *newidx,
-                            int *c0, int *c1, int *cmin) {
+                            int *c0, int *c1, int *cmin, double bound) {
     int n = 0;
     for (int k = 0; k < nf; ++k) {
         const int old = ord[k];
@@ -160,7 +190,17 @@ static double envelope_cost(const rcm_scratch_t *sc, int nf, const uint8_t *cbit
     }
     const int nch = (n + 15) >> 4;
     for (int q = 0; q < nch; ++q) cmin[q] = q;
-    for (int k = 0; k < nf; ++k) {
+    double cost = 0.0;
+    int run = nch, qdone = nch; /* chunks >= qdone are priced; run = their running minimum (ft of chunk qdone) */
+    for (int k = nf - 1; k >= 0; --k) {
+        /* every joint with rows in a chunk above c1[k] has been seen: those chunks are final */
+        while (qdone > c1[k] + 1) {
+            --qdone;
+            if (cmin[qdone] < run) run = cmin[qdone];
+            const double w = (double)(qdone - run + 1);
+            cost += w * (w + 12.0);
+        }
+        if (cost >= bound) return cost;
         const int old = ord[k];
         int m = k; /* the joint's own rows may straddle two chunks */
         for (int e = sc->start[old]; e < sc->start[old + 1]; ++e) {
@@ -171,11 +211,10 @@ static double envelope_cost(const rcm_scratch_t *sc, int nf, const uint8_t *cbit
         if (cmin[c0[k]] > col) cmin[c0[k]] = col;
         if (cmin[c1[k]] > col) cmin[c1[k]] = col;
     }
-    double cost = 0.0;
-    int run = nch;
-    for (int q = nch - 1; q >= 0; --q) {
-        if (cmin[q] < run) run = cmin[q];
-        const double w = (double)(q - run + 1);
+    while (qdone > 0) {
+        --qdone;
+        if (cmin[qdone] < run) run = cmin[qdone];
+        const double w = (double)(qdone - run + 1);
         cost += w * (w + 12.0);
     }
     return cost;
@@ -193,20 +232,14 @@ static void counting_pass(const int *ids, int *out, int n, const int *key, int s
  * 2 + 2 p + r the sweep with axis order p (0..5: xyz xzy yxz yzx zxy zyx, first axis slowest), r = 1 backwards */
 int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
                       const uint8_t *cbits, const int32_t *nJ, const int32_t *nM, int32_t *perm,
-                      int32_t *choice) {
+                      int32_t *choice, int effort) {
     static const int axes[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     const int bin_cap = 4 * nJ_max + 64; /* bins per axis (the bin width grows on an axis that would need more) */
     int rc = 0;
 #pragma omp parallel
     {
         rcm_scratch_t sc;
-        sc.start = (int *)malloc(sizeof(int) * (nJ_max + 2));
-        sc.adj = (int *)malloc(sizeof(int) * (2 * nM_max + 2));
-        sc.deg = (int *)malloc(sizeof(int) * (nJ_max + 1));
-        sc.level = (int *)malloc(sizeof(int) * (nJ_max + 1));
-        sc.queue = (int *)malloc(sizeof(int) * (nJ_max + 1));
-        sc.order = (int *)malloc(sizeof(int) * (nJ_max + 1));
-        sc.tmp = (int *)malloc(sizeof(int) * (nJ_max + 1));
+        const int sc_ok = scratch_alloc(&sc, nJ_max, nM_max);
         int *cand = (int *)malloc(sizeof(int) * (nJ_max + 1));
         int *ids = (int *)malloc(sizeof(int) * (nJ_max + 1));
         int *newidx = (int *)malloc(sizeof(int) * (nJ_max + 1));
@@ -216,7 +249,7 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
         int32_t *rcm = (int32_t *)malloc(sizeof(int32_t) * (nJ_max + 1));
         int *bins = (int *)malloc(sizeof(int) * 3 * (nJ_max + 1));
         int *count = (int *)malloc(sizeof(int) * (bin_cap + 2));
-        const int ok = sc.start && sc.adj && sc.deg && sc.level && sc.queue && sc.order && sc.tmp && cand && ids &&
+        const int ok = sc_ok && cand && ids &&
                        newidx && c0 && c1 && cmin && rcm && bins && count;
         if (!ok) {
 #pragma omp critical
@@ -235,25 +268,25 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
             for (int j = 0; j < nj; ++j) nf += (cb[j] & 7) != 7;
             for (int k = 0; k < nj; ++k) p[k] = rcm[k];
             for (int k = 0; k < nf; ++k) cand[k] = rcm[k];
-            double best = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin);
+            double best = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin, 1e300);
             int best_id = 0;
             /* candidate 1: plain Cuthill-McKee (RCM backwards) */
             for (int k = 0; k < nf; ++k) cand[k] = rcm[nf - 1 - k];
-            double c = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin);
+            double c = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin, best);
             if (c < best) {
                 best = c; best_id = 1;
                 for (int k = 0; k < nf; ++k) p[k] = cand[k];
             }
             /* coordinate bins: a quarter of the mean member length */
-            double len = 0.0;
+            double len2 = 0.0; /* root mean square member length (one square root per truss) */
             int nlen = 0;
             for (int m = 0; m < nm; ++m) {
                 const double *pa = X + 3 * cn[2 * m], *pb = X + 3 * cn[2 * m + 1];
                 const double dx = pb[0] - pa[0], dy = pb[1] - pa[1], dz = pb[2] - pa[2];
                 const double l2 = dx * dx + dy * dy + dz * dz;
-                if (l2 > 0.0) { len += __builtin_sqrt(l2); ++nlen; }
+                if (l2 > 0.0) { len2 += l2; ++nlen; }
             }
-            const double h = nlen ? 0.25 * len / nlen : 0.0;
+            const double h = nlen ? 0.25 * __builtin_sqrt(len2 / nlen) : 0.0;
             if (h > 0.0 && h < 1e300 && nf > 1) {
                 int nb[3];
                 for (int a = 0; a < 3; ++a) {
@@ -276,8 +309,16 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
                 int nk = 0;
                 for (int j = 0; j < nj; ++j)
                     if ((cb[j] & 7) != 7) ids[nk++] = j;
-                for (int ax = 0; ax < 6; ++ax) {
+                /* the sweep along the longest extent first (most bins slowest): it usually wins, and the
+                 * others then give up early against its cost */
+                int first_ax = 0;
+                for (int ax = 1; ax < 6; ++ax) {
+                    const int *A = axes[ax], *F = axes[first_ax];
+                    if (nb[A[0]] > nb[F[0]] || (nb[A[0]] == nb[F[0]] && nb[A[1]] > nb[F[1]])) first_ax = ax;
+                }
+                for (int i = 0; i < (effort >= 2 ? 6 : (effort == 1 ? 1 : 0)); ++i) {
                     /* lexicographic by (axis 0, axis 1, axis 2, joint id): three stable passes, last key first */
+                    const int ax = i == 0 ? first_ax : (i <= first_ax ? i - 1 : i);
                     const int *A = axes[ax];
                     counting_pass(ids, cand, nk, bins + A[2], 3, nb[A[2]], count);
                     counting_pass(cand, sc.order, nk, bins + A[1], 3, nb[A[1]], count);
@@ -289,7 +330,7 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
                                 cand[k] = cand[nk - 1 - k];
                                 cand[nk - 1 - k] = t;
                             }
-                        c = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin);
+                        c = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin, best);
                         if (c < best) {
                             best = c; best_id = 2 + 2 * ax + rev;
                             for (int k = 0; k < nf; ++k) p[k] = cand[k];
@@ -300,7 +341,7 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
             for (int k = nj; k < nJ_max; ++k) p[k] = k;
             if (choice) choice[b] = best_id;
         }
-        free(sc.start); free(sc.adj); free(sc.deg); free(sc.level); free(sc.queue); free(sc.order); free(sc.tmp);
+        scratch_free(&sc);
         free(cand); free(ids); free(newidx); free(c0); free(c1); free(cmin); free(rcm); free(bins); free(count);
     }
     return rc;

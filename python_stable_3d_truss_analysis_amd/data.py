@@ -373,23 +373,43 @@ def _dense_from_truss(truss):
 
 def dataset_chunks(n_samples, rank=0, world=1, chunk=16384, seed=0, numCubeRange=(8, 190), gridRange=(6, 6, 6),
                    fixedMemberType=None, taskType=TaskType.OPTIMIZATION, forceScale=1., displaceScale=1.,
-                   positionScale=1., device=None, reorder=True, **generator_args):
+                   positionScale=1., device=None, reorder=True, prefetch=True, **generator_args):
     """BASELINE config 5 as a generator: this rank's share of a dataset of `n_samples` random cube trusses,
     chunk by chunk - native generation (`generate_cube_batch`), both solves and the feature kernel on
     `device` (`feature_tensors_device`).  Yields `(first_index, packed, tensors)`; nothing larger than one
     chunk is ever held on the host.  The dataset is DEFINED by (seed, global sample index): any split into
     ranks and chunks produces the same samples (rank r owns the chunks r, r + world, ...).  One process per
-    GPU, no communication: run it under `torchrun` with rank / world from the environment, or in a loop."""
+    GPU, no communication: run it under `torchrun` with rank / world from the environment, or in a loop.
+    The native host work of the next chunk (generation, joint order) overlaps the GPU work of the current one."""
+    from concurrent.futures import ThreadPoolExecutor
+    from .batch import joint_order
     from .generate import generate_cube_batch
     n_chunks = (int(n_samples) + chunk - 1) // chunk
-    for k in range(rank, n_chunks, world):
+    mine = list(range(rank, n_chunks, world))
+
+    def host_side(k):   # native code (the GIL is released): generation and the joint order of chunk k
         first = k * chunk
         count = min(chunk, int(n_samples) - first)
         sizes = np.random.default_rng([int(seed), k]).integers(numCubeRange[0], numCubeRange[1] + 1, size=chunk)[:count]
         packed = generate_cube_batch(sizes, gridRange=gridRange, seed=seed, first_index=first, **generator_args)
-        tensors = feature_tensors_device(packed, fixedMemberType, taskType, forceScale, displaceScale,
-                                         positionScale, device, reorder)
-        yield first, packed, tensors
+        return first, packed, (joint_order(packed, reorder) if reorder is not False and reorder is not None else False)
+
+    def device_side(packed, order):
+        return feature_tensors_device(packed, fixedMemberType, taskType, forceScale, displaceScale,
+                                      positionScale, device, order)
+
+    if not prefetch:
+        for k in mine:
+            first, packed, order = host_side(k)
+            yield first, packed, device_side(packed, order)
+        return
+    # the host side of chunk k + 1 runs on a worker thread while the GPU works on chunk k
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        ahead = pool.submit(host_side, mine[0]) if mine else None
+        for i in range(len(mine)):
+            first, packed, order = ahead.result()
+            ahead = pool.submit(host_side, mine[i + 1]) if i + 1 < len(mine) else None
+            yield first, packed, device_side(packed, order)
 
 
 class TrussHeteroDataCreator:

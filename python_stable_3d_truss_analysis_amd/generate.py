@@ -23,6 +23,29 @@ GENLIB_PATH = os.path.join(_HERE, "libtrs_host.so")
 _gen = None
 
 
+def available_cpus():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup CPU quota (v2
+    `cpu.max`, v1 `cpu.cfs_quota_us`) when the container has one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, period = int(fq.read()), int(fp.read())
+                if q > 0 and period > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 def _load():
     global _gen
     if _gen is None:
@@ -35,6 +58,10 @@ def _load():
                                     P, P, P, P, P, P, P, P, P, P, ctypes.c_int64]
         lib.trs_cubegen_bounds.restype = I
         lib.trs_cubegen_bounds.argtypes = [I, I, I, I, I, P, P]
+        lib.trs_host_threads.restype = I
+        lib.trs_host_threads.argtypes = [I]
+        if "OMP_NUM_THREADS" not in os.environ:   # a team of every logical CPU is throttled under a CPU quota
+            lib.trs_host_threads(available_cpus())
         _gen = lib
     return _gen
 

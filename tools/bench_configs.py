@@ -69,7 +69,7 @@ def config4(out):
     out["config4"] = {"nPop": 1024, "generation_eval_s": dt, "fitness_evals_per_s": 1024 / dt}
 
 
-def config5(B, out):
+def config5(B, out, order=True):
     """Dataset sample = generate -> two batched solves (actual + fixed section) -> graph tensors.
     Host form: results downloaded, features formed on the host (graphfeat.c).  Device form: the two solves
     share one upload / reordering, the features are formed on the GPU (graphfeat.hip) and only float32
@@ -81,9 +81,9 @@ def config5(B, out):
     packed = gen.generate_cube_batch(rng.integers(8, 191, size=B), gridRange=(6, 6, 6), seed=11)
     t1 = time.perf_counter()
     fixed = MemberType(1., 1e7, 0.1)
-    gdata.solve_actual_and_prior(packed.take(np.arange(min(B, 256))), fixed, device="cuda:0", reorder=True)   # warm
+    gdata.solve_actual_and_prior(packed.take(np.arange(min(B, 256))), fixed, device="cuda:0", reorder=order)   # warm
     t2 = time.perf_counter()
-    actual, prior = gdata.solve_actual_and_prior(packed, fixed, device="cuda:0", reorder=True)
+    actual, prior = gdata.solve_actual_and_prior(packed, fixed, device="cuda:0", reorder=order)
     t3 = time.perf_counter()
     graphs = gdata.hetero_tensors_batch(packed, actual, prior, fixed.a, TaskType.REGRESSION)
     t4 = time.perf_counter()
@@ -92,10 +92,10 @@ def config5(B, out):
         "samples_per_s": B / ((t1 - t0) + (t3 - t2) + (t4 - t3)), "graphs": len(graphs),
         "info_nonzero": int((actual.info != 0).sum() + (prior.info != 0).sum())}
     del graphs, actual, prior
-    gdata.feature_tensors_device(packed.take(np.arange(min(B, 256))), fixed, TaskType.REGRESSION, reorder=True)
+    gdata.feature_tensors_device(packed.take(np.arange(min(B, 256))), fixed, TaskType.REGRESSION, reorder=order)
     torch.cuda.synchronize()
     t5 = time.perf_counter()
-    tensors = gdata.feature_tensors_device(packed, fixed, TaskType.REGRESSION, reorder=True)
+    tensors = gdata.feature_tensors_device(packed, fixed, TaskType.REGRESSION, reorder=order)
     torch.cuda.synchronize()
     t6 = time.perf_counter()
     host = {k: v.cpu() for k, v in tensors.items() if hasattr(v, "cpu") and k != "conn"}
@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--only", choices=("ga", "generator", "rcm", "profile", "dataset"), help="run one configuration only")
     ap.add_argument("--samples", type=int, default=16384, help="dataset samples of config 5")
     ap.add_argument("--slab-gb", type=int, default=48, help="stiffness-slab memory per launch pipeline")
+    ap.add_argument("--order", default="profile", choices=("profile", "fast", "rcm"), help="joint order of the dataset path")
     ap.add_argument("--bucket", type=int, default=64, help="size-bucket granularity (multiple of 64)")
     args = ap.parse_args()
     out = {}
@@ -124,7 +125,7 @@ def main():
     if args.only in (None, "generator"):
         config3(args.cubes, out, False, "config3_generator_order", args.slab_gb, args.bucket)
     if args.only in (None, "dataset"):
-        config5(args.samples, out)
+        config5(args.samples, out, args.order)
     if args.only in (None, "rcm"):
         config3(args.cubes, out, "rcm", "config3_rcm_order", args.slab_gb, args.bucket)
     if args.only in (None, "profile"):

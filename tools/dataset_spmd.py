@@ -19,6 +19,8 @@ from python_stable_3d_truss_analysis_amd.type import TaskType
 ap = argparse.ArgumentParser()
 ap.add_argument("--samples", type=int, default=131072)
 ap.add_argument("--chunk", type=int, default=16384)
+ap.add_argument("--no-prefetch", action="store_true")
+ap.add_argument("--order", default="profile", choices=("profile", "fast", "rcm"))
 args = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()}"
@@ -27,11 +29,11 @@ count, bad, bytes_down = 0, 0, 0
 for first, packed, tensors in data.dataset_chunks(args.samples, rank, world, args.chunk, seed=1, device=device,
                                                   fixedMemberType=MemberType(1., 1e7, 0.1),
                                                   taskType=TaskType.REGRESSION, forceScale=1e3, displaceScale=0.1,
-                                                  positionScale=100.):
+                                                  positionScale=100., reorder=args.order, prefetch=not args.no_prefetch):
     host = {k: v.cpu() for k, v in tensors.items() if hasattr(v, "cpu")}   # what a data loader would store
     bad += int(host["info"].sum())
     bytes_down += sum(v.numel() * v.element_size() for v in host.values())
     count += packed.B
 dt = time.perf_counter() - t0
 print(json.dumps({"rank": rank, "world": world, "samples": count, "seconds": dt, "samples_per_s": count / dt,
-                  "info_nonzero": bad, "downloaded_MB": bytes_down / 1e6}))
+                  "order": args.order, "prefetch": not args.no_prefetch, "info_nonzero": bad, "downloaded_MB": bytes_down / 1e6}))
