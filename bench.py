@@ -235,6 +235,11 @@ def main():
     ap.add_argument("--compact", action="store_true",
                     help="A/B: the stiffness matrix leaves the assembly as compact entry lists and the fused "
                          "factorisation forms the tiles from them (K_ff never dense in HBM) instead of the slab")
+    ap.add_argument("--joint-order", default="profile", choices=("profile", "rcm", "given"),
+                    help="numbering of the joints in the resident batch: 'profile' (default) = the cheapest of "
+                         "RCM and the coordinate sweeps (csrc/reorder.c, host, once per topology, outside the "
+                         "timed region like the upload); results are delivered in the GIVEN numbering either "
+                         "way (trs_recover's joint_out) and checked against the oracle in it")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than visible GPUs (ranks share devices round-robin; for testing "
                          "the multi-rank path on a 1-GPU box - the line then reports the devices really used)")
@@ -299,7 +304,8 @@ def main():
     if args.compact:
         from python_stable_3d_truss_analysis_amd import _capi
         _capi.check(_capi.load().trs_set_option(b"compact", 1), "trs_set_option")
-    dev = batch.DeviceBatch(packed, device, use_envelope=not args.dense)
+    order = False if args.joint_order == "given" or args.dense else args.joint_order
+    dev = batch.DeviceBatch(packed, device, use_envelope=not args.dense, reorder=order)
     n, nJ, nM = int(packed.n_free[0]), int(packed.nJ[0]), int(packed.nM[0])
 
     def step(events=None):
@@ -417,6 +423,7 @@ def main():
                 rec = json.load(fh)
             # the PMC pass is valid for the configuration AND the kernel sources it was taken on only
             if rec.get("envelope") == (not args.dense) and rec.get("batch") == args.batch and \
+                    rec.get("joint_order", "given") == (order or "given") and \
                     rec.get("source_sha") == kernel_source_sha() and rec.get("kernel") == potrf_kernel:
                 traffic = rec.get("hbm_bytes_per_launch")
         # Which roof bounds the factorisation: its arithmetic intensity (executed FLOP per byte of the
@@ -466,7 +473,9 @@ def main():
             "data": "synthetic: bundled bar-942 truss replicated as independent problems",
             "config": {"workload": f"{args.case} x {args.batch} independent copies per GPU "
                                    f"(nJ {nJ}, nM {nM}, n_free {n})",
-                       "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, no collective"},
+                       "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, no collective",
+                       "joint_order": (order or "given") + (" (host, once per topology, before the timed region; "
+                                                            "results in the given numbering)" if order else "")},
             "roofline": roofline,
             "stages_ms": stage_ms,
             "assemble_roofline": {"bound": "hbm", "achieved": asm_gbs, "peak": PEAK_HBM_GBS,

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define TRS_ABI_VERSION 4
+#define TRS_ABI_VERSION 5
 
 /* trs_assemble flags */
 #define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests); implies the slab form */
@@ -133,12 +133,17 @@ int trs_potrs_batched(int B, const int32_t *n_free, int ld, int slab_rows, const
  * vecF[~mask] = K[~mask,:] @ u (truss.py:348-349) and the member-force loop
  * (truss.py:354-359, Member.IsTension truss.py:89-91): u and f_ext are dense [nJ_max][3],
  * N[m] is the axial force, tension positive.  f_ext holds the applied load at free DOFs and
- * the stiffness reaction K u at constrained DOFs, as the reference's `external`. */
+ * the stiffness reaction K u at constrained DOFs, as the reference's `external`.
+ * joint_out (or NULL): [B][nJ_max], a permutation of 0..nJ_max-1 per truss - the results of joint j are
+ * written to row joint_out[b][j] of u / f_ext.  A caller who renumbered the joints for a narrower envelope
+ * (trs_profile_order, trs_host.h) passes the order it applied and receives the results in the ORIGINAL
+ * numbering with no extra pass (members keep their order, N is unaffected). */
 int trs_recover(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
                 const double *E, const double *A, const double *loads,
                 const int32_t *free_index, const int32_t *nJ, const int32_t *nM,
                 const double *uf, int ld_uf, double *u /* [B][nJ_max][3] */,
-                double *f_ext /* [B][nJ_max][3] */, double *N /* [B][nM_max] */, void *stream);
+                double *f_ext /* [B][nJ_max][3] */, double *N /* [B][nM_max] */,
+                const int32_t *joint_out /* [B][nJ_max] or NULL */, void *stream);
 
 /* Constraint reductions of the GA fitness (truss.py:166-168,429-462; ga.py:139-149):
  *   weight[b]   = sum_m A*L*rho
@@ -188,14 +193,15 @@ int trs_graph_features_dev(int B, int nJ_max, int nM_max, const double *xyz, con
 
 /* The whole Truss.Solve() pipeline (truss.py:329-364) on one stream: trs_solve_small when the batch
  * shape qualifies (the slab, uf, work and env arguments are then not touched), otherwise
- * dofmap -> assemble -> potrf -> potrs -> recover.  Workspace pointers as above. */
+ * dofmap -> assemble -> potrf -> potrs -> recover.  Workspace pointers as above; joint_out as in
+ * trs_recover (a batch with a joint_out never takes the fused small-system kernel). */
 int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound,
               const double *xyz, const int32_t *conn, const double *E, const double *A,
               const uint8_t *cbits, const double *loads, const int32_t *nJ, const int32_t *nM,
               int32_t *free_index, int32_t *n_free, int ld, int slab_rows, double *S,
               double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info,
               void *work, int32_t *env /* workspace for the envelope metadata, or NULL = dense */,
-              void *stream);
+              const int32_t *joint_out /* [B][nJ_max] or NULL */, void *stream);
 
 #ifdef __cplusplus
 }

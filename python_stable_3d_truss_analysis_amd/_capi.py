@@ -27,7 +27,7 @@ SIGNATURES = {
     "trs_assemble": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "trs_potrf_batched": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "trs_potrs_batched": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
-    "trs_recover": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "trs_recover": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "trs_fitness": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _P, _P, _P, _P]),
     "trs_solve_small_fits": (_I, [_I, _I, _I]),
     "trs_solve_small": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -35,11 +35,11 @@ SIGNATURES = {
     "trs_graph_features_dev": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D,
                                     _I, _P, _P, _P, _P, _P, _P]),
     "trs_solve": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
-                       _P, _P, _P, _P, _P, _P, _P]),
+                       _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 #: must equal TRS_ABI_VERSION of include/trs_solver.h
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

@@ -240,26 +240,42 @@ class DeviceBatch:
     """
     INPUT_FIELDS = ("xyz", "conn", "E", "A", "rho", "cbits", "loads", "nJ", "nM")
 
-    def __init__(self, packed: PackedBatch, device=None, use_envelope=True, use_small=True):
+    def __init__(self, packed: PackedBatch, device=None, use_envelope=True, use_small=True, reorder=False):
         """`use_envelope=False` treats every reduced stiffness matrix as dense (no tile skipping);
         `use_small=False` keeps a batch of small trusses off the fused single-kernel path
-        (`trs_solve_small`) and sends it through the staged pipeline."""
+        (`trs_solve_small`) and sends it through the staged pipeline; `reorder` (see `joint_order`) uploads
+        the trusses with their joints renumbered for a narrower envelope - the results still arrive in the
+        caller's numbering (`trs_recover` writes them through `joint_out`), so nothing else changes."""
         torch, dev = _require_gpu(device)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.packed = packed
-        self._setup(torch, dev, {f: up(getattr(packed, f)) for f in self.INPUT_FIELDS},
+        perm, resident = None, packed
+        wants = reorder is not False and reorder is not None
+        if wants and not (use_small and _capi.load().trs_solve_small_fits(packed.nJ_max, packed.nM_max, packed.n_max)):
+            perm = joint_order(packed, reorder)
+            resident = permute_joints(packed, perm)
+        self._setup(torch, dev, {f: up(getattr(resident, f)) for f in self.INPUT_FIELDS},
                     packed.B, packed.nJ_max, packed.nM_max, packed.n_max, use_envelope, use_small)
+        if perm is not None:
+            self.joint_out = up(perm)
 
     @classmethod
-    def from_device(cls, tensors, n_max, use_envelope=True, use_small=True):
+    def from_device(cls, tensors, n_max, use_envelope=True, use_small=True, joint_out=None):
         """A batch whose inputs already live on the device: `tensors` maps INPUT_FIELDS to contiguous
         device tensors of the padded shapes (see PackedBatch); `n_max` bounds the free DOFs per truss
-        (host-known, it sizes the slab)."""
+        (host-known, it sizes the slab); `joint_out` (int32 [B, nJ_max] on the device, or None): the
+        results of joint j go to row joint_out[b, j] (the joint order the caller applied to the inputs)."""
         torch, dev = _require_gpu(tensors["xyz"].device)
         self = cls.__new__(cls)
         self.packed = None
         self._setup(torch, dev, tensors, int(tensors["xyz"].shape[0]), int(tensors["xyz"].shape[1]),
                     int(tensors["conn"].shape[1]), int(n_max), use_envelope, use_small)
+        if joint_out is not None:
+            if self.small:
+                raise ValueError("a batch on the fused small-system path takes no joint order")
+            if tuple(joint_out.shape) != (self.B, self.nJ_max) or joint_out.dtype != torch.int32:
+                raise ValueError("joint_out must be int32 [B, nJ_max]")
+            self.joint_out = joint_out.contiguous()
         return self
 
     def _setup(self, torch, dev, tensors, B, nJ_max, nM_max, n_max, use_envelope, use_small=True):
@@ -280,6 +296,7 @@ class DeviceBatch:
         self.N = torch.empty([B, self.nM_max], dtype=torch.float64, device=dev)
         self.info = torch.empty([B], dtype=torch.int32, device=dev)
         self._slab = None   # (S, uf, work, env): the staged pipeline's workspace, allocated on first use
+        self.joint_out = None   # int32 [B, nJ_max]: where the results of (resident) joint j go, or None
 
     def _workspace(self):
         """Stiffness slab, reduced solution, assembly workspace and envelope metadata of the staged
@@ -338,7 +355,8 @@ class DeviceBatch:
             self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
             self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
             self.nJ.data_ptr(), self.nM.data_ptr(), self.uf.data_ptr(), self.rows, self.u.data_ptr(),
-            self.f_ext.data_ptr(), self.N.data_ptr(), self._stream()), "trs_recover")
+            self.f_ext.data_ptr(), self.N.data_ptr(),
+            self.joint_out.data_ptr() if self.joint_out is not None else None, self._stream()), "trs_recover")
 
     def _solve_small(self, fitness=None):
         """`trs_solve_small`: the whole of `Truss.Solve()` in one kernel (optionally with the GA
@@ -386,7 +404,8 @@ class DeviceBatch:
                 self.nJ.data_ptr(), self.nM.data_ptr(), self.free_index.data_ptr(),
                 self.n_free.data_ptr(), self.ld, self.rows, self.S.data_ptr(), self.uf.data_ptr(),
                 self.rows, self.u.data_ptr(), self.f_ext.data_ptr(), self.N.data_ptr(),
-                self.info.data_ptr(), self.work.data_ptr(), self._env_ptr(), self._stream()),
+                self.info.data_ptr(), self.work.data_ptr(), self._env_ptr(),
+                self.joint_out.data_ptr() if self.joint_out is not None else None, self._stream()),
                 "trs_solve")
 
     def fitness(self, allow_stress, allow_displace):
@@ -741,9 +760,10 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
     full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS}
     original = dict(full)   # the caller's joint order (the reordering below makes new tensors)
-    perm = None
+    perm32 = None
     if reorder is not False and reorder is not None:
-        perm = up(joint_order(packed, reorder)).long()                       # [B, nJ_max], joint k := old perm[k]
+        perm32 = up(joint_order(packed, reorder))                            # [B, nJ_max] int32, joint k := old perm[k]
+        perm = perm32.long()
         inverse = torch.empty_like(perm)
         inverse.scatter_(1, perm, torch.arange(nJ_max, device=dev).expand(B, -1))
         by_joint = perm[:, :, None].expand(-1, -1, 3)
@@ -767,17 +787,25 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
                      "N": z([B, nM_max], dtype=torch.float64, device=dev),
                      "info": z([B], dtype=torch.int32, device=dev)})
     joint_fields = ("xyz", "cbits", "loads")
+    lib = _capi.load()
     for idx in groups:
+        n_b = int(packed.n_free[idx].max()) if not whole else packed.n_max
         if whole:
             rows, nJ_b, nM_b = None, nJ_max, nM_max
-            sub = dict(full)
         else:
             rows = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(dev)
             nJ_b = max(1, int(packed.nJ[idx].max()))
             nM_b = max(1, int(packed.nM[idx].max()))
+        # a bucket of small trusses runs on the fused kernel, which takes no joint order (and gains
+        # nothing from one): it reads the caller's numbering
+        renumbered = perm32 is not None and not lib.trs_solve_small_fits(nJ_b, nM_b, n_b)
+        source = full if renumbered else original
+        if whole:
+            sub = dict(source)
+        else:
             sub = {}
             for f in DeviceBatch.INPUT_FIELDS:
-                t = full[f].index_select(0, rows)
+                t = source[f].index_select(0, rows)
                 if f in ("nJ", "nM"):
                     sub[f] = t
                 else:  # trimmed to the bucket's own maxima
@@ -785,7 +813,12 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
         own = (sub["A"], sub["E"]) if len(variants) > 1 else None
         if own is not None:   # the bucket's own sections survive the fixed-section solves
             sub["A"], sub["E"] = own[0].clone(), own[1].clone()
-        bucket = DeviceBatch.from_device(sub, int(packed.n_free[idx].max()) if not whole else packed.n_max)
+        # the bucket's kernels see the renumbered joints; trs_recover writes the results of joint k to the
+        # caller's row perm[k] (a real joint's target is a real joint, so the trimmed width holds it)
+        jout = None
+        if renumbered:
+            jout = perm32 if whole else perm32.index_select(0, rows)[:, :nJ_b].contiguous()
+        bucket = DeviceBatch.from_device(sub, n_b, joint_out=jout)
         for slot, sec in enumerate(variants):
             if sec is not None:
                 bucket.A.fill_(float(sec[0]))
@@ -805,13 +838,6 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
                 o["info"].index_copy_(0, rows, bucket.info)
         del bucket
     results = []
-    for o in outs:
-        u, f_ext = o["u"], o["f_ext"]
-        if perm is not None:  # back to the caller's joint numbering
-            by_joint = perm[:, :, None].expand(-1, -1, 3)
-            u = torch.zeros_like(u).scatter_(1, by_joint, u)
-            f_ext = torch.zeros_like(f_ext).scatter_(1, by_joint, f_ext)
-        o["u"], o["f_ext"] = u, f_ext
     if on_device:
         results = [DeviceResult(o["u"], o["f_ext"], o["N"], o["info"], original) for o in outs]
         return results[0] if sections is None else results

@@ -15,7 +15,7 @@ int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int
 int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, const int*, hipStream_t);
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, const int*, const double*, int, double*,
-                       double*, double*, hipStream_t);
+                       double*, double*, const int*, hipStream_t);
 void trs_recover_set_unstaged(int);
 int trs_solve_small_fits(int, int, int);
 int trs_solve_small_launch(int, int, int, int, const double*, const int*, const double*, const double*,
@@ -117,10 +117,10 @@ int trs_potrs_batched(int B, const int32_t* n_free, int ld, int slab_rows, const
 int trs_recover(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const double* E,
                 const double* A, const double* loads, const int32_t* free_index, const int32_t* nJ,
                 const int32_t* nM, const double* uf, int ld_uf, double* u, double* f_ext, double* N,
-                void* stream) {
+                const int32_t* joint_out, void* stream) {
     if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
     return trs_recover_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf,
-                              u, f_ext, N, (hipStream_t)stream);
+                              u, f_ext, N, joint_out, (hipStream_t)stream);
 }
 
 int trs_fitness(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const double* A,
@@ -136,8 +136,8 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
               const double* E, const double* A, const uint8_t* cbits, const double* loads,
               const int32_t* nJ, const int32_t* nM, int32_t* free_index, int32_t* n_free, int ld,
               int slab_rows, double* S, double* uf, int ld_uf, double* u, double* f_ext, double* N,
-              int32_t* info, void* work, int32_t* env, void* stream) {
-    if (g_small_path && trs_solve_small_fits(nJ_max, nM_max, n_max_bound))  // everything in one kernel
+              int32_t* info, void* work, int32_t* env, const int32_t* joint_out, void* stream) {
+    if (g_small_path && !joint_out && trs_solve_small_fits(nJ_max, nM_max, n_max_bound))  // everything in one kernel
         return trs_solve_small(B, nJ_max, nM_max, n_max_bound, xyz, conn, E, A, cbits, loads, nJ, nM, u,
                                f_ext, N, info, free_index, n_free, nullptr, 0.0, 0.0, nullptr, nullptr,
                                nullptr, stream);
@@ -152,7 +152,7 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
     rc = trs_potrs_batched(B, n_free, ld, slab_rows, S, uf, ld_uf, env, stream);
     if (rc) return rc;
     return trs_recover(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf, u,
-                       f_ext, N, stream);
+                       f_ext, N, joint_out, stream);
 }
 
 }  // extern "C"

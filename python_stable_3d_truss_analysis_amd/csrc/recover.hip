@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     const double* __restrict__ A, const double* __restrict__ loads,
     const int* __restrict__ free_index, const int* __restrict__ nJ, const int* __restrict__ nM,
     const int nJ_max, const int nM_max, const double* __restrict__ uf, const int ld_uf,
-    double* __restrict__ u_out, double* __restrict__ f_out, double* __restrict__ N_out) {
+    double* __restrict__ u_out, double* __restrict__ f_out, double* __restrict__ N_out,
+    const int* __restrict__ joint_out) {
     extern __shared__ double sh[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int joints = nJ[b];
@@ -68,10 +69,17 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     const int* fi = free_index + (size_t)b * ndof_max;
     const double* F = loads + (size_t)b * ndof_max;
     const double* ufb = uf + (size_t)b * ld_uf;
+    // joint_out (optional): results of joint j go to row joint_out[b][j] of u / f_ext - a batch whose joints
+    // were renumbered for a narrower envelope delivers its results in the caller's numbering at no cost.
+    // STAGED: the map is applied by the final copy out of LDS; otherwise u and f ARE the output arrays and
+    // every access goes through it.
+    const int* jo = joint_out ? joint_out + (size_t)b * nJ_max : nullptr;
+    auto J = [&](int j) { return (!STAGED && jo) ? jo[j] : j; };
     for (int d = tid; d < ndof_max; d += 256) {
         const int r = d < ndof ? fi[d] : -1;
-        u[d] = r >= 0 ? ufb[r] : 0.0;
-        f[d] = r >= 0 ? F[d] : 0.0;  // constrained: reaction accumulated below (load ignored)
+        const int o = 3 * J(d / 3) + d % 3;
+        u[o] = r >= 0 ? ufb[r] : 0.0;
+        f[o] = r >= 0 ? F[d] : 0.0;  // constrained: reaction accumulated below (load ignored)
     }
     if constexpr (STAGED)
         for (int j = tid; j < nJ_max; j += 256) cnt[j] = 0;
@@ -86,15 +94,15 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         if (m < members) {
             const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
             const MemberGeom g = member_geom(X, j0, j1);
-            axial = member_axial(g, E[mm] * A[mm], u, j0, j1);
+            axial = member_axial(g, E[mm] * A[mm], u, J(j0), J(j1));
             if constexpr (STAGED) {
                 if (constrained(j0)) atomicAdd(&cnt[j0], 1);
                 if (constrained(j1)) atomicAdd(&cnt[j1], 1);
             } else {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    if (fi[3 * j1 + a] < 0) atomicAdd(&f[3 * j1 + a], axial * g.c[a]);
-                    if (fi[3 * j0 + a] < 0) atomicAdd(&f[3 * j0 + a], -axial * g.c[a]);
+                    if (fi[3 * j1 + a] < 0) atomicAdd(&f[3 * J(j1) + a], axial * g.c[a]);
+                    if (fi[3 * j0 + a] < 0) atomicAdd(&f[3 * J(j0) + a], -axial * g.c[a]);
                 }
             }
         }
@@ -156,8 +164,9 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         }
         __syncthreads();
         for (int d = tid; d < ndof_max; d += 256) {
-            u_out[(size_t)b * ndof_max + d] = u[d];
-            f_out[(size_t)b * ndof_max + d] = d < ndof ? f[d] : 0.0;
+            const int o = jo ? 3 * jo[d / 3] + d % 3 : d;
+            u_out[(size_t)b * ndof_max + o] = u[d];
+            f_out[(size_t)b * ndof_max + o] = d < ndof ? f[d] : 0.0;
         }
     }
 }
@@ -220,14 +229,14 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
                                   const double* E, const double* A, const double* loads,
                                   const int* free_index, const int* nJ, const int* nM,
                                   const double* uf, int ld_uf, double* u, double* f_ext, double* N,
-                                  hipStream_t stream) {
+                                  const int* joint_out, hipStream_t stream) {
     if (B <= 0) return 0;
     // u, f_ext (doubles) + member-end tables (ints)
     const size_t lds = ((size_t)6 * nJ_max * sizeof(double) +
                         ((size_t)2 * nJ_max + 1 + 2 * (size_t)nM_max) * sizeof(int) + 15) / 16 * 16;
     if (lds > 160 * 1024 || g_recover_unstaged) {
         hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), 0, stream, xyz, conn, E, A, loads,
-                           free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N);
+                           free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out);
         return (int)hipGetLastError();
     }
     static const int lds_limit_set = (int)hipFuncSetAttribute(   // once per process, not per launch
@@ -235,7 +244,7 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
         160 * 1024);
     (void)lds_limit_set;
     hipLaunchKernelGGL(trs_recover_kernel<true>, dim3(B), dim3(256), lds, stream, xyz, conn, E, A, loads,
-                       free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N);
+                       free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out);
     return (int)hipGetLastError();
 }
 

@@ -460,6 +460,58 @@ def test_recover_without_lds_staging_matches(gpu):
     assert np.abs(got.external - ref.external).max() <= 1e-12 * np.abs(ref.external).max()
 
 
+def test_resident_batch_with_a_joint_order_delivers_results_in_the_given_numbering(gpu):
+    """`DeviceBatch(..., reorder=...)`: the kernels work on renumbered joints (narrower envelope), and
+    `trs_recover` writes u / f_ext through `joint_out` - the caller sees the given numbering.  Checked
+    against the goldens and against the batch solved in the given numbering, through `trs_solve` (one
+    call), through the separate stages, and on the recovery path without LDS staging."""
+    names = ["bar-942_input_0", "bar-120_input_0", "bar-47_input_0"]
+    datas = [H.load_json(nm) for nm in names] + [d for _, d, _ in H.ragged_cube_cases()]
+    z = H.dense_golden()
+    golds = [{k: z[f"{nm}/{k}"] for k in ("u", "f_ext", "N")} for nm in names] + \
+            [g for _, _, g in H.ragged_cube_cases()]
+    packed = gpu.pack_json(datas)
+    given = gpu.DeviceBatch(packed)
+    given.solve()
+    ref = given.result()
+    tiles = lambda dev: int((dev.env.cpu().numpy()[:, -dev.rows // 16:] - np.arange(dev.rows // 16)).clip(0).sum())
+    for order in ("profile", "rcm", "fast", gpu.profile_permutation(packed)):
+        dev = gpu.DeviceBatch(packed, reorder=order)
+        assert dev.joint_out is not None and dev.joint_out.dtype == dev.torch.int32
+        for how in ("one call", "stages", "unstaged recover"):
+            dev.u.fill_(float("nan")); dev.f_ext.fill_(float("nan"))
+            if how == "one call":
+                dev.solve()
+            else:
+                dev.lib.trs_set_option(b"recover_unstaged", int(how == "unstaged recover"))
+                try:
+                    dev.dofmap(); dev.assemble(); dev.potrf(); dev.potrs(); dev.recover()
+                    dev.torch.cuda.synchronize()
+                finally:
+                    dev.lib.trs_set_option(b"recover_unstaged", 0)
+            got = dev.result()
+            assert not got.info.any()
+            for b, (data, gold) in enumerate(zip(datas, golds)):
+                dim, nJ, nM = orc.truss_dim(data), len(data["joint"]), len(data["member"])
+                tag = (b, how, order if isinstance(order, str) else "array")
+                assert H.max_scaled_err(got.displace[b, :nJ, :dim], gold["u"]) <= TOL_FP64, tag
+                assert H.max_scaled_err(got.external[b, :nJ, :dim], gold["f_ext"]) <= TOL_FP64, tag
+                assert H.max_scaled_err(got.internal[b, :nM], gold["N"]) <= TOL_FP64, tag
+                assert not got.displace[b, nJ:].any() and not got.external[b, nJ:].any(), tag   # padding stays zero
+            assert H.max_scaled_err(got.displace, ref.displace) <= 1e-9
+        if isinstance(order, str) and order == "profile":
+            assert tiles(dev) < tiles(given)      # the point of it: fewer stored tiles
+    # a batch on the fused small-system path ignores the request (nothing to gain), from_device refuses it
+    small = gpu.DeviceBatch(gpu.pack_json([H.load_json("bar-25_input_0")]), reorder=True)
+    assert small.small and small.joint_out is None
+    small.solve()
+    assert not small.result().info.any()
+    with pytest.raises(ValueError):
+        gpu.DeviceBatch.from_device({f: getattr(small, f) for f in gpu.DeviceBatch.INPUT_FIELDS}, small.n_max,
+                                    joint_out=small.torch.zeros([1, small.nJ_max], dtype=small.torch.int32,
+                                                                device=small.device))
+
+
 def test_empty_batch_and_fully_constrained_truss(gpu):
     """Degenerate inputs: a batch of zero trusses, and a truss without free DOFs next to a normal one
     (the reference's solve of a 0 x 0 system gives zero displacements, forces and reactions)."""

@@ -3,7 +3,7 @@
 fingerprint of the kernel sources it was measured on (bench.kernel_source_sha): bench.py quotes the
 record as `roofline.traffic` only while the sources are unchanged.
 
-    python tools/make_traffic_record.py profiles/r02_xxx_pmc_summary.json <kernel name> [batch]
+    python tools/make_traffic_record.py profiles/r02_xxx_pmc_summary.json <kernel name> [batch] [joint order of the profiled run: profile | rcm | given]
 """
 import json
 import os
@@ -14,11 +14,11 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-def main(summary_path, kernel, batch=4096):
+def main(summary_path, kernel, batch=4096, joint_order="profile"):
     with open(summary_path) as fh:
         rec = json.load(fh)[kernel]
     pmc = rec["pmc_per_launch"]
-    out = {"kernel": kernel, "workload": f"bar-942 x {batch}", "envelope": True, "batch": int(batch),
+    out = {"kernel": kernel, "workload": f"bar-942 x {batch}", "envelope": True, "batch": int(batch), "joint_order": joint_order,
            "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "fetch_size_kib": pmc["FETCH_SIZE"],
            "write_size_kib": pmc["WRITE_SIZE"], "avg_ns": rec.get("avg_ns"),
            "source_sha": bench.kernel_source_sha(),
@@ -32,4 +32,4 @@ def main(summary_path, kernel, batch=4096):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
