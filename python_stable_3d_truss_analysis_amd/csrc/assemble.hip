@@ -118,6 +118,31 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     int* wgflag = rowdof + n_pad_max;                                // [4] [0]: this matrix leaves as entry lists
 
     // ---- phase 0 ---------------------------------------------------------------------------------------
+    // The end joints of a thread's first MR members stay in registers: three passes over the members need
+    // them (geometry, adjacency fill, rank sort) and each re-read would be another trip to L2 in a phase
+    // that is bound by exactly such latencies; the loads are issued here, ahead of the first barrier.
+    // (Hoisting the coordinate and E, A loads up here as well was tried and gained nothing: they only queue
+    // in front of the loads of the first pass.)
+    constexpr int MR = 3;
+    int cj0[MR], cj1[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const int m = tid + r * NT;
+        const size_t mm = (size_t)b * nM_max + (m < nM ? m : 0);
+        cj0[r] = m < nM ? conn[2 * mm] : 0;
+        cj1[r] = m < nM ? conn[2 * mm + 1] : 0;
+    }
+    auto for_members = [&](auto&& body) {  // body(m, j0, j1) for this thread's members
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const int m = tid + r * NT;
+            if (m < nM) body(m, cj0[r], cj1[r]);
+        }
+        for (int m = tid + MR * NT; m < nM; m += NT) {
+            const size_t mm = (size_t)b * nM_max + m;
+            body(m, conn[2 * mm], conn[2 * mm + 1]);
+        }
+    };
     const double* X = xyz + (size_t)b * 3 * nJ_max;
     const double* F = loads + (size_t)b * 3 * nJ_max;
     const int* fi_global = free_index + (size_t)b * 3 * nJ_max;
@@ -140,9 +165,8 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     if (!rank_sort)
         for (int x = tid * 2; x < TR * (WT + 16); x += 2 * NT) *reinterpret_cast<d2*>(T + x) = d2{0.0, 0.0};
     __syncthreads();
-    for (int m = tid; m < nM; m += NT) {
+    for_members([&](int m, int j0, int j1) {
         const size_t mm = (size_t)b * nM_max + m;
-        const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
         double d[3], len2 = 0.0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -155,7 +179,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         for (int a = 0; a < 3; ++a) mc[3 * m + a] = d[a] / len;  // truss.py:60-63
         atomicAdd(&cnt[j0], 1);
         atomicAdd(&cnt[j1], 1);
-    }
+    });
     __syncthreads();
     if (tid < 64) {  // exclusive scan of cnt by one wave, 64 joints per step
         int base = 0;
@@ -175,17 +199,13 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     }
     for (int j = tid; j < nJ; j += NT) fill[j] = 0;
     __syncthreads();
-    for (int m = tid; m < nM; m += NT) {
-        const size_t mm = (size_t)b * nM_max + m;
-        const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
+    for_members([&](int m, int j0, int j1) {
         unsorted[start[j0] + atomicAdd(&fill[j0], 1)] = ((unsigned)j1 << 16) | (unsigned)m;
         unsorted[start[j1] + atomicAdd(&fill[j1], 1)] = ((unsigned)j0 << 16) | (unsigned)m;
-    }
+    });
     __syncthreads();
     if (rank_sort) {
-        for (int m = tid; m < nM; m += NT) {
-            const size_t mm = (size_t)b * nM_max + m;
-            const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
+        for_members([&](int m, int j0, int j1) {
             const unsigned k0 = ((unsigned)j1 << 16) | (unsigned)m, k1 = ((unsigned)j0 << 16) | (unsigned)m;
             const int s0 = start[j0], s1 = start[j1], d0 = cnt[j0], d1 = cnt[j1];
             int r0 = 0, r1 = 0;
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 for (int i = 0; i < d1; ++i) r1 += unsorted[s1 + i] < k1 ? 1 : 0;
                 adj[s1 + r1] = k1;
             }
-        }
+        });
         __syncthreads();
         for (int x = tid * 2; x < TR * (WT + 16); x += 2 * NT) *reinterpret_cast<d2*>(T + x) = d2{0.0, 0.0};
     }
