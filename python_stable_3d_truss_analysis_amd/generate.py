@@ -188,7 +188,7 @@ def GenerateRandomCubeTrusses(gridRange=(5, 5, 5), numCubeRange=(5, 5), numEachR
         trusses.append(truss)
     if isDoStructuralAnalysis:
         from .batch import solve_batch
-        res = solve_batch(trusses)
+        res = solve_batch(trusses, reorder=True)   # generator order is far from banded
         for b, truss in enumerate(trusses):
             if int(res.info[b]) != 0:
                 raise np.linalg.LinAlgError("Singular matrix")
