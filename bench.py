@@ -308,8 +308,13 @@ def main():
     dev = batch.DeviceBatch(packed, device, use_envelope=not args.dense, reorder=order)
     n, nJ, nM = int(packed.n_free[0]), int(packed.nJ[0]), int(packed.nM[0])
 
-    def step(events=None):
+    def step(events=None, potrf_events=None):
         calls = (dev.dofmap, dev.assemble, dev.potrf, dev.potrs, dev.recover)
+        if potrf_events is not None:   # the timed step: the stages one by one, events around the dominant kernel
+            dev.dofmap(); dev.assemble()
+            potrf_events[0].record(); dev.potrf(); potrf_events[1].record()
+            dev.potrs(); dev.recover()
+            return
         if events is None:
             dev.solve()
             return
@@ -320,15 +325,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # events are recorded on torch's current stream, which is the stream the C ABI launches on
-    all_events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                   for _ in STAGES] for _ in range(args.steps)]
+    # Events are recorded on torch's current stream, which is the stream the C ABI launches on.  The TIMED
+    # steps carry two events each, around the factorisation (roofline.avg_launch_ms); an event pair around
+    # every stage costs 2.5 % of the step (tools/event_overhead.py), so the per-stage breakdown comes from an
+    # equal number of instrumented steps right after the timed region.
+    new_event = lambda: torch.cuda.Event(enable_timing=True)
+    potrf_events = [(new_event(), new_event()) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(all_events[k])
+        step(potrf_events=potrf_events[k])
     barrier()
     elapsed = time.perf_counter() - t0
+    all_events = [[(new_event(), new_event()) for _ in STAGES] for _ in range(args.steps)]
+    for k in range(args.steps):
+        step(all_events[k])
+    torch.cuda.synchronize(device)
 
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64,
@@ -338,6 +350,7 @@ def main():
 
     stage_ms = {s: float(np.mean([all_events[k][i][0].elapsed_time(all_events[k][i][1])
                                   for k in range(args.steps)])) for i, s in enumerate(STAGES)}
+    potrf_ms_timed = float(np.mean([e0.elapsed_time(e1) for e0, e1 in potrf_events]))
     res = dev.result()
 
     # reference point outside the timed region (rank 0): the same kernels with the envelope switched
@@ -352,6 +365,22 @@ def main():
         e0.record(); dense.potrf(); e1.record(); torch.cuda.synchronize(device)
         dense_ms = e0.elapsed_time(e1)
         del dense
+
+    # informational: the same timed loop with the joints in the numbering the data came in (rank 0, N = 1)
+    given = None
+    if world == 1 and order and not args.no_dense_ref:
+        plain = batch.DeviceBatch(packed, device, use_envelope=True)
+        for _ in range(args.warmup):
+            plain.solve()
+        torch.cuda.synchronize(device)
+        t0g = time.perf_counter()
+        for _ in range(args.steps):
+            plain.solve()
+        torch.cuda.synchronize(device)
+        dtg = time.perf_counter() - t0g
+        given = {"value": args.batch * args.steps / dtg, "unit": "solves/s", "ms_per_step": dtg / args.steps * 1e3,
+                 "note": "the same batch resident in the given joint numbering (--joint-order given as the headline)"}
+        del plain
 
     # informational: the same step fed from / drained to page-locked host memory over PCIe, upload of the
     # next batch, solve and download of the previous one overlapped on three streams (batch.StreamedSolver)
@@ -383,7 +412,7 @@ def main():
 
     if rank == 0:
         total_trusses = world * args.batch * args.steps
-        potrf_s = stage_ms["potrf"] * 1e-3
+        potrf_s = potrf_ms_timed * 1e-3   # the dominant kernel, measured inside the timed region
         potrf_kernel = "trs_potrf_kernel"
         if dev.env is not None:
             env = dev.env[0].cpu().numpy()
@@ -433,7 +462,7 @@ def main():
         intensity = tile_flops / potrf_bytes
         balance = PEAK_FP64_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
         mfma_frac, hbm_frac = achieved_tflops / PEAK_FP64_TFLOPS, potrf_gbs / PEAK_HBM_GBS
-        roofline = {"kernel": potrf_kernel, "traffic": traffic, "avg_launch_ms": stage_ms["potrf"],
+        roofline = {"kernel": potrf_kernel, "traffic": traffic, "avg_launch_ms": potrf_ms_timed,
                     "flop_per_truss": tile_flops, "bytes_per_truss": potrf_bytes,
                     "intensity_flop_per_byte": intensity, "machine_balance_flop_per_byte": balance,
                     "mfma": {"achieved": achieved_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
@@ -478,6 +507,9 @@ def main():
                                                             "results in the given numbering)" if order else "")},
             "roofline": roofline,
             "stages_ms": stage_ms,
+            "stages_ms_note": "event pairs around every stage, measured over an equal number of instrumented steps "
+                              "right after the timed region (the timed steps carry events around the factorisation "
+                              "only: roofline.avg_launch_ms)",
             "assemble_roofline": {"bound": "hbm", "achieved": asm_gbs, "peak": PEAK_HBM_GBS,
                                   "unit": "GB/s", "frac": asm_gbs / PEAK_HBM_GBS,
                                   "bytes_per_truss": counts["assemble_bytes"],
@@ -498,6 +530,8 @@ def main():
                 line["cube_batch"] = cube_batch_rate(device, args.cube_batch, torch, batch)
             except Exception as exc:  # informational only: never lose the headline line over it
                 line["cube_batch"] = {"error": repr(exc)}
+        if given is not None:
+            line["given_joint_order"] = given
         if dense_ms is not None:
             line["dense_mode_potrf"] = {
                 "avg_launch_ms": dense_ms,

@@ -221,7 +221,21 @@ __global__ __launch_bounds__(64 * PMW, 3) void trs_potrs_narrow_kernel(
     if (!trs_env_is_narrow(env)) return;  // trs_potrs_kernel's matrix
     double* us = sh + (size_t)wave * n_pad_max;
     double* ub = uf + (size_t)b * ld_uf;
-    for (int c = lane; c < npad; c += 64) us[c] = ub[c];  // y = L^-1 f
+    // y = L^-1 f into the wave's LDS strip, eight requests in flight (one at a time, each waited for, is a
+    // serial chain of eleven memory latencies at the start of every wave of the launch)
+    for (int c0 = 0; c0 < npad; c0 += 8 * 64) {
+        double yv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + 64 * i + lane;
+            yv[i] = c < npad ? ub[c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + 64 * i + lane;
+            if (c < npad) us[c] = yv[i];
+        }
+    }
     __builtin_amdgcn_wave_barrier();
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(S_all) + (size_t)b * slab_stride, 0, (int)(slab_stride * sizeof(double)), 0x00020000);
