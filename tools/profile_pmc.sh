@@ -8,7 +8,9 @@ ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-dense-ref --no-pcie --cube
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS > "$OUT/stats.log" 2>&1
+# the kernel-trace pass runs the default number of steps, so that the cold first launch does not weigh on the averages
+STATS_ARGS=${STATS_ARGS:---no-cpu-baseline --cpu-pool-seconds 0 --no-dense-ref --no-pcie --cube-batch 0}
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $STATS_ARGS > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INST_CYCLES_VMEM --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > "$OUT/pmc_write.log" 2>&1
