@@ -64,6 +64,20 @@ class PackedBatch:
         return PackedBatch(*(np.ascontiguousarray(getattr(self, f)[index])
                              for f in self.__dataclass_fields__))
 
+    def pinned(self):
+        """The same batch in page-locked host memory (one copy; needs the GPU runtime): `solve_batch`
+        then uploads it by DMA at the full PCIe rate instead of through the driver's bounce buffers.
+        The arrays are numpy views of pinned torch tensors, which they keep alive."""
+        import torch
+        fields = []
+        for f in self.__dataclass_fields__:
+            a = np.ascontiguousarray(getattr(self, f))
+            t = torch.empty(a.shape, dtype=torch.from_numpy(a[:0].copy()).dtype, pin_memory=True)
+            v = t.numpy()
+            v[...] = a
+            fields.append(v)
+        return PackedBatch(*fields)
+
     def trimmed(self):
         """The same batch with the joint / member padding cut to this batch's own maxima."""
         jm = max(1, int(self.nJ.max(initial=1)))
@@ -252,7 +266,7 @@ class DeviceBatch:
         perm, resident = None, packed
         wants = reorder is not False and reorder is not None
         if wants and not (use_small and _capi.load().trs_solve_small_fits(packed.nJ_max, packed.nM_max, packed.n_max)):
-            perm = joint_order(packed, reorder)
+            perm = joint_order(packed, "profile" if reorder is True else reorder)   # found once: every candidate
             resident = permute_joints(packed, perm)
         self._setup(torch, dev, {f: up(getattr(resident, f)) for f in self.INPUT_FIELDS},
                     packed.B, packed.nJ_max, packed.nM_max, packed.n_max, use_envelope, use_small)
@@ -573,19 +587,20 @@ def profile_permutation(packed: PackedBatch, return_choice=False, effort=2):
 
 
 def joint_order(packed: PackedBatch, reorder):
-    """The permutation `solve_batch(..., reorder=...)` applies: True / "profile" = `profile_permutation`
-    (every candidate), "fast" = the same with one coordinate sweep instead of six (80 % of the gain for
-    half the host time), "rcm" = `rcm_permutation`; an int32 array [B, nJ_max] found earlier (e.g. on
-    another thread) passes through."""
+    """The permutation `solve_batch(..., reorder=...)` applies: "profile" = `profile_permutation` with every
+    candidate (what a RESIDENT batch wants: the order is found once, `DeviceBatch(reorder=True)`), True /
+    "fast" = the same with one coordinate sweep instead of six (80 % of the gain for half the host time:
+    what a host-in / host-out call wants, where finding the order is the longest step), "rcm" =
+    `rcm_permutation`; an int32 array [B, nJ_max] found earlier (e.g. on another thread) passes through."""
     if isinstance(reorder, np.ndarray):
         if reorder.shape != (packed.B, packed.nJ_max):
             raise ValueError(f"joint order of shape {reorder.shape}, expected {(packed.B, packed.nJ_max)}")
         return np.ascontiguousarray(reorder, dtype=np.int32)
-    if reorder == "fast":
+    if reorder is True or reorder == "fast":
         return profile_permutation(packed, effort=1)
     if reorder == "rcm":
         return rcm_permutation(packed)
-    if reorder is True or reorder == "profile":
+    if reorder == "profile":
         return profile_permutation(packed)
     raise ValueError(f"unknown joint order {reorder!r} (True, 'profile', 'fast', 'rcm' or a permutation array)")
 
@@ -729,17 +744,33 @@ def _solve_small_host(packed: PackedBatch, torch, dev, variants, on_device=False
     return results
 
 
+class ResultPool:
+    """Page-locked host buffers for the results of `solve_batch(..., pool=...)`, reused from call to call:
+    the download is one DMA per array instead of a copy into freshly page-faulted memory.  The arrays of a
+    returned `BatchResult` are views of the pool and stay valid until the pool serves another call."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def take(self, torch, key, shape, dtype):
+        buf = self._bufs.get(key)
+        if buf is None or tuple(buf.shape) != tuple(shape) or buf.dtype != dtype:
+            buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+            self._bufs[key] = buf
+        return buf
+
+
 def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False, sections=None,
-                on_device=False):
+                on_device=False, pool=None):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
 
     The packed inputs go up once; a ragged batch is bucketed by padded system size
     (`size_buckets`) and every bucket is gathered, solved and scattered back ON THE DEVICE
     (`index_select` / `index_copy_`), inputs trimmed to the bucket's own maxima; the dense results come
-    down once.  `reorder=True` (or "profile") renumbers the joints of every truss first, by the cheapest of
-    reverse Cuthill-McKee and twelve coordinate sweeps (`profile_permutation`; "rcm" = plain RCM; the
-    order is found on the host, natively; inputs are permuted and results mapped back on the device):
-    worth it when the trusses are not numbered along their long axis, e.g. generated cube trusses.
+    down once.  `reorder=True` renumbers the joints of every truss first, by the cheapest of reverse
+    Cuthill-McKee and coordinate sweeps (`joint_order`: True / "fast", "profile", "rcm"; the order is found
+    on the host, natively; inputs are permuted and results mapped back on the device): worth it when the
+    trusses are not numbered along their long axis, e.g. generated cube trusses.
 
     `sections=[None, (a, e, density), ...]` solves the same trusses several times - `None` with their
     own member sections, a triple with every member set to it (the "fixed member type" prior of the
@@ -747,7 +778,11 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     uploaded, reordered and bucketed once, only A and E change between the solves.
 
     `on_device=True` leaves the results on the GPU (`DeviceResult`, torch tensors in the caller's joint
-    order, plus the resident inputs) for device-side consumers such as the graph-feature kernel."""
+    order, plus the resident inputs) for device-side consumers such as the graph-feature kernel.
+
+    Host side of a large batch: the joint order is found on a worker thread while the inputs go up; a
+    `PackedBatch.pinned()` uploads by DMA; `pool=ResultPool()` downloads into reused page-locked buffers
+    (the returned arrays are then views of the pool, valid until its next use)."""
     packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
         else pack_trusses(list(trusses_or_packed))
     torch, dev = _require_gpu(device)
@@ -758,11 +793,23 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
         out = _solve_small_host(packed, torch, dev, variants, on_device)
         return out[0] if sections is None else out
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+    wants_order = reorder is not False and reorder is not None
+    ordering = None
+    if wants_order and not isinstance(reorder, np.ndarray) and B >= 1024:
+        # native code (the GIL is released): the order is found while the inputs go up
+        from concurrent.futures import ThreadPoolExecutor
+        worker = ThreadPoolExecutor(max_workers=1)
+        ordering = worker.submit(joint_order, packed, reorder)
     full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS}
     original = dict(full)   # the caller's joint order (the reordering below makes new tensors)
     perm32 = None
-    if reorder is not False and reorder is not None:
-        perm32 = up(joint_order(packed, reorder))                            # [B, nJ_max] int32, joint k := old perm[k]
+    if wants_order:
+        if ordering is not None:
+            host_perm = ordering.result()
+            worker.shutdown(wait=False)
+        else:
+            host_perm = joint_order(packed, reorder)
+        perm32 = up(host_perm)                                               # [B, nJ_max] int32, joint k := old perm[k]
         perm = perm32.long()
         inverse = torch.empty_like(perm)
         inverse.scatter_(1, perm, torch.arange(nJ_max, device=dev).expand(B, -1))
@@ -840,6 +887,17 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     results = []
     if on_device:
         results = [DeviceResult(o["u"], o["f_ext"], o["N"], o["info"], original) for o in outs]
+        return results[0] if sections is None else results
+    if pool is not None:   # one DMA per array into the pool's page-locked buffers
+        host = []
+        for slot, o in enumerate(outs):
+            h = {k: pool.take(torch, (slot, k), v.shape, v.dtype) for k, v in o.items()}
+            for k, v in o.items():
+                h[k].copy_(v, non_blocking=True)
+            host.append(h)
+        torch.cuda.synchronize(dev)
+        for h in host:
+            results.append(BatchResult(h["u"].numpy(), h["f_ext"].numpy(), h["N"].numpy(), h["info"].numpy()))
         return results[0] if sections is None else results
     torch.cuda.synchronize(dev)
     for o in outs:

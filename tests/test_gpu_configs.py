@@ -142,6 +142,31 @@ def test_config3_full_batch_65536_random_cube_trusses():
         assert H.max_scaled_err(other.internal, res.internal[::64, :other.internal.shape[1]]) <= 1e-7, order
 
 
+def test_pinned_inputs_and_result_pool_give_the_same_results():
+    """`PackedBatch.pinned()` + `solve_batch(..., pool=ResultPool())`: DMA upload, download into reused
+    page-locked buffers, joint order found on a worker thread - bitwise the results of the plain call."""
+    from python_stable_3d_truss_analysis_amd import batch
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    rng = np.random.default_rng(3)
+    packed = gen.generate_cube_batch(rng.integers(8, 191, size=2048), gridRange=(6, 6, 6), seed=5)
+    plain = batch.solve_batch(packed, reorder=True)
+    pool = batch.ResultPool()
+    pinned = packed.pinned()
+    for f in ("xyz", "conn", "E", "A", "cbits", "loads", "nJ", "nM", "n_free"):
+        np.testing.assert_array_equal(getattr(pinned, f), getattr(packed, f))
+    for _ in range(2):                      # the second call reuses the pool's buffers
+        got = batch.solve_batch(pinned, reorder=True, pool=pool)
+        for k in ("displace", "external", "internal", "info"):
+            np.testing.assert_array_equal(getattr(got, k), getattr(plain, k))
+    # two solves of one call land in two buffers of the pool (the generator's members all have the section
+    # (1, 1e7, 0.1), so doubling the area halves the displacements and leaves the member forces alone)
+    two = batch.solve_batch(pinned, reorder="rcm", pool=pool, sections=[None, (2.0, 1e7, 0.1)])
+    assert not two[0].info.any() and not two[1].info.any()
+    assert H.max_scaled_err(two[0].displace, plain.displace) <= 1e-8
+    assert H.max_scaled_err(2.0 * two[1].displace, two[0].displace) <= 1e-8
+    assert H.max_scaled_err(two[1].internal, two[0].internal) <= 1e-8
+
+
 # ---- config 5: dataset generation sharded over worker processes, HeteroData-shaped tensors -------------
 
 def test_config5_dataset_16384_samples_through_the_sharded_entry_point():

@@ -18,5 +18,13 @@ for reorder in (False, True):
         dt = time.perf_counter() - t0
         print(f"reorder={reorder}, {attempt}: {dt:.3f} s end to end = {B / dt:.0f} solves/s, "
               f"info_nonzero={int((res.info != 0).sum())}")
-cProfile.run("batch.solve_batch(packed, reorder=True)", "/tmp/e2e.prof")
+pinned, pool = packed.pinned(), batch.ResultPool()
+for reorder in (True, "fast", "rcm"):
+    for attempt in ("first call (pool allocation)", "second call", "third call"):
+        t0 = time.perf_counter()
+        res = batch.solve_batch(pinned, reorder=reorder, pool=pool)
+        dt = time.perf_counter() - t0
+        print(f"pinned inputs + result pool, reorder={reorder}, {attempt}: {dt:.3f} s end to end = {B / dt:.0f} solves/s, "
+              f"info_nonzero={int((res.info != 0).sum())}")
+cProfile.run("batch.solve_batch(pinned, reorder=True, pool=pool)", "/tmp/e2e.prof")
 pstats.Stats("/tmp/e2e.prof").sort_stats("cumtime").print_stats(14)
