@@ -10,7 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from python_stable_3d_truss_analysis_amd import batch, generate as gen
+from python_stable_3d_truss_analysis_amd import _capi, batch, generate as gen
+if os.environ.get("TRS_LIB_VARIANT"):  # A/B builds of tools/build_variants.sh
+    _capi.LIB_PATH = os.path.join(ROOT, "python_stable_3d_truss_analysis_amd", "variants",
+                                  f"libtrs_{os.environ['TRS_LIB_VARIANT']}.so")
 import bench
 
 ap = argparse.ArgumentParser()
