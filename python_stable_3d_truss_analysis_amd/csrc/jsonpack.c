@@ -118,6 +118,69 @@ static double number(cur_t *c) {
             }
         }
     }
+#if defined(__x86_64__) && defined(__SIZEOF_LONG_DOUBLE__) && __LDBL_MANT_DIG__ == 64
+    {   /* second path (exact, with a guard): up to 19 significant digits - what repr() of a Python float
+           prints (16-17) - and a power of ten up to 10^27.  The integer mantissa (< 2^64) and 10^|p| (5^27 <
+           2^63) are exact in the x87 extended format, so their product or quotient carries ONE rounding, to 64
+           bits; rounding that to 53 bits is the correctly rounded double unless the eleven dropped bits sit
+           within one unit of the half-way pattern - then (3 cases in 2048) strtod below decides. */
+        static const long double LPOW10[28] = {1e0L,  1e1L,  1e2L,  1e3L,  1e4L,  1e5L,  1e6L,  1e7L,  1e8L,  1e9L,
+                                               1e10L, 1e11L, 1e12L, 1e13L, 1e14L, 1e15L, 1e16L, 1e17L, 1e18L, 1e19L,
+                                               1e20L, 1e21L, 1e22L, 1e23L, 1e24L, 1e25L, 1e26L, 1e27L};
+        const char *q = c->p;
+        int neg = 0, digits = 0, frac = 0, seen_dot = 0, ok = 1, any = 0;
+        uint64_t mant = 0;
+        if (q < c->end && *q == '-') {
+            neg = 1;
+            ++q;
+        }
+        while (q < c->end && ((*q >= '0' && *q <= '9') || (*q == '.' && !seen_dot))) {
+            if (*q == '.') {
+                seen_dot = 1;
+            } else {
+                if (mant || *q != '0') ++digits;
+                if (digits > 19) {
+                    ok = 0;
+                    break;
+                }
+                mant = mant * 10 + (uint64_t)(*q - '0');
+                frac += seen_dot;
+                any = 1;
+            }
+            ++q;
+        }
+        if (ok && any) {
+            int ex = 0;
+            if (q < c->end && (*q == 'e' || *q == 'E')) {
+                const char *e = q + 1;
+                int eneg = 0, ed = 0;
+                if (e < c->end && (*e == '-' || *e == '+')) eneg = *e++ == '-';
+                while (e < c->end && *e >= '0' && *e <= '9' && ed < 4) {
+                    ex = ex * 10 + (*e++ - '0');
+                    ++ed;
+                }
+                if (ed == 0 || (e < c->end && *e >= '0' && *e <= '9')) ok = 0;
+                ex = eneg ? -ex : ex;
+                q = e;
+            }
+            const int p10 = ex - frac;
+            const int ch = q < c->end ? *q : ',';
+            if (ok && mant != 0 && p10 >= -27 && p10 <= 27 &&
+                (ch == ',' || ch == ']' || ch == '}' || ch == ' ' || ch == '\n')) {
+                long double w = (long double)mant;
+                w = p10 < 0 ? w / LPOW10[-p10] : w * LPOW10[p10];
+                uint64_t sig;
+                memcpy(&sig, &w, sizeof sig);  /* x87 extended: bytes 0-7 = the 64-bit significand */
+                const unsigned low = (unsigned)(sig & 0x7ffu);
+                if ((low < 0x3ffu || low > 0x401u) && w > 1e-290L && w < 1e290L) {
+                    const double v = (double)w;
+                    c->p = q;
+                    return neg ? -v : v;
+                }
+            }
+        }
+    }
+#endif
     char buf[64];
     size_t n = 0;
     while (c->p + n < c->end && n < sizeof buf - 1) {

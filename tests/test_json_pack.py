@@ -77,3 +77,29 @@ def test_unreadable_file_is_reported(tmp_path):
     path.write_text(json.dumps(H.load_json("bar-6_input_0")))
     with pytest.raises(ValueError, match="#1: file cannot be read"):
         batch.pack_json_files([str(path), str(tmp_path / "missing.json")])
+
+
+def test_numbers_are_parsed_exactly_like_python_including_rounding_boundaries():
+    """Every float text -> the same double as Python's float(): short decimals (first fast path), 16-19
+    digit texts as repr() prints them (extended-precision path with its guard band), texts within a hair
+    of a rounding boundary, and magnitudes outside either fast path (strtod)."""
+    from fractions import Fraction
+    rng = np.random.default_rng(11)
+    texts_of = []
+    bits = rng.integers(0x0010000000000000, 0x7fe0000000000000, size=6000, dtype=np.uint64)
+    texts_of += [repr(float(v)) for v in bits.view(np.float64)]                      # the whole normal range
+    texts_of += [repr(float(v)) for v in rng.uniform(-500, 500, 20000)]              # what a geometry file holds
+    texts_of += [repr(float(v)) for v in rng.normal(0, 1, 6000) * 10.0 ** rng.integers(-25, 25, 6000)]
+    texts_of += ["0.1", "62.5", "1e7", "-0.0", "123456789012345678", "1e-320", "1.7976931348623157e308", "5e-324"]
+    for a in rng.uniform(1, 10, 4000):                                               # 19 digits around a midpoint
+        f = float(a)
+        mid = (Fraction(f) + Fraction(float(np.nextafter(f, 100)))) / 2
+        d = str(int(mid * 10 ** 18))
+        texts_of += [d[0] + "." + d[1:], d[0] + "." + d[1:-1] + str((int(d[-1]) + 1) % 10)]
+    n = len(texts_of) // 500 * 500
+    docs = ['{"joint":[%s],"force":[],"member":[]}' % ",".join('[[%s,0.0,0.0],"PIN"]' % t for t in texts_of[i:i + 500])
+            for i in range(0, n, 500)]
+    got = batch.pack_json_texts(docs).xyz[:, :, 0].ravel()
+    want = np.array([float(t) for t in texts_of[:n]])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
