@@ -800,7 +800,10 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
         from concurrent.futures import ThreadPoolExecutor
         worker = ThreadPoolExecutor(max_workers=1)
         ordering = worker.submit(joint_order, packed, reorder)
-    full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS}
+    # the densities play no part in the solve (weights and graph features only): they go up for on-device
+    # consumers; otherwise the field is not transferred at all (a fifth of the upload of a cube-truss batch)
+    needs_rho = on_device
+    full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS if f != "rho" or needs_rho}
     original = dict(full)   # the caller's joint order (the reordering below makes new tensors)
     perm32 = None
     if wants_order:
@@ -852,11 +855,15 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
         else:
             sub = {}
             for f in DeviceBatch.INPUT_FIELDS:
+                if f not in source:
+                    continue
                 t = source[f].index_select(0, rows)
                 if f in ("nJ", "nM"):
                     sub[f] = t
                 else:  # trimmed to the bucket's own maxima
                     sub[f] = t[:, :(nJ_b if f in joint_fields else nM_b)].contiguous()
+        if "rho" not in sub:
+            sub["rho"] = sub["A"]   # placeholder of the right shape: no kernel of the solve reads it
         own = (sub["A"], sub["E"]) if len(variants) > 1 else None
         if own is not None:   # the bucket's own sections survive the fixed-section solves
             sub["A"], sub["E"] = own[0].clone(), own[1].clone()
