@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--dense", action="store_true", help="no envelope tile skipping")
     ap.add_argument("--fused", action="append", default=[],
                     help="tags (repeatable) that run with trs_set_option('compact', 1): compact entry lists + fused factorisation")
+    ap.add_argument("--option", action="append", default=[],
+                    help="tag:name=value (repeatable): trs_set_option(name, value) while that tag runs, 0 otherwise")
     args = ap.parse_args()
     with open(os.path.join(ROOT, "tests", "golden", "data", args.case + ".json")) as fh:
         data = json.load(fh)
@@ -48,15 +50,24 @@ def main():
     stages = ("dofmap", "assemble", "potrf", "potrs", "recover")
     times = {t: {s: [] for s in stages} for t in args.tags}
     ref_u = None
+    options = {}
+    for spec in args.option:
+        tag, kv = spec.split(":")
+        name, value = kv.split("=")
+        options.setdefault(tag, []).append((name.encode(), int(value)))
     for rnd in range(args.rounds + 1):
         for tag in args.tags:
             dev.lib = libs[tag]
+            for name, value in options.get(tag, []):
+                assert libs[tag].trs_set_option(name, value) == 0, name
             evs = []
             for s in stages:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); getattr(dev, s)(); e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
+            for name, _ in options.get(tag, []):
+                libs[tag].trs_set_option(name, 0)
             if rnd == 0:   # warm-up round + correctness
                 u = dev.u[0].cpu().numpy()
                 info = int(dev.info.abs().sum().item())
