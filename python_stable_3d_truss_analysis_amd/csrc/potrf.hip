@@ -756,7 +756,15 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
                                                                // tiles; the diagonal block's images use wlds
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    // Work-groups are dispatched in blockIdx order; the matrices are taken in DESCENDING order: trs_assemble
+    // wrote the highest-numbered trusses last, so their stiffness tiles are the ones still in the memory-side
+    // cache when this kernel starts, and the lowest-numbered ones are factored last - where
+    // trs_potrs_batched, which runs in ascending order, starts.
+#ifdef TRS_EXP_POTRF_ASCENDING
     const int b = blockIdx.x * MPW + wave;
+#else
+    const int b = ((int)gridDim.x - 1 - (int)blockIdx.x) * MPW + wave;
+#endif
     if (b >= B) return;  // no work-group barrier anywhere in this kernel: waves are independent
     const int npad = trs_round_up(n_free[b], TRS_NB);
     if (npad == 0) {
