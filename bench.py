@@ -422,6 +422,7 @@ def main():
             narrow = (slack & 0xff) == 1   # the kernel choice recorded by trs_assemble (csrc/trs_common.h)
             compact = bool(slack & 0x100)  # K_ff as compact entry lists, tiles formed in the factorisation
             rs = 4 if slack & 0x200 else 2  # items of four chunks for the wider ones of the narrow envelopes
+            substituted = bool(slack & 0x400)  # the factorising wave substituted as well (trs_common.h)
             potrf_kernel = ("trs_potrf_narrow_kernel<true, 2>" if compact else f"trs_potrf_narrow_kernel<false, {rs}>") \
                 if narrow else "trs_potrf_kernel"
             env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nchm]
@@ -439,7 +440,10 @@ def main():
                 counts["compact_list_bytes"] = lists
                 counts["assemble_bytes"] += lists - counts["slab_tile_bytes"]
                 counts["potrf_bytes"] += lists - counts["slab_tile_bytes"]
+            if substituted:  # one kernel does both stages: its bytes are those of both
+                counts["potrf_bytes"] += counts["potrs_bytes"]
         else:
+            substituted = False
             tile_flops = potrf_tile_flops(n)
             counts = algorithmic_counts(n, nJ, nM)
         dense_flops = algorithmic_counts(n, nJ, nM)["potrf_flops"]
@@ -471,7 +475,10 @@ def main():
                     "flop_model": "MFMA work inside the 16x16-tile envelope of K_ff (what the kernel "
                                   "executes; equals the dense tile count with --dense)",
                     "byte_model": "stiffness tiles inside the envelope (or their compact entry lists) read once, "
-                                  "factor tiles written once, load vector in / out (uf)",
+                                  "factor tiles written once, load vector in / out (uf)" +
+                                  ("; the same wave then substitutes: factor tiles read once more, y in, u out "
+                                   "(the trs_potrs launch finds nothing left to do)" if substituted else ""),
+                    "fused_substitution": substituted,
                     "dense_equivalent_tflops": dense_flops * args.batch / potrf_s / 1e12,
                     "dense_flop_per_truss": dense_flops}
         if intensity >= balance:
@@ -516,7 +523,10 @@ def main():
                                   "note": "bytes of the slab part that is stored (upper 16-row tiles inside the "
                                           "envelope + load column) + inputs; the full symmetric dense "
                                           f"figure of SURVEY 8d would be {counts['assemble_bytes_full_contract']} B"},
-            "potrs_roofline": hbm_stage("potrs", counts["potrs_bytes"]),
+            "potrs_roofline": ({"note": "substituted by the factorising wave: see roofline (its bytes are counted "
+                                        "there); the stage time is the launch that finds no work",
+                                "avg_launch_ms": stage_ms["potrs"]} if substituted
+                               else hbm_stage("potrs", counts["potrs_bytes"])),
             "recover_roofline": hbm_stage("recover", counts["recover_bytes"]),
             "info_nonzero": int((res.info != 0).sum()),
             "envelope": not args.dense,

@@ -66,6 +66,8 @@ int trs_abi_version(void);
  *   "compact"          0/1  1: trs_assemble leaves narrow-envelope matrices as compact entry lists and
  *                           trs_potrf_batched forms the tiles from them (see "Compact form" above);
  *                           0 (default): TRS_ASM_NO_COMPACT on every call, the matrix goes through the slab.
+ *   "fused_substitution" 1/0  the factorising wave of a narrow-envelope matrix substitutes it as well
+ *                           (default 1; see trs_potrf_batched).
  * Returns 0, or hipErrorInvalidValue for an unknown name. */
 int trs_set_option(const char *name, int value);
 
@@ -115,7 +117,13 @@ int trs_assemble(int B, int nJ_max, int nM_max,
  * column.  Replaces the factorisation half of np.linalg.solve (truss.py:343; LAPACK dgesv in
  * the reference, potrf here because K_ff is SPD for a stable truss).
  * info[b] = 0 on success, k > 0 when the pivot of column k (1-based) is not positive
- * (the reference raises numpy.linalg.LinAlgError for an exactly singular matrix). */
+ * (the reference raises numpy.linalg.LinAlgError for an exactly singular matrix).
+ * Fused substitution (default; trs_set_option("fused_substitution", 0) keeps the stages apart): the wave that
+ * factors a narrow-envelope matrix of at most 1024 rows goes straight on to the back substitution, while the
+ * factor's last panels are still cached.  uf[b] then holds the reduced DISPLACEMENTS when this call returns,
+ * bit 0x400 of the matrix's routing word in env says so, and trs_potrs_batched skips the matrix - callers who
+ * run the stages in order notice nothing.  Matrices with a failed pivot, wide envelopes, the dense mode and
+ * larger systems are substituted by trs_potrs_batched as before. */
 int trs_potrf_batched(int B, const int32_t *n_free, int ld, int slab_rows, double *S,
                       int32_t *info /* [B] */, const int32_t *env /* or NULL */,
                       const void *work /* the buffer trs_assemble filled */,

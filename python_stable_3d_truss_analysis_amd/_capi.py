@@ -75,6 +75,10 @@ def load():
         fn.argtypes = argtypes
     if lib.trs_abi_version() != ABI_VERSION:
         raise HipExtensionError("libtrs_hip.so ABI version mismatch")
+    # A/B runs of the tools: TRS_OPTIONS="name=value,name=value" -> trs_set_option at load time
+    for item in filter(None, os.environ.get("TRS_OPTIONS", "").split(",")):
+        name, _, value = item.partition("=")
+        check(lib.trs_set_option(name.strip().encode(), int(value)), f"TRS_OPTIONS: trs_set_option({name!r})")
     _lib = lib
     return lib
 

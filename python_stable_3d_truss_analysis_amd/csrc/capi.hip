@@ -17,6 +17,7 @@ int trs_recover_launch(int, int, int, const double*, const int*, const double*, 
                        const double*, const int*, const int*, const int*, const double*, int, double*,
                        double*, double*, const int*, hipStream_t);
 void trs_recover_set_unstaged(int);
+void trs_potrf_set_fused_substitution(int);
 int trs_solve_small_fits(int, int, int);
 int trs_solve_small_launch(int, int, int, int, const double*, const int*, const double*, const double*,
                            const uint8_t*, const double*, const int*, const int*, double*, double*, double*,
@@ -55,6 +56,10 @@ int trs_set_option(const char* name, int value) {
     }
     if (name != nullptr && strcmp(name, "compact") == 0) {
         g_compact = value != 0;
+        return 0;
+    }
+    if (name != nullptr && strcmp(name, "fused_substitution") == 0) {
+        trs_potrf_set_fused_substitution(value != 0);
         return 0;
     }
     return (int)hipErrorInvalidValue;

@@ -26,6 +26,7 @@
 // block runs as MFMAs with no data movement, and loads/stores of a tile are 128-byte
 // segments of S rows.
 #include "trs_common.h"
+#include "trs_subst.h"
 #include "trs_chol16.h"
 
 // Diagnostic builds only (-DTRS_POTRF_STAMPS via tools/build_variants.sh): per-phase wave-cycle
@@ -749,7 +750,7 @@ template <bool FUSED, int RSV>
 __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV > 2 ? 2 : TRS_NARROW_WAVES_PER_SIMD)) void trs_potrf_narrow_kernel(
     double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
     int* __restrict__ info, const int* __restrict__ env_all, const int n_pad_max, const int B,
-    const unsigned char* __restrict__ work, double* __restrict__ uf_all, const int ld_uf) {
+    const unsigned char* __restrict__ work, double* __restrict__ uf_all, const int ld_uf, const int substitute) {
     __shared__ ChScratch scratch[MPW];
     __shared__ double wlds[MPW][CT][256];  // per wave: inv(L_ss), s = 0..3, as A-fragments (PanelLds::W layout)
     __shared__ double kimg[FUSED ? MPW : 1][FUSED ? 512 : 1];  // per wave: image of an item's (up to two) stiffness
@@ -1011,6 +1012,17 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
     }
     st.flush();
     if (lane == 0) info[b] = bad_col;
+    // The substitution U u = y by the same wave, right behind its factorisation (trs_subst.h): the factor's last
+    // panels are still in the caches, the launch of trs_potrs_batched finds nothing left to do for this matrix,
+    // and the memory-bound substitution of one wave overlaps the issue-bound factorisation of its neighbours.
+    // The solution strip takes the place of the inv(L_ss) fragments (dead now): up to 1024 rows.
+    if (substitute != 0 && bad_col == 0 && npad <= CT * 256) {
+        trs_subst::narrow_substitute(S.rs, S.ld, npad, env.cend, Wl, uf_all + (size_t)b * ld_uf, ld_uf);
+        if (lane == 0) {
+            int* meta = const_cast<int*>(env.last) + n_pad_max / 64;
+            meta[0] = env.slack | TRS_ENV_SUBSTITUTED;
+        }
+    }
 }
 
 }  // namespace
@@ -1025,6 +1037,9 @@ extern "C" int trs_debug_stamps(unsigned long long* host_out, int reset) {
     return rc;
 }
 #endif
+
+static int g_fused_substitution = 1;  // trs_set_option("fused_substitution", 0 / 1)
+extern "C" void trs_potrf_set_fused_substitution(int on) { g_fused_substitution = on; }
 
 extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
                                 double* S, int* info, const int* env, const void* work, double* uf,
@@ -1041,15 +1056,15 @@ extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_st
         int rc = 0;
         if (compact_possible) {  // (the compact form is opt-in: no launch while it is switched off)
             hipLaunchKernelGGL((trs_potrf_narrow_kernel<true, 2>), grid, block, 0, stream, S, n_free, ld, slab_stride,
-                               info, env, n_pad_max, B, wk, uf, ld_uf);
+                               info, env, n_pad_max, B, wk, uf, ld_uf, g_fused_substitution);
             if ((rc = (int)hipGetLastError())) return rc;
         }
         hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 2>), grid, block, 0, stream, S, n_free, ld, slab_stride,
-                           info, env, n_pad_max, B, wk, uf, ld_uf);
+                           info, env, n_pad_max, B, wk, uf, ld_uf, g_fused_substitution);
         if ((rc = (int)hipGetLastError())) return rc;
         if (TRS_NARROW_RS4_ABOVE <= TRS_NARROW_MAX_BELOW) {  // (compile-time: see trs_common.h)
             hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 4>), grid, block, 0, stream, S, n_free, ld, slab_stride,
-                               info, env, n_pad_max, B, wk, uf, ld_uf);
+                               info, env, n_pad_max, B, wk, uf, ld_uf, g_fused_substitution);
             if ((rc = (int)hipGetLastError())) return rc;
         }
     }

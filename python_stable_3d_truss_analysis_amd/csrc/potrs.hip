@@ -8,6 +8,7 @@
 // depend on the solution, only the multiplications do: they are issued one block ahead, so the
 // serial chain over the blocks sees the triangle solves and not the memory latencies.
 #include "trs_common.h"
+#include "trs_subst.h"
 
 namespace {
 
@@ -203,94 +204,21 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
 // The solution lives in the wave's LDS strip (it starts as y).
 // ======================================================================================================
 constexpr int PMW = 4;    // matrices (waves) per work-group
-#ifndef TRS_POTRS_PTG
-#define TRS_POTRS_PTG 4
-#endif
-constexpr int PTG = TRS_POTRS_PTG;  // tiles in flight per group of loads
 __global__ __launch_bounds__(64 * PMW, 3) void trs_potrs_narrow_kernel(
     const double* __restrict__ S_all, const int* __restrict__ n_free, const int ld, const size_t slab_stride,
     double* __restrict__ uf, const int ld_uf, const int* __restrict__ env_all, const int n_pad_max, const int B) {
     extern __shared__ double sh[];  // [PMW][n_pad_max]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
     const int b = blockIdx.x * PMW + wave;
     if (b >= B) return;
     const int npad = trs_round_up(n_free[b], TRS_NB);
     if (npad == 0) return;
     const TrsEnv env = trs_env_of(env_all, b, n_pad_max);
-    if (!trs_env_is_narrow(env)) return;  // trs_potrs_kernel's matrix
-    double* us = sh + (size_t)wave * n_pad_max;
-    double* ub = uf + (size_t)b * ld_uf;
-    // y = L^-1 f into the wave's LDS strip, eight requests in flight (one at a time, each waited for, is a
-    // serial chain of eleven memory latencies at the start of every wave of the launch)
-    for (int c0 = 0; c0 < npad; c0 += 8 * 64) {
-        double yv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = c0 + 64 * i + lane;
-            yv[i] = c < npad ? ub[c] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = c0 + 64 * i + lane;
-            if (c < npad) us[c] = yv[i];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
+    if (!trs_env_is_narrow(env)) return;       // trs_potrs_kernel's matrix
+    if (trs_env_is_substituted(env)) return;   // the factorisation has substituted it already
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(S_all) + (size_t)b * slab_stride, 0, (int)(slab_stride * sizeof(double)), 0x00020000);
-    const unsigned loff = ((unsigned)lq * (unsigned)ld + (unsigned)li) * 8u;
-    const int rstep = ld * 32;  // four slab rows, bytes
-    auto tile = [&](d4& a, int c0, int i0, bool exists) {  // D-form tile; outside the envelope: zeros, no traffic
-        const unsigned vo = exists ? loff : 0x80000000u;
-        const int o = (c0 * ld + i0) * 8;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            a[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, o + r * rstep, 0));
-    };
-    // does this lane hold the diagonal entry of its column (row lq + 4 r == li), and in which register
-    const bool has_diag = li >= lq && ((li - lq) & 3) == 0;
-    const int rdiag = (li - lq) >> 2;
-    for (int s = npad / 16 - 1; s >= 0; --s) {
-        const int ce = env.cend[s];
-        d4 dg;
-        tile(dg, 16 * s, 16 * s, true);
-        d4 part = {0.0, 0.0, 0.0, 0.0};
-        for (int q0 = s + 1; q0 < ce; q0 += PTG) {
-            d4 a[PTG];
-#pragma unroll
-            for (int g = 0; g < PTG; ++g) tile(a[g], 16 * s, 16 * (q0 + g), q0 + g < ce);
-#pragma unroll
-            for (int g = 0; g < PTG; ++g) {
-                const double uq = q0 + g < ce ? us[16 * (q0 + g) + li] : 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) part[r] += a[g][r] * uq;
-            }
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[r] += __shfl_xor(part[r], off);
-        // t[c] for the rows c = lq + 4 r; u_s[li] = t[li] / U[li][li] + sum_{c > li} inv(L)[c][li] t[c]
-        double val = 0.0;
-        double ddiag = 1.0, tdiag = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double t = us[16 * s + lq + 4 * r] - part[r];
-            val += (lq + 4 * r > li ? dg[r] : 0.0) * t;
-            if (has_diag && rdiag == r) {
-                ddiag = dg[r];
-                tdiag = t;
-            }
-        }
-        val += tdiag / ddiag;  // (lanes without the diagonal entry add 0 / 1)
-        val += __shfl_xor(val, 16);
-        val += __shfl_xor(val, 32);
-        __builtin_amdgcn_wave_barrier();
-        if (lq == 0) us[16 * s + li] = val;
-        __builtin_amdgcn_wave_barrier();
-    }
-    for (int c = lane; c < npad && c < ld_uf; c += 64) ub[c] = us[c];
+    trs_subst::narrow_substitute(rs, ld, npad, env.cend, sh + (size_t)wave * n_pad_max, uf + (size_t)b * ld_uf, ld_uf);
 }
 
 }  // namespace

@@ -80,12 +80,16 @@ __host__ __device__ static inline TrsEnv trs_env_of(const int* env, int b, int n
 // and bar-942 loses 3 %, but routing PART of a batch to a second kernel costs more than it gains (two
 // launches that each fill the chip only partly: threshold 12: -8 %, threshold 5: +1 %).
 #define TRS_ENV_RS4 0x200
+// bit 10, set by trs_potrf_batched (not by trs_assemble, which resets the word): the wave that factored this
+// narrow-envelope matrix went on to substitute it (uf holds u already); trs_potrs_batched skips it.
+#define TRS_ENV_SUBSTITUTED 0x400
 #ifndef TRS_NARROW_RS4_ABOVE
 #define TRS_NARROW_RS4_ABOVE 1000000
 #endif
 __host__ __device__ static inline bool trs_env_is_narrow(const TrsEnv& e) { return (e.slack & 0xff) == TRS_NARROW_ITEM - 1; }
 __host__ __device__ static inline bool trs_env_is_compact(const TrsEnv& e) { return (e.slack & TRS_ENV_COMPACT) != 0; }
 __host__ __device__ static inline bool trs_env_is_rs4(const TrsEnv& e) { return (e.slack & TRS_ENV_RS4) != 0; }
+__host__ __device__ static inline bool trs_env_is_substituted(const TrsEnv& e) { return (e.slack & TRS_ENV_SUBSTITUTED) != 0; }
 
 // ---- compact stiffness matrix of a narrow-envelope truss (per truss, in the assembly workspace) --------
 // K_ff as per-TILE entry lists instead of slab tiles: the factorisation reads ~10 bytes per non-zero

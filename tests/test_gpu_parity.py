@@ -171,7 +171,12 @@ def test_stages_against_oracle(gpu, name, compact_mode):
             assert np.isnan(S[c, hi:npad]).all() or hi >= npad      # ... and nothing was written there
 
     # --- potrf: U^T U = K_ff, y = L^-1 f ------------------------------------------------------
-    dev.potrf()
+    # (the stages apart: by default the wave that factors a narrow-envelope matrix substitutes it as well)
+    assert dev.lib.trs_set_option(b"fused_substitution", 0) == 0
+    try:
+        dev.potrf()
+    finally:
+        dev.lib.trs_set_option(b"fused_substitution", 1)
     assert int(dev.info.cpu()[0]) == 0
     S = dev.S.cpu().numpy()[0]
     U, _ = _upper_from_slab(S, npad)
@@ -198,6 +203,18 @@ def test_stages_against_oracle(gpu, name, compact_mode):
     uref = np.linalg.solve(ref["K_ff"], f_free)
     assert H.max_scaled_err(uf[:n], uref) <= TOL_FP64
     assert not uf[n:npad].any()
+    # the default: factorisation and substitution by the same wave - uf holds u after trs_potrf_batched, bit
+    # for bit the u of the separate stages, the routing word says so and trs_potrs_batched leaves it alone
+    if narrow_any and npad <= 1024:
+        u_separate = dev.uf.clone()
+        dev.assemble(flags=0)
+        dev.potrf()
+        dev.torch.cuda.synchronize()
+        nchm = dev.rows // 16
+        assert int(dev.env.cpu()[0][nchm + dev.rows // 64]) & 0x400
+        assert bool((dev.uf.view(dev.torch.int64) == u_separate.view(dev.torch.int64)).all())
+        dev.potrs()
+        assert bool((dev.uf.view(dev.torch.int64) == u_separate.view(dev.torch.int64)).all())
 
     # --- recover -------------------------------------------------------------------------------
     dev.recover()

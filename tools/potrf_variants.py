@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--fused", action="append", default=[],
                     help="tags (repeatable) that run with trs_set_option('compact', 1): compact entry lists + fused factorisation")
     ap.add_argument("--option", action="append", default=[],
-                    help="tag:name=value (repeatable): trs_set_option(name, value) while that tag runs, 0 otherwise")
+                    help="tag:name=value[/restore] (repeatable): trs_set_option(name, value) while that tag runs, restore (0) otherwise")
     args = ap.parse_args()
     with open(os.path.join(ROOT, "tests", "golden", "data", args.case + ".json")) as fh:
         data = json.load(fh)
@@ -54,11 +54,12 @@ def main():
     for spec in args.option:
         tag, kv = spec.split(":")
         name, value = kv.split("=")
-        options.setdefault(tag, []).append((name.encode(), int(value)))
+        value, _, reset = value.partition("/")          # name=value[/value to restore afterwards, default 0]
+        options.setdefault(tag, []).append((name.encode(), int(value), int(reset or 0)))
     for rnd in range(args.rounds + 1):
         for tag in args.tags:
             dev.lib = libs[tag]
-            for name, value in options.get(tag, []):
+            for name, value, _ in options.get(tag, []):
                 assert libs[tag].trs_set_option(name, value) == 0, name
             evs = []
             for s in stages:
@@ -66,8 +67,8 @@ def main():
                 e0.record(); getattr(dev, s)(); e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
-            for name, _ in options.get(tag, []):
-                libs[tag].trs_set_option(name, 0)
+            for name, _, reset in options.get(tag, []):
+                libs[tag].trs_set_option(name, reset)
             if rnd == 0:   # warm-up round + correctness
                 u = dev.u[0].cpu().numpy()
                 info = int(dev.info.abs().sum().item())
