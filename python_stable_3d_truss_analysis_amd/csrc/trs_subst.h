@@ -48,13 +48,32 @@ __device__ __forceinline__ void narrow_substitute(const __amdgpu_buffer_rsrc_t r
     // does this lane hold the diagonal entry of its column (row lq + 4 r == li), and in which register
     const bool has_diag = li >= lq && ((li - lq) & 3) == 0;
     const int rdiag = (li - lq) >> 2;
+    // The tiles of a chunk do not depend on the solution: the diagonal tile and the first PTG off-diagonal
+    // tiles of chunk s - 1 are requested BEFORE chunk s is worked on.  With every matrix of a launch resident
+    // (trs_potrs_narrow_kernel) the memory system is the limit either way; behind the factorisation, where the
+    // last matrices of a SIMD run alone, it takes the memory latency out of the chain of 44 chunks.
+    sd4 dg_n, a_n[PTG];
+    auto fetch = [&](int s) {
+        const int ce = cend[s];
+        tile(dg_n, 16 * s, 16 * s, true);
+#pragma unroll
+        for (int g = 0; g < PTG; ++g) tile(a_n[g], 16 * s, 16 * (s + 1 + g), s + 1 + g < ce);
+    };
+    fetch(npad / 16 - 1);
     for (int s = npad / 16 - 1; s >= 0; --s) {
         const int ce = cend[s];
-        sd4 dg;
-        tile(dg, 16 * s, 16 * s, true);
+        sd4 dg = dg_n, a[PTG];
+#pragma unroll
+        for (int g = 0; g < PTG; ++g) a[g] = a_n[g];
+        if (s > 0) fetch(s - 1);
         sd4 part = {0.0, 0.0, 0.0, 0.0};
-        for (int q0 = s + 1; q0 < ce; q0 += PTG) {
-            sd4 a[PTG];
+#pragma unroll
+        for (int g = 0; g < PTG; ++g) {
+            const double uq = s + 1 + g < ce ? us[16 * (s + 1 + g) + li] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[r] += a[g][r] * uq;
+        }
+        for (int q0 = s + 1 + PTG; q0 < ce; q0 += PTG) {  // envelopes wider than PTG tiles: the rest, not ahead
 #pragma unroll
             for (int g = 0; g < PTG; ++g) tile(a[g], 16 * s, 16 * (q0 + g), q0 + g < ce);
 #pragma unroll
