@@ -79,7 +79,8 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     const int* __restrict__ nM_arr, const int nJ_max, const int nM_max, const int n_pad_max,
     const int ld, const size_t slab_stride, double* __restrict__ S_all, const int flags,
     unsigned char* __restrict__ work_all, const size_t work_stride, int* __restrict__ env_all,
-    const int WT, double* __restrict__ uf_all, const int ld_uf, const size_t ck_off, const int compact_ok) {
+    const int WT, double* __restrict__ uf_all, const int ld_uf, const size_t ck_off, const int compact_ok,
+    const int WTn) {
     extern __shared__ unsigned char lds_raw[];
     constexpr int TR = tile_rows(NT);
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -475,13 +476,25 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
 #endif
     // ---- phase 1 ---------------------------------------------------------------------------------------
     const bool with_col = !(has_env && wgflag[1] != 0);  // the 16-wide load-column chunk rides in the slab
+    // A matrix whose load vector has gone to uf needs neither the staged vector nor the tile's 16 columns for
+    // it any more: the row tile then takes over both (the vector lies right in front of it in LDS) and is wide
+    // enough - WTn columns - for a whole row of a narrow envelope, which otherwise goes out in two segments.
+    double* Tt = T;
+    int WTe = WT, Wstride = WT + 16;
     if (!with_col) {
         double* ufb = uf_all + (size_t)b * ld_uf;
         for (int c = tid; c < npad; c += NT) ufb[c] = c < n ? rhs[c] : 0.0;
+        if (MODE != 2 && WTn > WT) {
+            __syncthreads();   // every thread has read its part of the vector
+            for (int c = tid; c < n_pad_max; c += NT) rhs[c] = 0.0;
+            __syncthreads();
+            Tt = rhs;
+            WTe = WTn;
+            Wstride = WTn;
+        }
     }
     double* S = S_all + (size_t)b * slab_stride;
     const int rr = tid / TPR, e_first = tid % TPR;
-    const int Wstride = WT + 16;
     // Thread TPR-1 of a row carries the joint's own block, threads 0 .. TPR-2 the heads of the runs of
     // its adjacency list (stride TPR-1).  The first piece of every thread is formed one block AHEAD,
     // while the previous block's stores drain, so the scatter itself is three LDS writes.
@@ -537,13 +550,13 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         const int chunk = __builtin_amdgcn_readfirstlane(c0 + rr) >> 4;  // of this wave's rows
         const int i_lo = full ? 0 : 16 * chunk;
         const int i_hi = (has_env && !full) ? 16 * cendl[chunk] : npad;
-        for (int seg_lo = i_lo; seg_lo < i_hi; seg_lo += WT) {
-            const int seg_hi = min(i_hi, seg_lo + WT);
+        for (int seg_lo = i_lo; seg_lo < i_hi; seg_lo += WTe) {
+            const int seg_hi = min(i_hi, seg_lo + WTe);
             const int Ws = seg_hi - seg_lo;  // multiple of 16
             const bool is_last = seg_hi == i_hi;
             const int W = Ws + (is_last && with_col ? 16 : 0);
             {   // scatter: every (row, column) of the tile is written by exactly one thread
-                double* row = T + (size_t)rr * Wstride - seg_lo;
+                double* row = Tt + (size_t)rr * Wstride - seg_lo;
                 if (pq0 >= seg_lo && pq0 < seg_hi) row[pq0] = pv0;
                 if (pq1 >= seg_lo && pq1 < seg_hi) row[pq1] = pv1;
                 if (pq2 >= seg_lo && pq2 < seg_hi) row[pq2] = pv2;
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             __builtin_amdgcn_wave_barrier();
             {   // all TR rows in parallel: TPR threads per row, 16 bytes per thread and pass
                 double* dst = S + (size_t)(c0 + rr) * ld;
-                double* src = T + (size_t)rr * Wstride;
+                double* src = Tt + (size_t)rr * Wstride;
                 for (int x = e_first * 2; x < W; x += 2 * TPR) {
                     const int col = x < Ws ? seg_lo + x : npad + (x - Ws);  // envelope part | load column
                     *reinterpret_cast<d2*>(dst + col) = *reinterpret_cast<const d2*>(src + x);
@@ -587,11 +600,19 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
 // tile width, table placement (kernel MODE) and work-group size for a batch shape
 struct AsmPlan {
     int WT, mode, big;
+    int WTn;           // tile width of a matrix whose load vector went to uf (tile + staged vector), 0: as WT
     size_t lds, work;  // LDS per work-group, workspace bytes per truss (tables/geometry + compact lists)
     int compact_ok;    // the tables of the compact path fit (they alias the row tile)
     size_t ck_off;     // offset of the compact-list region inside a truss's workspace
 };
 inline AsmPlan asm_finish(AsmPlan p, int nJ_max, int nM_max, int n_pad_max, size_t tile_bytes) {
+    p.WTn = 0;
+    if (p.mode != 2) {
+        const int TR = tile_rows(p.big ? NT_BIG : NT_DEFAULT);
+        int w = (int)((tile_bytes + (size_t)n_pad_max * 8) / ((size_t)TR * 8)) / 16 * 16;
+        if (w > n_pad_max) w = n_pad_max;
+        p.WTn = w > p.WT ? w : 0;
+    }
     p.ck_off = p.work;
     p.compact_ok = p.mode != 2 && tile_bytes >= asm_compact_tab_bytes(n_pad_max);
     p.work += trs_compact_layout(nJ_max, nM_max < 1 ? 1 : nM_max, n_pad_max).total;
@@ -613,7 +634,7 @@ inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
             int WT = (int)((budget - fixed) / (TR * 8)) - 16;
             WT = WT / 16 * 16;
             if (WT > n_pad_max) WT = n_pad_max;
-            return asm_finish(AsmPlan{WT, g ? 0 : 1, big, asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, g, TR).total,
+            return asm_finish(AsmPlan{WT, g ? 0 : 1, big, 0, asm_lds_layout(nJ_max, nM_max, n_pad_max, WT, g, TR).total,
                                       geom_bytes, 0, 0},
                               nJ_max, nM_max, n_pad_max, (size_t)TR * (WT + 16) * 8);
         }
@@ -621,7 +642,7 @@ inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
     const int TR = tile_rows(NT_DEFAULT);
     const int WT = n_pad_max < 240 ? n_pad_max : 240;  // 64 KiB of tile: two work-groups per CU
     const size_t tables = asm_lds_layout(nJ_max, nM_max, n_pad_max, -16, 1, TR).total;
-    return asm_finish(AsmPlan{WT, 2, 0, (size_t)TR * (WT + 16) * 8, (tables + 255) / 256 * 256, 0, 0}, nJ_max,
+    return asm_finish(AsmPlan{WT, 2, 0, 0, (size_t)TR * (WT + 16) * 8, (tables + 255) / 256 * 256, 0, 0}, nJ_max,
                       nM_max, n_pad_max, 0);
 }
 
@@ -654,7 +675,7 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
         hipLaunchKernelGGL((trs_assemble_kernel<MODE, NTV>), dim3(B), dim3(NTV), plan.lds, stream, xyz,  \
                            conn, E, A, loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max, ld, \
                            slab_stride, S, flags, static_cast<unsigned char*>(work), plan.work, env,     \
-                           plan.WT, uf, ld_uf, plan.ck_off, compact_ok);                                 \
+                           plan.WT, uf, ld_uf, plan.ck_off, compact_ok, plan.WTn);                                 \
     } while (0)
     if (plan.mode == 2)
         TRS_LAUNCH_ASSEMBLE(2, NT_DEFAULT);
