@@ -57,6 +57,15 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
                       int32_t *choice /* [B] or NULL */,
                       int effort /* 0: RCM and its reverse, 1: + the sweep along the longest extent, 2: all sweeps */);
 
+/* Reach of the row envelope below the 64 x 64 diagonal blocks of K_ff, in 16-row chunks, per truss, for the
+ * numbering given or after a renumbering (what trs_assemble derives on the device).  A batch that stays at or below 24 everywhere holds
+ * no matrix for the work-group kernels: see TRS_ASM_ALL_NARROW / TRS_HINT_NO_WIDE in trs_solver.h. */
+int trs_envelope_reach(int B, int nJ_max, int nM_max, const int32_t *conn, const uint8_t *cbits,
+                       const int32_t *nJ, const int32_t *nM,
+                       const int32_t *perm /* [B][nJ_max] as trs_profile_order gives it: the reach AFTER that
+                                              renumbering; NULL: the numbering as it is */,
+                       int32_t *reach /* [B] */);
+
 /* Apply a joint order out of place (members keep their order, their end joints are renumbered). */
 int trs_apply_joint_order(int B, int nJ_max, int nM_max, const int32_t *perm, const int32_t *nM,
                           const double *xyz, const int32_t *conn, const uint8_t *cbits,

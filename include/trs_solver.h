@@ -52,11 +52,20 @@
 extern "C" {
 #endif
 
-#define TRS_ABI_VERSION 5
+#define TRS_ABI_VERSION 6
 
 /* trs_assemble flags */
 #define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests); implies the slab form */
 #define TRS_ASM_NO_COMPACT 2     /* narrow-envelope matrices too are written to the slab (tests, A/B runs) */
+#define TRS_ASM_ALL_NARROW 4     /* every matrix is routed to the wave-per-matrix kernels, whatever its envelope */
+
+/* hints of trs_potrf_batched / trs_potrs_batched / trs_solve: what the caller knows about the batch, so that
+ * kernels that would find no matrix of theirs are not launched at all (each such launch costs 4-9 us).
+ * A hint never changes a result when it is true; a FALSE hint leaves matrices unprocessed. */
+#define TRS_HINT_NO_WIDE 1       /* trs_assemble ran with TRS_ASM_ALL_NARROW: no matrix for the work-group kernels */
+#define TRS_HINT_SUBSTITUTED 2   /* trs_potrs_batched only: trs_potrf_batched ran with the fused substitution on and
+                                    no system has more than 1024 rows: nothing is left for the wave-per-matrix
+                                    substitution either (a matrix with a failed pivot stays unsolved: info[b] > 0) */
 
 int trs_abi_version(void);
 
@@ -70,6 +79,8 @@ int trs_abi_version(void);
  *                           (default 1; see trs_potrf_batched).
  * Returns 0, or hipErrorInvalidValue for an unknown name. */
 int trs_set_option(const char *name, int value);
+/* Current value of "small_path", "compact" or "fused_substitution"; -1 for any other name. */
+int trs_get_option(const char *name);
 
 /* Leading dimension / row count of the stiffness slab for a batch whose largest reduced
  * system has n_max free DOFs. */
@@ -128,14 +139,14 @@ int trs_potrf_batched(int B, const int32_t *n_free, int ld, int slab_rows, doubl
                       int32_t *info /* [B] */, const int32_t *env /* or NULL */,
                       const void *work /* the buffer trs_assemble filled */,
                       double *uf /* [B][ld_uf]: out y = L^-1 f (in: f, for the trusses in compact form) */,
-                      int ld_uf, void *stream);
+                      int ld_uf, int hints, void *stream);
 
 /* Back substitution U u_f = y, in place on uf.  Replaces the solve half of np.linalg.solve
  * (truss.py:343).  In: uf[b][c] = y[c] (from trs_potrf_batched); out: uf[b][c] = reduced displacement c
  * (c < n_free[b]); entries up to n_pad are written. */
 int trs_potrs_batched(int B, const int32_t *n_free, int ld, int slab_rows, const double *S,
                       double *uf /* inout [B][ld_uf] */, int ld_uf, const int32_t *env /* or NULL */,
-                      void *stream);
+                      int hints, void *stream);
 
 /* Result recovery.  Replaces the displacement scatter (truss.py:342), the reactions
  * vecF[~mask] = K[~mask,:] @ u (truss.py:348-349) and the member-force loop
@@ -209,7 +220,7 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound,
               int32_t *free_index, int32_t *n_free, int ld, int slab_rows, double *S,
               double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info,
               void *work, int32_t *env /* workspace for the envelope metadata, or NULL = dense */,
-              const int32_t *joint_out /* [B][nJ_max] or NULL */, void *stream);
+              const int32_t *joint_out /* [B][nJ_max] or NULL */, int hints /* TRS_HINT_NO_WIDE: route and treat every matrix as narrow */, void *stream);
 
 #ifdef __cplusplus
 }

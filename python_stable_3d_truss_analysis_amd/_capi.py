@@ -18,6 +18,7 @@ _D = ctypes.c_double
 #: every symbol `include/trs_solver.h` declares -> (restype, argtypes)
 SIGNATURES = {
     "trs_abi_version": (_I, []),
+    "trs_get_option": (_I, [ctypes.c_char_p]),
     "trs_set_option": (_I, [ctypes.c_char_p, _I]),
     "trs_slab_ld": (_I, [_I]),
     "trs_slab_rows": (_I, [_I]),
@@ -25,8 +26,8 @@ SIGNATURES = {
     "trs_env_ints": (_I, [_I]),
     "trs_assemble_work_bytes": (ctypes.c_size_t, [_I, _I, _I]),
     "trs_assemble": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
-    "trs_potrf_batched": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
-    "trs_potrs_batched": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
+    "trs_potrf_batched": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "trs_potrs_batched": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "trs_recover": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "trs_fitness": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _P, _P, _P, _P]),
     "trs_solve_small_fits": (_I, [_I, _I, _I]),
@@ -35,11 +36,11 @@ SIGNATURES = {
     "trs_graph_features_dev": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D,
                                     _I, _P, _P, _P, _P, _P, _P]),
     "trs_solve": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
-                       _P, _P, _P, _P, _P, _P, _P, _P]),
+                       _P, _P, _P, _P, _P, _P, _P, _I, _P]),
 }
 
 #: must equal TRS_ABI_VERSION of include/trs_solver.h
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 

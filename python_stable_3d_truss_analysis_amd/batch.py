@@ -272,9 +272,12 @@ class DeviceBatch:
                     packed.B, packed.nJ_max, packed.nM_max, packed.n_max, use_envelope, use_small)
         if perm is not None:
             self.joint_out = up(perm)
+        # what the host can tell the launches about this batch (see `all_narrow`)
+        if use_envelope and not self.small and packed.B:
+            self.all_narrow = bool(envelope_reach(resident).max() <= NARROW_MAX_BELOW)
 
     @classmethod
-    def from_device(cls, tensors, n_max, use_envelope=True, use_small=True, joint_out=None):
+    def from_device(cls, tensors, n_max, use_envelope=True, use_small=True, joint_out=None, all_narrow=False):
         """A batch whose inputs already live on the device: `tensors` maps INPUT_FIELDS to contiguous
         device tensors of the padded shapes (see PackedBatch); `n_max` bounds the free DOFs per truss
         (host-known, it sizes the slab); `joint_out` (int32 [B, nJ_max] on the device, or None): the
@@ -290,6 +293,7 @@ class DeviceBatch:
             if tuple(joint_out.shape) != (self.B, self.nJ_max) or joint_out.dtype != torch.int32:
                 raise ValueError("joint_out must be int32 [B, nJ_max]")
             self.joint_out = joint_out.contiguous()
+        self.all_narrow = bool(all_narrow and use_envelope and not self.small)
         return self
 
     def _setup(self, torch, dev, tensors, B, nJ_max, nM_max, n_max, use_envelope, use_small=True):
@@ -311,6 +315,12 @@ class DeviceBatch:
         self.info = torch.empty([B], dtype=torch.int32, device=dev)
         self._slab = None   # (S, uf, work, env): the staged pipeline's workspace, allocated on first use
         self.joint_out = None   # int32 [B, nJ_max]: where the results of (resident) joint j go, or None
+        #: the host knows that no envelope of this batch reaches further than NARROW_MAX_BELOW chunks below its
+        #: diagonal blocks (`envelope_reach`): every matrix is then routed to the wave-per-matrix kernels
+        #: (TRS_ASM_ALL_NARROW) and the work-group kernels, which would find nothing, are not launched.  Safe
+        #: either way - with the flag the device routes so regardless - it only must not outlive the topology.
+        self.all_narrow = False
+        self._potrf_fused = False
 
     def _workspace(self):
         """Stiffness slab, reduced solution, assembly workspace and envelope metadata of the staged
@@ -345,7 +355,16 @@ class DeviceBatch:
                                         self.free_index.data_ptr(), self.n_free.data_ptr(),
                                         self._stream()), "trs_dofmap")
 
+    def _hints(self, substituted=False):
+        if not self.all_narrow or self.env is None:
+            return 0
+        # (whether THIS batch's last factorisation ran with the substitution fused in, not the option's value now)
+        fused = substituted and self.rows <= 1024 and self._potrf_fused
+        return HINT_NO_WIDE | (HINT_SUBSTITUTED if fused else 0)
+
     def assemble(self, flags=0):
+        if self.all_narrow and self.env is not None:
+            flags |= ASM_ALL_NARROW
         _capi.check(self.lib.trs_assemble(
             self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
             self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
@@ -354,15 +373,17 @@ class DeviceBatch:
             self._stream()), "trs_assemble")
 
     def potrf(self):
+        self._potrf_fused = self.lib.trs_get_option(b"fused_substitution") == 1
         _capi.check(self.lib.trs_potrf_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
                                                self.S.data_ptr(), self.info.data_ptr(), self._env_ptr(),
                                                self.work.data_ptr(), self.uf.data_ptr(), self.rows,
-                                               self._stream()), "trs_potrf_batched")
+                                               self._hints(), self._stream()), "trs_potrf_batched")
 
     def potrs(self):
         _capi.check(self.lib.trs_potrs_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
                                                self.S.data_ptr(), self.uf.data_ptr(), self.rows,
-                                               self._env_ptr(), self._stream()), "trs_potrs_batched")
+                                               self._env_ptr(), self._hints(substituted=True), self._stream()),
+                    "trs_potrs_batched")
 
     def recover(self):
         _capi.check(self.lib.trs_recover(
@@ -419,7 +440,8 @@ class DeviceBatch:
                 self.n_free.data_ptr(), self.ld, self.rows, self.S.data_ptr(), self.uf.data_ptr(),
                 self.rows, self.u.data_ptr(), self.f_ext.data_ptr(), self.N.data_ptr(),
                 self.info.data_ptr(), self.work.data_ptr(), self._env_ptr(),
-                self.joint_out.data_ptr() if self.joint_out is not None else None, self._stream()),
+                self.joint_out.data_ptr() if self.joint_out is not None else None,
+                HINT_NO_WIDE if self.all_narrow and self.env is not None else 0, self._stream()),
                 "trs_solve")
 
     def fitness(self, allow_stress, allow_displace):
@@ -441,6 +463,7 @@ class DeviceBatch:
     def upload(self, host_inputs):
         """Replace the resident inputs by another batch of the same padded shapes (asynchronous on
         the current stream when `host_inputs` come from `pinned_inputs`)."""
+        self.all_narrow = False   # another topology: the host's knowledge of the envelopes is gone
         for f in self.INPUT_FIELDS:
             getattr(self, f).copy_(host_inputs[f], non_blocking=True)
 
@@ -584,6 +607,31 @@ def profile_permutation(packed: PackedBatch, return_choice=False, effort=2):
     if rc != 0:
         raise RuntimeError(f"trs_profile_order failed ({rc})")
     return (perm, choice) if return_choice else perm
+
+
+NARROW_MAX_BELOW = 24   # csrc/trs_common.h TRS_NARROW_MAX_BELOW: reach up to which a matrix goes to a wave of its own
+HINT_NO_WIDE, HINT_SUBSTITUTED, ASM_ALL_NARROW = 1, 2, 4   # include/trs_solver.h
+
+
+def envelope_reach(packed: PackedBatch, perm=None):
+    """Per truss, how many 16-row chunks the row envelope of K_ff reaches below its 64 x 64 diagonal blocks in
+    the numbering given, or after the renumbering `perm` (native, `csrc/reorder.c`; the metadata `trs_assemble`
+    derives on the device).  A batch that stays at or below `NARROW_MAX_BELOW` holds no matrix for the
+    work-group kernels."""
+    import ctypes
+    from .generate import _load
+    lib = _load()
+    lib.trs_envelope_reach.restype = ctypes.c_int
+    reach = np.empty([packed.B], dtype=np.int32)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    conn, nJ, nM = (np.ascontiguousarray(a, dtype=np.int32) for a in (packed.conn, packed.nJ, packed.nM))
+    cbits = np.ascontiguousarray(packed.cbits, dtype=np.uint8)
+    pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+    rc = lib.trs_envelope_reach(ctypes.c_int(packed.B), ctypes.c_int(packed.nJ_max), ctypes.c_int(packed.nM_max),
+                                ptr(conn), ptr(cbits), ptr(nJ), ptr(nM), None if pm is None else ptr(pm), ptr(reach))
+    if rc != 0:
+        raise RuntimeError(f"trs_envelope_reach failed ({rc})")
+    return reach
 
 
 def joint_order(packed: PackedBatch, reorder):
@@ -805,13 +853,15 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     needs_rho = on_device
     full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS if f != "rho" or needs_rho}
     original = dict(full)   # the caller's joint order (the reordering below makes new tensors)
-    perm32 = None
+    perm32 = reach_new = None
+    reach_given = envelope_reach(packed) if B else np.zeros([0], dtype=np.int32)
     if wants_order:
         if ordering is not None:
             host_perm = ordering.result()
             worker.shutdown(wait=False)
         else:
             host_perm = joint_order(packed, reorder)
+        reach_new = envelope_reach(packed, host_perm)
         perm32 = up(host_perm)                                               # [B, nJ_max] int32, joint k := old perm[k]
         perm = perm32.long()
         inverse = torch.empty_like(perm)
@@ -872,7 +922,10 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
         jout = None
         if renumbered:
             jout = perm32 if whole else perm32.index_select(0, rows)[:, :nJ_b].contiguous()
-        bucket = DeviceBatch.from_device(sub, n_b, joint_out=jout)
+        # no envelope of the bucket reaches beyond the wave-per-matrix kernels' range: the others are not launched
+        reach = (reach_new if renumbered else reach_given)[idx]
+        bucket = DeviceBatch.from_device(sub, n_b, joint_out=jout,
+                                         all_narrow=bool(len(reach) and reach.max() <= NARROW_MAX_BELOW))
         for slot, sec in enumerate(variants):
             if sec is not None:
                 bucket.A.fill_(float(sec[0]))

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) widest = max(widest, __shfl_xor(widest, off));
             // which factorisation kernel will take this matrix decides the shape of the stored part
-            const bool narrow = widest <= TRS_NARROW_MAX_BELOW;
+            const bool narrow = widest <= TRS_NARROW_MAX_BELOW || (flags & TRS_ASM_ALL_NARROW) != 0;
             // narrow envelopes leave as compact entry lists (phase 1c) unless the caller asked for the
             // slab (tests, A/B runs) or the list tables do not fit next to this batch's other tables
             const bool compact = narrow && compact_ok != 0 && !full && uf_all != nullptr &&

@@ -10,14 +10,15 @@ int trs_assemble_launch(int, int, int, const double*, const int*, const double*,
                         const double*, const int*, const int*, const int*, const int*, int, size_t,
                         int, double*, int, void*, int*, double*, int, hipStream_t);
 size_t trs_assemble_work_bytes(int, int, int);
-int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int*, const void*, double*, int, int,
+int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int*, const void*, double*, int, int, int,
                      hipStream_t);
-int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, const int*, hipStream_t);
+int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, const int*, int, hipStream_t);
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, const int*, const double*, int, double*,
                        double*, double*, const int*, hipStream_t);
 void trs_recover_set_unstaged(int);
 void trs_potrf_set_fused_substitution(int);
+int trs_potrf_fused_substitution(void);
 int trs_solve_small_fits(int, int, int);
 int trs_solve_small_launch(int, int, int, int, const double*, const int*, const double*, const double*,
                            const uint8_t*, const double*, const int*, const int*, double*, double*, double*,
@@ -65,6 +66,13 @@ int trs_set_option(const char* name, int value) {
     return (int)hipErrorInvalidValue;
 }
 
+int trs_get_option(const char* name) {
+    if (name != nullptr && strcmp(name, "small_path") == 0) return g_small_path;
+    if (name != nullptr && strcmp(name, "compact") == 0) return g_compact;
+    if (name != nullptr && strcmp(name, "fused_substitution") == 0) return trs_potrf_fused_substitution();
+    return -1;
+}
+
 int trs_solve_small(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz, const int32_t* conn,
                     const double* E, const double* A, const uint8_t* cbits, const double* loads,
                     const int32_t* nJ, const int32_t* nM, double* u, double* f_ext, double* N, int32_t* info,
@@ -105,17 +113,17 @@ int trs_assemble(int B, int nJ_max, int nM_max, const double* xyz, const int32_t
 }
 
 int trs_potrf_batched(int B, const int32_t* n_free, int ld, int slab_rows, double* S, int32_t* info,
-                      const int32_t* env, const void* work, double* uf, int ld_uf, void* stream) {
+                      const int32_t* env, const void* work, double* uf, int ld_uf, int hints, void* stream) {
     if (B < 0 || bad_slab(ld, slab_rows) || (B > 0 && (uf == nullptr || ld_uf < slab_rows)))
         return (int)hipErrorInvalidValue;
     return trs_potrf_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, info, env, work, uf, ld_uf,
-                            g_compact, (hipStream_t)stream);
+                            g_compact, hints, (hipStream_t)stream);
 }
 
 int trs_potrs_batched(int B, const int32_t* n_free, int ld, int slab_rows, const double* S, double* uf,
-                      int ld_uf, const int32_t* env, void* stream) {
+                      int ld_uf, const int32_t* env, int hints, void* stream) {
     if (B < 0 || bad_slab(ld, slab_rows) || ld_uf < slab_rows) return (int)hipErrorInvalidValue;
-    return trs_potrs_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, uf, ld_uf, env,
+    return trs_potrs_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, uf, ld_uf, env, hints,
                             (hipStream_t)stream);
 }
 
@@ -141,7 +149,7 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
               const double* E, const double* A, const uint8_t* cbits, const double* loads,
               const int32_t* nJ, const int32_t* nM, int32_t* free_index, int32_t* n_free, int ld,
               int slab_rows, double* S, double* uf, int ld_uf, double* u, double* f_ext, double* N,
-              int32_t* info, void* work, int32_t* env, const int32_t* joint_out, void* stream) {
+              int32_t* info, void* work, int32_t* env, const int32_t* joint_out, int hints, void* stream) {
     if (g_small_path && !joint_out && trs_solve_small_fits(nJ_max, nM_max, n_max_bound))  // everything in one kernel
         return trs_solve_small(B, nJ_max, nM_max, n_max_bound, xyz, conn, E, A, cbits, loads, nJ, nM, u,
                                f_ext, N, info, free_index, n_free, nullptr, 0.0, 0.0, nullptr, nullptr,
@@ -149,12 +157,16 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
     if (n_max_bound > slab_rows) return (int)hipErrorInvalidValue;
     int rc = trs_dofmap(B, nJ_max, cbits, nJ, free_index, n_free, stream);
     if (rc) return rc;
+    const int no_wide = env != nullptr && (hints & TRS_HINT_NO_WIDE) != 0;
     rc = trs_assemble(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM, ld,
-                      slab_rows, S, 0, work, env, uf, ld_uf, stream);
+                      slab_rows, S, no_wide ? TRS_ASM_ALL_NARROW : 0, work, env, uf, ld_uf, stream);
     if (rc) return rc;
-    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, env, work, uf, ld_uf, stream);
+    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, env, work, uf, ld_uf, no_wide ? TRS_HINT_NO_WIDE : 0,
+                           stream);
     if (rc) return rc;
-    rc = trs_potrs_batched(B, n_free, ld, slab_rows, S, uf, ld_uf, env, stream);
+    rc = trs_potrs_batched(B, n_free, ld, slab_rows, S, uf, ld_uf, env,
+                           no_wide ? (TRS_HINT_NO_WIDE | (trs_potrf_fused_substitution() && slab_rows <= 1024
+                                                              ? TRS_HINT_SUBSTITUTED : 0)) : 0, stream);
     if (rc) return rc;
     return trs_recover(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf, u,
                        f_ext, N, joint_out, stream);

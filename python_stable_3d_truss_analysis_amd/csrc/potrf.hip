@@ -25,6 +25,7 @@
 // panel column c (component r = k-step r), so the triangular solve against the diagonal
 // block runs as MFMAs with no data movement, and loads/stores of a tile are 128-byte
 // segments of S rows.
+#include "../../include/trs_solver.h"
 #include "trs_common.h"
 #include "trs_subst.h"
 #include "trs_chol16.h"
@@ -1040,10 +1041,11 @@ extern "C" int trs_debug_stamps(unsigned long long* host_out, int reset) {
 
 static int g_fused_substitution = 1;  // trs_set_option("fused_substitution", 0 / 1)
 extern "C" void trs_potrf_set_fused_substitution(int on) { g_fused_substitution = on; }
+extern "C" int trs_potrf_fused_substitution(void) { return g_fused_substitution; }
 
 extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
                                 double* S, int* info, const int* env, const void* work, double* uf,
-                                int ld_uf, int compact_possible, hipStream_t stream) {
+                                int ld_uf, int compact_possible, int hints, hipStream_t stream) {
     if (B <= 0) return 0;
     // a slab is addressed through one buffer descriptor with 32-bit byte offsets, the upper half of
     // the offset range being the "tile not stored" marker (Slab::gone)
@@ -1068,6 +1070,7 @@ extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_st
             if ((rc = (int)hipGetLastError())) return rc;
         }
     }
+    if (env != nullptr && (hints & TRS_HINT_NO_WIDE) != 0) return 0;  // no matrix for the work-group kernel
     hipLaunchKernelGGL(trs_potrf_kernel, dim3(B), dim3(NW * 64), 0, stream, S, n_free, ld,
                        slab_stride, info, env, n_pad_max, uf, ld_uf);
     return (int)hipGetLastError();

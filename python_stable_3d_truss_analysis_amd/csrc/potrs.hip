@@ -7,6 +7,7 @@
 // the 64 x 64 diagonal block in LDS; wave 0 then solves the triangle.  The loads of a block do not
 // depend on the solution, only the multiplications do: they are issued one block ahead, so the
 // serial chain over the blocks sees the triangle solves and not the memory latencies.
+#include "../../include/trs_solver.h"
 #include "trs_common.h"
 #include "trs_subst.h"
 
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64 * PMW, 3) void trs_potrs_narrow_kernel(
 }  // namespace
 
 extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
-                                const double* S, double* uf, int ld_uf, const int* env,
+                                const double* S, double* uf, int ld_uf, const int* env, int hints,
                                 hipStream_t stream) {
     if (B <= 0 || n_pad_max <= 0) return 0;
     const size_t lds = (size_t)(n_pad_max + BS * (BS + 1) + BS) * sizeof(double);
@@ -241,12 +242,15 @@ extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_st
     // (and the slab fits the 31-bit offsets of a buffer descriptor, as in trs_potrf_batched)
     const size_t lds_narrow = (size_t)PMW * n_pad_max * sizeof(double);
     const int narrow = env != nullptr && lds_narrow <= 64 * 1024 && slab_stride * sizeof(double) < ((size_t)1 << 31);
+    if (narrow && (hints & TRS_HINT_SUBSTITUTED) != 0 && (hints & TRS_HINT_NO_WIDE) != 0 && n_pad_max <= 1024)
+        return 0;  // every matrix was substituted by the wave that factored it
     if (narrow) {
         hipLaunchKernelGGL(trs_potrs_narrow_kernel, dim3((B + PMW - 1) / PMW), dim3(64 * PMW), lds_narrow, stream, S,
                            n_free, ld, slab_stride, uf, ld_uf, env, n_pad_max, B);
         const int rc = (int)hipGetLastError();
         if (rc) return rc;
     }
+    if (narrow && (hints & TRS_HINT_NO_WIDE) != 0) return 0;  // no matrix for the work-group kernel
     if (env != nullptr)
         hipLaunchKernelGGL(trs_potrs_kernel<true>, dim3(B), dim3(256), lds, stream, S, n_free, ld,
                            slab_stride, uf, ld_uf, env, n_pad_max, narrow);

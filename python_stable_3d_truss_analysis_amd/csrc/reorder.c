@@ -347,6 +347,74 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
     return rc;
 }
 
+/* ---- envelope reach ---------------------------------------------------------------------------------
+ * How far the row envelope of K_ff reaches below its 64 x 64 diagonal blocks, in 16-row chunks, for the
+ * numbering the trusses come in: the same metadata trs_assemble derives on the device (chunkmin from every
+ * joint's smallest coupled free DOF, ft = its running minimum from the end, last chunk reaching each panel).
+ * A caller whose batch stays below TRS_NARROW_MAX_BELOW (24) everywhere may tell the solver that it holds
+ * no wide matrix (TRS_ASM_ALL_NARROW + TRS_HINT_NO_WIDE in trs_solver.h), which saves the launches of the
+ * kernels that would find nothing to do.  The hint is safe either way: with TRS_ASM_ALL_NARROW the device
+ * routes every matrix to the wave-per-matrix kernels regardless of what this function found. */
+int trs_envelope_reach(int B, int nJ_max, int nM_max, const int32_t *conn, const uint8_t *cbits,
+                       const int32_t *nJ, const int32_t *nM, const int32_t *perm /* [B][nJ_max] or NULL */,
+                       int32_t *reach /* [B] */) {
+    int rc = 0;
+#pragma omp parallel
+    {
+        int *first = (int *)malloc(sizeof(int) * (size_t)(nJ_max + 1));   /* first free DOF of a joint, -1: none */
+        int *mincol = (int *)malloc(sizeof(int) * (size_t)(nJ_max + 1));
+        int *cmin = (int *)malloc(sizeof(int) * (size_t)(3 * nJ_max / 16 + 8));
+        int *lastc = (int *)malloc(sizeof(int) * (size_t)(3 * nJ_max / 16 + 8));
+        const int ok = first && mincol && cmin && lastc;
+        if (!ok) {
+#pragma omp critical
+            rc = -2;
+        }
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            if (!ok) continue;
+            const int nj = nJ[b], nm = nM[b];
+            const int32_t *cn = conn + (size_t)b * 2 * nM_max;
+            const uint8_t *cb = cbits + (size_t)b * nJ_max;
+            const int32_t *pm = perm ? perm + (size_t)b * nJ_max : NULL;  /* joint k of the solve = joint pm[k] here */
+            int n = 0;
+            for (int k = 0; k < nj; ++k) {
+                const int j = pm ? pm[k] : k;
+                const int nf = 3 - ((cb[j] & 1) + ((cb[j] >> 1) & 1) + ((cb[j] >> 2) & 1));
+                first[j] = nf ? n : -1;
+                mincol[j] = nf ? n : 0x7fffffff;
+                n += nf;
+            }
+            for (int m = 0; m < nm; ++m) { /* a joint's rows reach back to the smallest free DOF of any neighbour */
+                const int a = cn[2 * m], c = cn[2 * m + 1];
+                if (first[c] >= 0 && first[c] < mincol[a]) mincol[a] = first[c];
+                if (first[a] >= 0 && first[a] < mincol[c]) mincol[c] = first[a];
+            }
+            const int npad = (n + 63) / 64 * 64, nch = npad / 16;
+            for (int q = 0; q < nch; ++q) cmin[q] = q;
+            for (int k = 0, dof = 0; k < nj; ++k) {
+                const int j = pm ? pm[k] : k;
+                if (first[j] < 0) continue;
+                const int nf = 3 - ((cb[j] & 1) + ((cb[j] >> 1) & 1) + ((cb[j] >> 2) & 1));
+                for (int s = 0; s < nf; ++s, ++dof)
+                    if (mincol[j] / 16 < cmin[dof / 16]) cmin[dof / 16] = mincol[j] / 16;
+            }
+            for (int q = nch - 2; q >= 0; --q)
+                if (cmin[q + 1] < cmin[q]) cmin[q] = cmin[q + 1]; /* ft */
+            for (int q = 0; q < nch; ++q) { /* chunk q owns the tiles ft[q] .. ft[q+1]-1 */
+                const int hi = q + 1 < nch ? cmin[q + 1] : nch;
+                for (int t = cmin[q]; t < hi; ++t) lastc[t] = q;
+            }
+            int widest = 0;
+            for (int j = 0; j < nch / 4; ++j)
+                if (lastc[4 * j + 3] - (4 * j + 3) > widest) widest = lastc[4 * j + 3] - (4 * j + 3);
+            reach[b] = widest;
+        }
+        free(first); free(mincol); free(cmin); free(lastc);
+    }
+    return rc;
+}
+
 /* Apply a joint order: joint k of the output is joint perm[b][k] of the input (members keep their
  * order, their end joints are renumbered; padding members stay (0, 0)).  Out-of-place. */
 int trs_apply_joint_order(int B, int nJ_max, int nM_max, const int32_t *perm, const int32_t *nM,

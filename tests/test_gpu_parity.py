@@ -529,6 +529,59 @@ def test_resident_batch_with_a_joint_order_delivers_results_in_the_given_numberi
                                                                 device=small.device))
 
 
+def test_launch_hints_and_forced_narrow_routing(gpu):
+    """`envelope_reach` (host) equals what `trs_assemble` derives on the device; a batch it clears runs with
+    TRS_ASM_ALL_NARROW / TRS_HINT_NO_WIDE / TRS_HINT_SUBSTITUTED (the kernels that would find nothing are not
+    launched) and gives the same bits; a truss with a WIDE envelope forced through the wave-per-matrix kernels
+    still matches the oracle (the hint can cost time, never correctness)."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    rng = np.random.default_rng(2)
+    cubes = gen.generate_cube_batch(rng.integers(60, 191, size=24), gridRange=(6, 6, 6), seed=9)
+    datas = [H.load_json("bar-942_input_0"), H.load_json("bar-120_input_0")]
+    for packed in (gpu.pack_json(datas), cubes, gpu.permute_joints(cubes, gpu.profile_permutation(cubes))):
+        plain = gpu.DeviceBatch(packed)
+        plain.all_narrow = False
+        plain.solve()
+        ref = plain.result()
+        env = plain.env.cpu().numpy()
+        nchm, npan = plain.rows // 16, plain.rows // 64
+        last = env[:, nchm:nchm + npan]
+        npads = (packed.n_free + 63) // 64
+        widest = np.array([max(int(last[b, j]) - (4 * j + 3) for j in range(int(npads[b]))) for b in range(packed.B)])
+        np.testing.assert_array_equal(gpu.envelope_reach(packed), widest)
+        wide_present = bool((env[:, nchm + npan] & 0xff != 1).any())
+        assert wide_present == bool(widest.max() > gpu.NARROW_MAX_BELOW)
+        forced = gpu.DeviceBatch(packed)
+        forced.all_narrow = True                       # also for the batch that holds wide envelopes
+        for how in ("one call", "stages"):
+            forced.u.fill_(float("nan"))
+            if how == "one call":
+                forced.solve()
+            else:
+                forced.dofmap(); forced.assemble(); forced.potrf(); forced.potrs(); forced.recover()
+            got = forced.result()
+            assert not got.info.any()
+            assert (forced.env.cpu().numpy()[:, nchm + npan] & 0xff == 1).all()      # every matrix routed narrow
+            if not wide_present:                       # same kernels, same bits
+                for k in ("displace", "external", "internal"):
+                    np.testing.assert_array_equal(getattr(got, k), getattr(ref, k))
+            else:
+                assert H.max_scaled_err(got.displace, ref.displace) <= 1e-9
+                assert H.max_scaled_err(got.internal, ref.internal) <= 1e-9
+    # and against the oracle for one truss of the wide batch
+    b = int(np.argmax(gpu.envelope_reach(cubes)))
+    assert gpu.envelope_reach(cubes)[b] > gpu.NARROW_MAX_BELOW
+    data = gen.packed_to_json(cubes, b)
+    want = orc.solve(data)
+    dev = gpu.DeviceBatch(cubes.take(np.array([b])))
+    dev.all_narrow = True
+    dev.solve()
+    got = dev.result()
+    nJ, nM = len(data["joint"]), len(data["member"])
+    assert H.max_scaled_err(got.displace[0, :nJ], want["u"]) <= 1e-8
+    assert H.max_scaled_err(got.internal[0, :nM], want["N"]) <= 1e-8
+
+
 def test_empty_batch_and_fully_constrained_truss(gpu):
     """Degenerate inputs: a batch of zero trusses, and a truss without free DOFs next to a normal one
     (the reference's solve of a 0 x 0 system gives zero displacements, forces and reactions)."""

@@ -8,7 +8,7 @@ _P, _I = ctypes.c_void_p, ctypes.c_int
 _lib.trs_slab_ld.restype = _lib.trs_slab_rows.restype = _I
 _lib.trs_solve.restype = _I
 _lib.trs_solve.argtypes = [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
-                           _P, _P, _P, _P, _P, _P, _P, _P]
+                           _P, _P, _P, _P, _P, _P, _P, _I, _P]
 _lib.trs_assemble_work_bytes.restype = ctypes.c_size_t
 _BITS = {0: 0, 1: 7, 2: 1, 3: 2, 4: 4}          # SupportType -> constrained-axis bits (type.py:48-74)
 
@@ -43,6 +43,7 @@ def solve_on_gpu(truss):
                         fi.data_ptr(), nf.data_ptr(), ld, rows, S.data_ptr(), uf.data_ptr(), rows,
                         u.data_ptr(), fx.data_ptr(), N.data_ptr(), info.data_ptr(), work.data_ptr(),
                         env.data_ptr(), None,   # joint_out: the joints keep their numbering
+                        0,                      # hints: nothing known about the envelopes
                         torch.cuda.current_stream().cuda_stream)
     if rc: raise RuntimeError(f"trs_solve: hipError_t {rc}")
     if int(info.item()): raise np.linalg.LinAlgError("Singular matrix")

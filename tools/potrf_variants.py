@@ -50,6 +50,7 @@ def main():
     stages = ("dofmap", "assemble", "potrf", "potrs", "recover")
     times = {t: {s: [] for s in stages} for t in args.tags}
     ref_u = None
+    narrow_known = dev.all_narrow
     options = {}
     for spec in args.option:
         tag, kv = spec.split(":")
@@ -59,6 +60,7 @@ def main():
     for rnd in range(args.rounds + 1):
         for tag in args.tags:
             dev.lib = libs[tag]
+            dev.all_narrow = narrow_known and not tag.endswith("nohint")   # 'tag@nohint': every kernel is launched
             for name, value, _ in options.get(tag, []):
                 assert libs[tag].trs_set_option(name, value) == 0, name
             evs = []
