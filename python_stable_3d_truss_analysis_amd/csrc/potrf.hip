@@ -809,6 +809,25 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
     Stamps st;  // 0 tile loads, 1 block update, 2 factorisation, 3 load column + block stores, 4 items, 5 fence
     st.start();
 
+    // The diagonal block's stiffness tiles and load-vector entries of a panel are not touched by the panel before
+    // it: in the slab form they are requested at the END of that panel, ahead of the fence that waits for its
+    // stores, so that their latency and the drain of the stores overlap instead of following each other.
+    d4 t[CT][CT];
+    double yr[CT];
+    auto load_block = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int s = 0; s <= u; ++s)
+#ifdef TRS_EXP_NO_KLOADS   // timing experiment only (wrong results): the stiffness tile loads
+                for (int r = 0; r < 4; ++r) t[u][s][r] = (u == s && (lane >> 4) + 4 * r == (lane & 15)) ? 1e6 : 0.0;
+#else
+                tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+#endif
+#pragma unroll
+        for (int s = 0; s < CT; ++s) yr[s] = YR.load((r0 + 16 * s) * 8);
+    };
+    if constexpr (!FUSED) load_block(0);
     for (int r0 = 0, panel = 0; r0 < npad && bad_col == 0; r0 += TRS_NB, ++panel) {
         const int kd = 16 * env.ft[4 * panel];
         // first written column of each of the block's four row chunks (their envelope)
@@ -820,8 +839,6 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
         // chunk u, replicated over the quarter-waves) and advanced with plain FMAs and lane reductions.
         // As a 16-wide MFMA operand chunk (round 1) it cost 104 of the ~240 MFMAs of a panel, 15/16 of
         // them on zero columns, on the FP64 datapath that the matrix core and the VALU share.
-        d4 t[CT][CT];
-        double yr[CT];
         int tb[CT] = {0, 0, 0, 0};  // first tile id of the panel's four slab chunks (FUSED)
         if constexpr (FUSED) {
 #pragma unroll
@@ -852,18 +869,6 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
             for (int u = 2; u < CT; ++u) ktile_take<true>(t[u][2], Kd, u - 2);
             krange_scatter<2>(Kd, f3, 0);
             ktile_take<false>(t[3][3], Kd, 0);
-        } else {
-#pragma unroll
-            for (int u = 0; u < CT; ++u)
-#pragma unroll
-                for (int s = 0; s <= u; ++s)
-#ifdef TRS_EXP_NO_KLOADS   // timing experiment only (wrong results): the stiffness tile loads
-                    for (int r = 0; r < 4; ++r) t[u][s][r] = (u == s && (lane >> 4) + 4 * r == (lane & 15)) ? 1e6 : 0.0;
-#else
-                    tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
-#endif
-#pragma unroll
-            for (int s = 0; s < CT; ++s) yr[s] = YR.load((r0 + 16 * s) * 8);
         }
         st.drain();
         st.mark(0);
@@ -1007,7 +1012,10 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
             }
         }
         st.mark(4);
-        // this wave's stores must have landed before its own loads of the next panel
+        // (unconditionally: behind the last panel the requests fall outside the descriptors' ranges and return
+        // zeros that nobody reads; a condition here would keep the old tiles alive beside the new ones)
+        if constexpr (!FUSED) load_block(r0 + TRS_NB);
+        // this wave's stores must have landed before its own loads of the next panel's block update
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         st.mark(5);
     }
