@@ -853,15 +853,13 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     needs_rho = on_device
     full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS if f != "rho" or needs_rho}
     original = dict(full)   # the caller's joint order (the reordering below makes new tensors)
-    perm32 = reach_new = None
-    reach_given = envelope_reach(packed) if B else np.zeros([0], dtype=np.int32)
+    perm32 = None
     if wants_order:
         if ordering is not None:
             host_perm = ordering.result()
             worker.shutdown(wait=False)
         else:
             host_perm = joint_order(packed, reorder)
-        reach_new = envelope_reach(packed, host_perm)
         perm32 = up(host_perm)                                               # [B, nJ_max] int32, joint k := old perm[k]
         perm = perm32.long()
         inverse = torch.empty_like(perm)
@@ -922,10 +920,9 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
         jout = None
         if renumbered:
             jout = perm32 if whole else perm32.index_select(0, rows)[:, :nJ_b].contiguous()
-        # no envelope of the bucket reaches beyond the wave-per-matrix kernels' range: the others are not launched
-        reach = (reach_new if renumbered else reach_given)[idx]
-        bucket = DeviceBatch.from_device(sub, n_b, joint_out=jout,
-                                         all_narrow=bool(len(reach) and reach.max() <= NARROW_MAX_BELOW))
+        # (no launch hints here: finding the envelopes' reach on the host costs a one-shot call more than
+        # the handful of empty launches it would save; a resident DeviceBatch does it once and keeps it)
+        bucket = DeviceBatch.from_device(sub, n_b, joint_out=jout)
         for slot, sec in enumerate(variants):
             if sec is not None:
                 bucket.A.fill_(float(sec[0]))

@@ -1016,7 +1016,9 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
         // zeros that nobody reads; a condition here would keep the old tiles alive beside the new ones)
         if constexpr (!FUSED) load_block(r0 + TRS_NB);
         // this wave's stores must have landed before its own loads of the next panel's block update
+#ifndef TRS_EXP_NO_PANEL_FENCE
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#endif
         st.mark(5);
     }
     st.flush();
