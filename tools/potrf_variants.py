@@ -94,7 +94,7 @@ def main():
         mn = {s: float(np.min(v)) for s, v in times[tag].items()}
         total = sum(med.values())
         print(f"{tag:>12}: potrf med {med['potrf']:.3f} min {mn['potrf']:.3f} ms | assemble {med['assemble']:.3f} "
-              f"| potrs {med['potrs']:.3f} | recover {med['recover']:.3f} | total {total:.3f} ms "
+              f"| potrs {med['potrs']:.3f} | recover {med['recover']:.3f} | dofmap {med['dofmap']:.4f} | total {total:.3f} ms "
               f"-> {args.batch / total * 1e3:.0f} solves/s")
 
 
