@@ -23,6 +23,8 @@ Written files:
   hetero_bar25.npz       HeteroData tensors of bar-25 for the four (task, metapath) combinations
   augment.json           the reference's data augmenters (generate.py:13-148) applied to bar-25 with
                          seeded `random`: expected joint lists per augmenter
+  cube_stats.npz         integer statistics of 200 reference samples per (GenerateMethod, LinkType, polycube
+                         size): the distribution the native generator (csrc/cubegen.c) must reproduce
 """
 import glob
 import json
@@ -278,9 +280,57 @@ def capture_augmenters(rg):
     print("augment.json:", sorted(out))
 
 
+CUBE_STAT_NAMES = ("nJ", "nM", "nPin", "nLoad", "maxDegree", "sumDegree2", "extentX", "extentY", "extentZ",
+                   "nDiagonal")
+CUBE_STAT_SIZES = (8, 30, 100)
+CUBE_STAT_SAMPLES = 200
+
+
+def cube_statistics(data):
+    """Integer statistics of one generated cube truss (JSON dict): sizes, supports, loads, the joint-degree
+    distribution (maximum and sum of squares), the polycube's extent in cells along each axis (the growth
+    method shows there: depth-first snakes vs breadth-first lumps) and the number of face diagonals (the link
+    type shows there).  Lengths are divided out through the three cell edge lengths = the smallest gap
+    between distinct coordinate values of an axis (a polycube is connected, so neighbouring planes are one
+    cell apart)."""
+    xyz = np.array([p for p, _ in data["joint"]], dtype=float)
+    conn = np.array([c for c, _ in data["member"]], dtype=int)
+    nJ, nM = len(xyz), len(conn)
+    deg = np.bincount(conn.ravel(), minlength=nJ)
+    cell = [float(np.diff(np.unique(xyz[:, a])).min()) for a in range(3)]
+    grid = np.rint(xyz / np.array(cell)).astype(int)
+    ext = grid.max(axis=0) - grid.min(axis=0)
+    step = np.abs(grid[conn[:, 0]] - grid[conn[:, 1]]).sum(axis=1)   # 1 = cube edge, 2 = face diagonal
+    assert set(np.unique(step)) <= {1, 2}
+    return [nJ, nM, sum(1 for _, s in data["joint"] if s == "PIN"), len(data["force"]), int(deg.max()),
+            int((deg.astype(np.int64) ** 2).sum()), int(ext[0]), int(ext[1]), int(ext[2]), int((step == 2).sum())]
+
+
+def capture_cube_stats(rty, rg):
+    """200 reference samples per GenerateMethod x LinkType x polycube size on the 6x6x6 grid
+    (generate.py:186-231,266-286,314-376), reduced to integers (a few KB)."""
+    out = {"names": np.array(CUBE_STAT_NAMES), "sizes": np.array(CUBE_STAT_SIZES)}
+    methods = {"DFS": rty.GenerateMethod.DFS, "BFS": rty.GenerateMethod.BFS, "Random": rty.GenerateMethod.Random}
+    links = {"LBRT": rty.LinkType.LeftBottom_RightTop, "RBLT": rty.LinkType.RightBottom_LeftTop,
+             "Cross": rty.LinkType.Cross, "Random": rty.LinkType.Random}
+    for mi, (mname, method) in enumerate(methods.items()):
+        for li, (lname, link) in enumerate(links.items()):
+            for num in CUBE_STAT_SIZES:
+                trusses = rg.GenerateRandomCubeTrusses(
+                    gridRange=(6, 6, 6), numCubeRange=(num, num), numEachRange=(1, CUBE_STAT_SAMPLES),
+                    method=method, linkType=link, isPrintMessage=False, seed=5000 + 100 * mi + 10 * li + num)
+                rows = [cube_statistics(t.Serialize()) for t in trusses]
+                out[f"{mname}/{lname}/{num}"] = np.array(rows, dtype=np.int32)
+            print(f"  cube stats {mname}/{lname}: nM mean", [float(out[f'{mname}/{lname}/{n}'][:, 1].mean())
+                                                               for n in CUBE_STAT_SIZES])
+    np.savez_compressed(os.path.join(HERE, "cube_stats.npz"), **out)
+
+
 def main():
     rt, rty, rg, rga = import_reference()
-    which = sys.argv[1:] or ["data", "cube", "edge", "ga", "hetero", "augment"]
+    which = sys.argv[1:] or ["data", "cube", "edge", "ga", "hetero", "augment", "stats"]
+    if "stats" in which:
+        capture_cube_stats(rty, rg)
     if "augment" in which:
         capture_augmenters(rg)
     if "data" in which:
