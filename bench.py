@@ -301,11 +301,9 @@ def main():
         torch.cuda.synchronize(device)
 
     packed = batch.pack_json([data]).replicate(args.batch)
-    if args.compact:
-        from python_stable_3d_truss_analysis_amd import _capi
-        _capi.check(_capi.load().trs_set_option(b"compact", 1), "trs_set_option")
     order = False if args.joint_order == "given" or args.dense else args.joint_order
-    dev = batch.DeviceBatch(packed, device, use_envelope=not args.dense, reorder=order)
+    dev = batch.DeviceBatch(packed, device, use_envelope=not args.dense, reorder=order,
+                            options={"compact": True} if args.compact else None)
     n, nJ, nM = int(packed.n_free[0]), int(packed.nJ[0]), int(packed.nM[0])
 
     def step(events=None, potrf_events=None):
@@ -386,7 +384,7 @@ def main():
     # next batch, solve and download of the previous one overlapped on three streams (batch.StreamedSolver)
     pcie = None
     if world == 1 and not args.no_pcie:
-        pipe = batch.StreamedSolver(packed, device, slots=2, use_envelope=not args.dense)
+        pipe = batch.StreamedSolver(packed, device, slots=2, use_envelope=not args.dense, same_topology=True)
         src = pipe.host_in[0]
         for _ in range(3):          # warm-up: first use of the page-locked buffers, allocator, clocks
             pipe.submit(src)

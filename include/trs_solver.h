@@ -34,13 +34,18 @@
  *    16 x 16 diagonal tile the entries below the diagonal (c > i, same tile) hold the strictly
  *    lower part of inv(L_tile) (its diagonal is 1 / U[c][c]); trs_potrs_batched uses it.
  *
- * Compact form (narrow envelopes; opt-in, trs_set_option("compact", 1)): trusses whose envelope is
- *    narrow enough for the wave-per-matrix factorisation do NOT get their stiffness matrix written to
+ * Compact form (narrow envelopes; opt-in per call, TRS_ASM_COMPACT + TRS_HINT_COMPACT): trusses whose envelope
+ *    is narrow enough for the wave-per-matrix factorisation do NOT get their stiffness matrix written to
  *    the slab at all.  trs_assemble leaves it in the truss's share of `work` as per-tile entry lists
  *    (value + position, ~10 bytes per non-zero instead of 2 KB per 16 x 16 tile; layout
  *    TrsCompactLayout in csrc/trs_common.h) and the load vector in uf; trs_potrf_batched forms the
  *    tiles from the lists where it consumes them and writes only the factor to the slab.  K_ff then
- *    never exists in dense form in HBM.  TRS_ASM_NO_COMPACT keeps the slab form for such trusses.
+ *    never exists in dense form in HBM.  Without the flag every matrix goes through the slab (the default:
+ *    measured faster end to end).
+ *
+ * Thread safety: the library keeps NO mutable process-wide state.  Everything that selects a kernel or a data
+ * path is an argument of the call (flags / hints below), so concurrent calls on distinct streams with distinct
+ * buffers do not interact.
  */
 #ifndef TRS_SOLVER_H
 #define TRS_SOLVER_H
@@ -52,35 +57,35 @@
 extern "C" {
 #endif
 
-#define TRS_ABI_VERSION 6
+#define TRS_ABI_VERSION 7
 
 /* trs_assemble flags */
 #define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests); implies the slab form */
-#define TRS_ASM_NO_COMPACT 2     /* narrow-envelope matrices too are written to the slab (tests, A/B runs) */
+#define TRS_ASM_COMPACT 2        /* narrow-envelope matrices leave as compact entry lists in `work` instead of slab
+                                    tiles (see "Compact form"); the same batch must then be factored with
+                                    TRS_HINT_COMPACT.  Ignored (slab form) where the lists cannot be held: with
+                                    TRS_ASM_FULL_SYMMETRIC, without uf, or for an envelope forced narrow by
+                                    TRS_ASM_ALL_NARROW that reaches further than the lists are sized for */
 #define TRS_ASM_ALL_NARROW 4     /* every matrix is routed to the wave-per-matrix kernels, whatever its envelope */
 
 /* hints of trs_potrf_batched / trs_potrs_batched / trs_solve: what the caller knows about the batch, so that
  * kernels that would find no matrix of theirs are not launched at all (each such launch costs 4-9 us).
  * A hint never changes a result when it is true; a FALSE hint leaves matrices unprocessed. */
 #define TRS_HINT_NO_WIDE 1       /* trs_assemble ran with TRS_ASM_ALL_NARROW: no matrix for the work-group kernels */
-#define TRS_HINT_SUBSTITUTED 2   /* trs_potrs_batched only: trs_potrf_batched ran with the fused substitution on and
-                                    no system has more than 1024 rows: nothing is left for the wave-per-matrix
-                                    substitution either (a matrix with a failed pivot stays unsolved: info[b] > 0) */
+#define TRS_HINT_SUBSTITUTED 2   /* trs_potrs_batched only: trs_potrf_batched ran with the fused substitution (no
+                                    TRS_HINT_SEPARATE_STAGES) and no system has more than 1024 rows: nothing is left
+                                    for the wave-per-matrix substitution either (a matrix with a failed pivot stays
+                                    unsolved: info[b] > 0) */
+/* per-call selectors (they replace the process-wide switches of ABI <= 6; none changes a result) */
+#define TRS_HINT_COMPACT 4           /* trs_potrf_batched / trs_solve: the batch was (is to be) assembled with
+                                        TRS_ASM_COMPACT: also launch the kernel instance that forms tiles from lists */
+#define TRS_HINT_SEPARATE_STAGES 8   /* trs_potrf_batched / trs_solve: the factorising wave does NOT go on to the
+                                        back substitution; trs_potrs_batched substitutes every matrix */
+#define TRS_HINT_NO_SMALL 16         /* trs_solve: never the fused small-system kernel, always the staged pipeline */
+#define TRS_HINT_RECOVER_UNSTAGED 32 /* trs_recover / trs_solve: the path for trusses whose tables exceed a CU's LDS
+                                        (u, f_ext in the output arrays, reactions by FP64 atomics), whatever the size */
 
 int trs_abi_version(void);
-
-/* Process-wide switches for tests and diagnostics (no effect on results):
- *   "recover_unstaged" 0/1  force trs_recover's path for trusses whose tables exceed a CU's LDS;
- *   "small_path"       1/0  let trs_solve take the fused small-system kernel (default 1);
- *   "compact"          0/1  1: trs_assemble leaves narrow-envelope matrices as compact entry lists and
- *                           trs_potrf_batched forms the tiles from them (see "Compact form" above);
- *                           0 (default): TRS_ASM_NO_COMPACT on every call, the matrix goes through the slab.
- *   "fused_substitution" 1/0  the factorising wave of a narrow-envelope matrix substitutes it as well
- *                           (default 1; see trs_potrf_batched).
- * Returns 0, or hipErrorInvalidValue for an unknown name. */
-int trs_set_option(const char *name, int value);
-/* Current value of "small_path", "compact" or "fused_substitution"; -1 for any other name. */
-int trs_get_option(const char *name);
 
 /* Leading dimension / row count of the stiffness slab for a batch whose largest reduced
  * system has n_max free DOFs. */
@@ -129,7 +134,7 @@ int trs_assemble(int B, int nJ_max, int nM_max,
  * the reference, potrf here because K_ff is SPD for a stable truss).
  * info[b] = 0 on success, k > 0 when the pivot of column k (1-based) is not positive
  * (the reference raises numpy.linalg.LinAlgError for an exactly singular matrix).
- * Fused substitution (default; trs_set_option("fused_substitution", 0) keeps the stages apart): the wave that
+ * Fused substitution (default; TRS_HINT_SEPARATE_STAGES keeps the stages apart): the wave that
  * factors a narrow-envelope matrix of at most 1024 rows goes straight on to the back substitution, while the
  * factor's last panels are still cached.  uf[b] then holds the reduced DISPLACEMENTS when this call returns,
  * bit 0x400 of the matrix's routing word in env says so, and trs_potrs_batched skips the matrix - callers who
@@ -162,7 +167,8 @@ int trs_recover(int B, int nJ_max, int nM_max, const double *xyz, const int32_t 
                 const int32_t *free_index, const int32_t *nJ, const int32_t *nM,
                 const double *uf, int ld_uf, double *u /* [B][nJ_max][3] */,
                 double *f_ext /* [B][nJ_max][3] */, double *N /* [B][nM_max] */,
-                const int32_t *joint_out /* [B][nJ_max] or NULL */, void *stream);
+                const int32_t *joint_out /* [B][nJ_max] or NULL */,
+                int hints /* TRS_HINT_RECOVER_UNSTAGED or 0 */, void *stream);
 
 /* Constraint reductions of the GA fitness (truss.py:166-168,429-462; ga.py:139-149):
  *   weight[b]   = sum_m A*L*rho
@@ -220,7 +226,10 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound,
               int32_t *free_index, int32_t *n_free, int ld, int slab_rows, double *S,
               double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info,
               void *work, int32_t *env /* workspace for the envelope metadata, or NULL = dense */,
-              const int32_t *joint_out /* [B][nJ_max] or NULL */, int hints /* TRS_HINT_NO_WIDE: route and treat every matrix as narrow */, void *stream);
+              const int32_t *joint_out /* [B][nJ_max] or NULL */,
+              int hints /* TRS_HINT_NO_WIDE: route and treat every matrix as narrow; TRS_HINT_COMPACT,
+                           TRS_HINT_SEPARATE_STAGES, TRS_HINT_NO_SMALL, TRS_HINT_RECOVER_UNSTAGED as above */,
+              void *stream);
 
 #ifdef __cplusplus
 }

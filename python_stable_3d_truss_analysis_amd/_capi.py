@@ -18,8 +18,6 @@ _D = ctypes.c_double
 #: every symbol `include/trs_solver.h` declares -> (restype, argtypes)
 SIGNATURES = {
     "trs_abi_version": (_I, []),
-    "trs_get_option": (_I, [ctypes.c_char_p]),
-    "trs_set_option": (_I, [ctypes.c_char_p, _I]),
     "trs_slab_ld": (_I, [_I]),
     "trs_slab_rows": (_I, [_I]),
     "trs_dofmap": (_I, [_I, _I, _P, _P, _P, _P, _P]),
@@ -28,7 +26,7 @@ SIGNATURES = {
     "trs_assemble": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "trs_potrf_batched": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "trs_potrs_batched": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _I, _P]),
-    "trs_recover": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "trs_recover": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     "trs_fitness": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _P, _P, _P, _P]),
     "trs_solve_small_fits": (_I, [_I, _I, _I]),
     "trs_solve_small": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -40,7 +38,7 @@ SIGNATURES = {
 }
 
 #: must equal TRS_ABI_VERSION of include/trs_solver.h
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -76,10 +74,6 @@ def load():
         fn.argtypes = argtypes
     if lib.trs_abi_version() != ABI_VERSION:
         raise HipExtensionError("libtrs_hip.so ABI version mismatch")
-    # A/B runs of the tools: TRS_OPTIONS="name=value,name=value" -> trs_set_option at load time
-    for item in filter(None, os.environ.get("TRS_OPTIONS", "").split(",")):
-        name, _, value = item.partition("=")
-        check(lib.trs_set_option(name.strip().encode(), int(value)), f"TRS_OPTIONS: trs_set_option({name!r})")
     _lib = lib
     return lib
 

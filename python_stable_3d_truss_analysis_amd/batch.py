@@ -246,6 +246,28 @@ def _require_gpu(device):
     return torch, torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
 
 
+#: per-batch switches of the pipeline and their defaults.  None of them changes a result; they select
+#: between kernels that compute the same thing (A/B runs, tests).  They travel as flags / hints of every C
+#: call (include/trs_solver.h) - the library has no process-wide state - and are attributes of a
+#: `DeviceBatch` (`dev.options["compact"] = True`, or `DeviceBatch(..., options={...})`).
+#:   compact             K_ff leaves the assembly as compact entry lists, tiles formed in the factorisation
+#:   fused_substitution  the wave that factors a narrow-envelope matrix substitutes it as well
+#:   recover_unstaged    force trs_recover's path for trusses whose tables exceed a CU's LDS
+DEFAULT_OPTIONS = {"compact": False, "fused_substitution": True, "recover_unstaged": False}
+
+
+def default_options():
+    """`DEFAULT_OPTIONS`, overridden by the environment variable TRS_OPTIONS="name=value,name=value" (A/B runs
+    of the tools without touching code); an unknown name is an error."""
+    opts = dict(DEFAULT_OPTIONS)
+    for item in filter(None, os.environ.get("TRS_OPTIONS", "").split(",")):
+        name, _, value = item.partition("=")
+        if name.strip() not in opts:
+            raise ValueError(f"TRS_OPTIONS: unknown option {name.strip()!r} (known: {sorted(opts)})")
+        opts[name.strip()] = bool(int(value))
+    return opts
+
+
 class DeviceBatch:
     """A packed batch resident in HBM plus the workspace of the pipeline.
 
@@ -254,7 +276,8 @@ class DeviceBatch:
     """
     INPUT_FIELDS = ("xyz", "conn", "E", "A", "rho", "cbits", "loads", "nJ", "nM")
 
-    def __init__(self, packed: PackedBatch, device=None, use_envelope=True, use_small=True, reorder=False):
+    def __init__(self, packed: PackedBatch, device=None, use_envelope=True, use_small=True, reorder=False,
+                 options=None):
         """`use_envelope=False` treats every reduced stiffness matrix as dense (no tile skipping);
         `use_small=False` keeps a batch of small trusses off the fused single-kernel path
         (`trs_solve_small`) and sends it through the staged pipeline; `reorder` (see `joint_order`) uploads
@@ -270,6 +293,7 @@ class DeviceBatch:
             resident = permute_joints(packed, perm)
         self._setup(torch, dev, {f: up(getattr(resident, f)) for f in self.INPUT_FIELDS},
                     packed.B, packed.nJ_max, packed.nM_max, packed.n_max, use_envelope, use_small)
+        self.options.update(options or {})
         if perm is not None:
             self.joint_out = up(perm)
         # what the host can tell the launches about this batch (see `all_narrow`)
@@ -321,6 +345,7 @@ class DeviceBatch:
         #: either way - with the flag the device routes so regardless - it only must not outlive the topology.
         self.all_narrow = False
         self._potrf_fused = False
+        self.options = default_options()
 
     def _workspace(self):
         """Stiffness slab, reduced solution, assembly workspace and envelope metadata of the staged
@@ -362,9 +387,16 @@ class DeviceBatch:
         fused = substituted and self.rows <= 1024 and self._potrf_fused
         return HINT_NO_WIDE | (HINT_SUBSTITUTED if fused else 0)
 
+    def _stage_hints(self):
+        return (HINT_COMPACT if self.options["compact"] and self.env is not None else 0) | \
+               (0 if self.options["fused_substitution"] else HINT_SEPARATE_STAGES) | \
+               (HINT_RECOVER_UNSTAGED if self.options["recover_unstaged"] else 0)
+
     def assemble(self, flags=0):
         if self.all_narrow and self.env is not None:
             flags |= ASM_ALL_NARROW
+        if self.options["compact"] and self.env is not None:
+            flags |= ASM_COMPACT
         _capi.check(self.lib.trs_assemble(
             self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
             self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
@@ -373,11 +405,12 @@ class DeviceBatch:
             self._stream()), "trs_assemble")
 
     def potrf(self):
-        self._potrf_fused = self.lib.trs_get_option(b"fused_substitution") == 1
+        self._potrf_fused = bool(self.options["fused_substitution"])
         _capi.check(self.lib.trs_potrf_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
                                                self.S.data_ptr(), self.info.data_ptr(), self._env_ptr(),
                                                self.work.data_ptr(), self.uf.data_ptr(), self.rows,
-                                               self._hints(), self._stream()), "trs_potrf_batched")
+                                               self._hints() | (self._stage_hints() & (HINT_COMPACT | HINT_SEPARATE_STAGES)),
+                                               self._stream()), "trs_potrf_batched")
 
     def potrs(self):
         _capi.check(self.lib.trs_potrs_batched(self.B, self.n_free.data_ptr(), self.ld, self.rows,
@@ -391,7 +424,8 @@ class DeviceBatch:
             self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
             self.nJ.data_ptr(), self.nM.data_ptr(), self.uf.data_ptr(), self.rows, self.u.data_ptr(),
             self.f_ext.data_ptr(), self.N.data_ptr(),
-            self.joint_out.data_ptr() if self.joint_out is not None else None, self._stream()), "trs_recover")
+            self.joint_out.data_ptr() if self.joint_out is not None else None,
+            self._stage_hints() & HINT_RECOVER_UNSTAGED, self._stream()), "trs_recover")
 
     def _solve_small(self, fitness=None):
         """`trs_solve_small`: the whole of `Truss.Solve()` in one kernel (optionally with the GA
@@ -426,12 +460,6 @@ class DeviceBatch:
         if self.small:
             self._solve_small()
             return
-        if self.lib.trs_solve_small_fits(self.nJ_max, self.nM_max, self.n_max):
-            # small enough for the fused kernel but asked to stay off it: the stages one by one
-            # (trs_solve itself would pick the fused kernel)
-            with self.torch.cuda.device(self.device):
-                self.dofmap(); self.assemble(); self.potrf(); self.potrs(); self.recover()
-            return
         with self.torch.cuda.device(self.device):
             _capi.check(self.lib.trs_solve(
                 self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), self.conn.data_ptr(),
@@ -441,8 +469,9 @@ class DeviceBatch:
                 self.rows, self.u.data_ptr(), self.f_ext.data_ptr(), self.N.data_ptr(),
                 self.info.data_ptr(), self.work.data_ptr(), self._env_ptr(),
                 self.joint_out.data_ptr() if self.joint_out is not None else None,
-                HINT_NO_WIDE if self.all_narrow and self.env is not None else 0, self._stream()),
-                "trs_solve")
+                # (not on the fused small path here, by shape or by request: the staged pipeline in any case)
+                (HINT_NO_WIDE if self.all_narrow and self.env is not None else 0) | self._stage_hints() | HINT_NO_SMALL,
+                self._stream()), "trs_solve")
 
     def fitness(self, allow_stress, allow_displace):
         """(weight, stress_violation, displacement_violation) per truss, on device."""
@@ -505,10 +534,16 @@ class StreamedSolver:
     solve reads is uploaded (`fields`; the densities are not part of `Truss.Solve()`)."""
 
     def __init__(self, template: PackedBatch, device=None, slots=2, use_envelope=True,
-                 fields=("xyz", "conn", "E", "A", "cbits", "loads", "nJ", "nM")):
+                 fields=("xyz", "conn", "E", "A", "cbits", "loads", "nJ", "nM"), same_topology=False):
+        """`same_topology=True`: every batch of the stream has the template's connectivity and supports (only
+        coordinates, sections and loads vary - a parameter study, a GA, a replicated benchmark batch), so the
+        launch hints the host derived from the template's envelopes hold for all of them."""
         torch, dev = _require_gpu(device)
         self.torch, self.device, self.fields = torch, dev, tuple(fields)
         self.dev = [DeviceBatch(template, dev, use_envelope=use_envelope) for _ in range(slots)]
+        if not same_topology:   # the batches that follow need not share the template's envelopes: no launch hints
+            for d in self.dev:
+                d.all_narrow = False
         self.host_in = [{f: v for f, v in d.pinned_inputs(template).items() if f in self.fields} for d in self.dev]
         self.host_out = [{k: torch.empty(getattr(self.dev[0], k).shape, dtype=getattr(self.dev[0], k).dtype).pin_memory()
                           for k in ("u", "f_ext", "N", "info")} for _ in range(slots + 1)]
@@ -610,7 +645,9 @@ def profile_permutation(packed: PackedBatch, return_choice=False, effort=2):
 
 
 NARROW_MAX_BELOW = 24   # csrc/trs_common.h TRS_NARROW_MAX_BELOW: reach up to which a matrix goes to a wave of its own
-HINT_NO_WIDE, HINT_SUBSTITUTED, ASM_ALL_NARROW = 1, 2, 4   # include/trs_solver.h
+# include/trs_solver.h
+HINT_NO_WIDE, HINT_SUBSTITUTED, HINT_COMPACT, HINT_SEPARATE_STAGES, HINT_NO_SMALL, HINT_RECOVER_UNSTAGED = 1, 2, 4, 8, 16, 32
+ASM_FULL_SYMMETRIC, ASM_COMPACT, ASM_ALL_NARROW = 1, 2, 4
 
 
 def envelope_reach(packed: PackedBatch, perm=None):
@@ -809,7 +846,7 @@ class ResultPool:
 
 
 def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False, sections=None,
-                on_device=False, pool=None):
+                on_device=False, pool=None, options=None):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
 
     The packed inputs go up once; a ragged batch is bucketed by padded system size
@@ -830,7 +867,8 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
 
     Host side of a large batch: the joint order is found on a worker thread while the inputs go up; a
     `PackedBatch.pinned()` uploads by DMA; `pool=ResultPool()` downloads into reused page-locked buffers
-    (the returned arrays are then views of the pool, valid until its next use)."""
+    (the returned arrays are then views of the pool, valid until its next use).  `options`: per-call switches
+    of the pipeline (`DEFAULT_OPTIONS`), for A/B runs and tests."""
     packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
         else pack_trusses(list(trusses_or_packed))
     torch, dev = _require_gpu(device)
@@ -923,6 +961,7 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
         # (no launch hints here: finding the envelopes' reach on the host costs a one-shot call more than
         # the handful of empty launches it would save; a resident DeviceBatch does it once and keeps it)
         bucket = DeviceBatch.from_device(sub, n_b, joint_out=jout)
+        bucket.options.update(options or {})
         for slot, sec in enumerate(variants):
             if sec is not None:
                 bucket.A.fill_(float(sec[0]))

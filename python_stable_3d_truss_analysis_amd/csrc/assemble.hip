@@ -304,10 +304,12 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             for (int off = 32; off > 0; off >>= 1) widest = max(widest, __shfl_xor(widest, off));
             // which factorisation kernel will take this matrix decides the shape of the stored part
             const bool narrow = widest <= TRS_NARROW_MAX_BELOW || (flags & TRS_ASM_ALL_NARROW) != 0;
-            // narrow envelopes leave as compact entry lists (phase 1c) unless the caller asked for the
-            // slab (tests, A/B runs) or the list tables do not fit next to this batch's other tables
-            const bool compact = narrow && compact_ok != 0 && !full && uf_all != nullptr &&
-                                 (flags & TRS_ASM_NO_COMPACT) == 0;
+            // narrow envelopes leave as compact entry lists (phase 1c) when the caller asked for them
+            // (TRS_ASM_COMPACT) and the lists can be held: the tables fit next to this batch's other tables,
+            // and the envelope is narrow by its own reach - a matrix only FORCED narrow (TRS_ASM_ALL_NARROW)
+            // may store more tiles per chunk than the lists are sized for (ntile_cap) and keeps the slab
+            const bool compact = narrow && widest <= TRS_NARROW_MAX_BELOW && compact_ok != 0 && !full &&
+                                 uf_all != nullptr && (flags & TRS_ASM_COMPACT) != 0;
             if (tid == 0) {
                 int* meta = env + n_pad_max / 16 + n_pad_max / 64;
                 meta[0] = ((narrow ? TRS_NARROW_ITEM : TRS_WIDE_ITEM) - 1) | (compact ? TRS_ENV_COMPACT : 0) |

@@ -15,10 +15,7 @@ int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int
 int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, const int*, int, hipStream_t);
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, const int*, const double*, int, double*,
-                       double*, double*, const int*, hipStream_t);
-void trs_recover_set_unstaged(int);
-void trs_potrf_set_fused_substitution(int);
-int trs_potrf_fused_substitution(void);
+                       double*, double*, const int*, int, hipStream_t);
 int trs_solve_small_fits(int, int, int);
 int trs_solve_small_launch(int, int, int, int, const double*, const int*, const double*, const double*,
                            const uint8_t*, const double*, const int*, const int*, double*, double*, double*,
@@ -39,39 +36,6 @@ inline bool bad_slab(int ld, int slab_rows) {
 extern "C" {
 
 int trs_abi_version(void) { return TRS_ABI_VERSION; }
-
-static int g_small_path = 1;  // trs_set_option("small_path", 0): trs_solve never takes the fused kernel
-// trs_set_option("compact", 1): trs_assemble leaves narrow-envelope matrices as compact entry lists and the
-// fused wave-per-matrix factorisation forms the tiles from them.  Off by default: on bar-942 x 4096 the
-// fused factorisation pays for the bytes it saves with LDS and issue slots.
-static int g_compact = 0;
-
-int trs_set_option(const char* name, int value) {
-    if (name != nullptr && strcmp(name, "recover_unstaged") == 0) {
-        trs_recover_set_unstaged(value != 0);
-        return 0;
-    }
-    if (name != nullptr && strcmp(name, "small_path") == 0) {
-        g_small_path = value != 0;
-        return 0;
-    }
-    if (name != nullptr && strcmp(name, "compact") == 0) {
-        g_compact = value != 0;
-        return 0;
-    }
-    if (name != nullptr && strcmp(name, "fused_substitution") == 0) {
-        trs_potrf_set_fused_substitution(value != 0);
-        return 0;
-    }
-    return (int)hipErrorInvalidValue;
-}
-
-int trs_get_option(const char* name) {
-    if (name != nullptr && strcmp(name, "small_path") == 0) return g_small_path;
-    if (name != nullptr && strcmp(name, "compact") == 0) return g_compact;
-    if (name != nullptr && strcmp(name, "fused_substitution") == 0) return trs_potrf_fused_substitution();
-    return -1;
-}
 
 int trs_solve_small(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz, const int32_t* conn,
                     const double* E, const double* A, const uint8_t* cbits, const double* loads,
@@ -106,7 +70,6 @@ int trs_assemble(int B, int nJ_max, int nM_max, const double* xyz, const int32_t
     if (uf != nullptr && ld_uf < slab_rows) return (int)hipErrorInvalidValue;
     // with envelope metadata the wave-per-matrix factorisation reads the load vector from uf
     if (env != nullptr && uf == nullptr && B > 0) return (int)hipErrorInvalidValue;
-    if (!g_compact) flags |= TRS_ASM_NO_COMPACT;
     return trs_assemble_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM,
                                ld, (size_t)slab_rows * ld, slab_rows, S, flags, work, env, uf, ld_uf,
                                (hipStream_t)stream);
@@ -117,7 +80,7 @@ int trs_potrf_batched(int B, const int32_t* n_free, int ld, int slab_rows, doubl
     if (B < 0 || bad_slab(ld, slab_rows) || (B > 0 && (uf == nullptr || ld_uf < slab_rows)))
         return (int)hipErrorInvalidValue;
     return trs_potrf_launch(B, n_free, ld, (size_t)slab_rows * ld, slab_rows, S, info, env, work, uf, ld_uf,
-                            g_compact, hints, (hipStream_t)stream);
+                            (hints & TRS_HINT_COMPACT) != 0, hints, (hipStream_t)stream);
 }
 
 int trs_potrs_batched(int B, const int32_t* n_free, int ld, int slab_rows, const double* S, double* uf,
@@ -130,10 +93,11 @@ int trs_potrs_batched(int B, const int32_t* n_free, int ld, int slab_rows, const
 int trs_recover(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const double* E,
                 const double* A, const double* loads, const int32_t* free_index, const int32_t* nJ,
                 const int32_t* nM, const double* uf, int ld_uf, double* u, double* f_ext, double* N,
-                const int32_t* joint_out, void* stream) {
+                const int32_t* joint_out, int hints, void* stream) {
     if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
     return trs_recover_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf,
-                              u, f_ext, N, joint_out, (hipStream_t)stream);
+                              u, f_ext, N, joint_out, (hints & TRS_HINT_RECOVER_UNSTAGED) != 0,
+                              (hipStream_t)stream);
 }
 
 int trs_fitness(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const double* A,
@@ -150,7 +114,8 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
               const int32_t* nJ, const int32_t* nM, int32_t* free_index, int32_t* n_free, int ld,
               int slab_rows, double* S, double* uf, int ld_uf, double* u, double* f_ext, double* N,
               int32_t* info, void* work, int32_t* env, const int32_t* joint_out, int hints, void* stream) {
-    if (g_small_path && !joint_out && trs_solve_small_fits(nJ_max, nM_max, n_max_bound))  // everything in one kernel
+    if ((hints & TRS_HINT_NO_SMALL) == 0 && !joint_out &&
+        trs_solve_small_fits(nJ_max, nM_max, n_max_bound))  // everything in one kernel
         return trs_solve_small(B, nJ_max, nM_max, n_max_bound, xyz, conn, E, A, cbits, loads, nJ, nM, u,
                                f_ext, N, info, free_index, n_free, nullptr, 0.0, 0.0, nullptr, nullptr,
                                nullptr, stream);
@@ -158,18 +123,22 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
     int rc = trs_dofmap(B, nJ_max, cbits, nJ, free_index, n_free, stream);
     if (rc) return rc;
     const int no_wide = env != nullptr && (hints & TRS_HINT_NO_WIDE) != 0;
-    rc = trs_assemble(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM, ld,
-                      slab_rows, S, no_wide ? TRS_ASM_ALL_NARROW : 0, work, env, uf, ld_uf, stream);
+    const int compact = env != nullptr && (hints & TRS_HINT_COMPACT) != 0;
+    const int fused = (hints & TRS_HINT_SEPARATE_STAGES) == 0;
+    rc = trs_assemble(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM, ld, slab_rows, S,
+                      (no_wide ? TRS_ASM_ALL_NARROW : 0) | (compact ? TRS_ASM_COMPACT : 0), work, env, uf, ld_uf,
+                      stream);
     if (rc) return rc;
-    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, env, work, uf, ld_uf, no_wide ? TRS_HINT_NO_WIDE : 0,
-                           stream);
+    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, env, work, uf, ld_uf,
+                           (no_wide ? TRS_HINT_NO_WIDE : 0) | (compact ? TRS_HINT_COMPACT : 0) |
+                               (fused ? 0 : TRS_HINT_SEPARATE_STAGES), stream);
     if (rc) return rc;
     rc = trs_potrs_batched(B, n_free, ld, slab_rows, S, uf, ld_uf, env,
-                           no_wide ? (TRS_HINT_NO_WIDE | (trs_potrf_fused_substitution() && slab_rows <= 1024
-                                                              ? TRS_HINT_SUBSTITUTED : 0)) : 0, stream);
+                           no_wide ? (TRS_HINT_NO_WIDE | (fused && slab_rows <= 1024 ? TRS_HINT_SUBSTITUTED : 0)) : 0,
+                           stream);
     if (rc) return rc;
     return trs_recover(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf, u,
-                       f_ext, N, joint_out, stream);
+                       f_ext, N, joint_out, hints & TRS_HINT_RECOVER_UNSTAGED, stream);
 }
 
 }  // extern "C"

@@ -1049,10 +1049,6 @@ extern "C" int trs_debug_stamps(unsigned long long* host_out, int reset) {
 }
 #endif
 
-static int g_fused_substitution = 1;  // trs_set_option("fused_substitution", 0 / 1)
-extern "C" void trs_potrf_set_fused_substitution(int on) { g_fused_substitution = on; }
-extern "C" int trs_potrf_fused_substitution(void) { return g_fused_substitution; }
-
 extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_stride, int n_pad_max,
                                 double* S, int* info, const int* env, const void* work, double* uf,
                                 int ld_uf, int compact_possible, int hints, hipStream_t stream) {
@@ -1061,6 +1057,8 @@ extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_st
     // the offset range being the "tile not stored" marker (Slab::gone)
     if (slab_stride * sizeof(double) >= (size_t)1 << 31) return (int)hipErrorInvalidValue;
     if (uf == nullptr || ld_uf < n_pad_max) return (int)hipErrorInvalidValue;
+    // the factorising wave of a narrow-envelope matrix substitutes it as well unless the caller keeps the stages apart
+    const int fused_substitution = (hints & TRS_HINT_SEPARATE_STAGES) == 0;
     if (env != nullptr) {
         // the wave-per-matrix kernels: each takes the matrices trs_assemble routed to it (csrc/trs_common.h)
         const dim3 grid((B + MPW - 1) / MPW), block(64 * MPW);
@@ -1068,15 +1066,15 @@ extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_st
         int rc = 0;
         if (compact_possible) {  // (the compact form is opt-in: no launch while it is switched off)
             hipLaunchKernelGGL((trs_potrf_narrow_kernel<true, 2>), grid, block, 0, stream, S, n_free, ld, slab_stride,
-                               info, env, n_pad_max, B, wk, uf, ld_uf, g_fused_substitution);
+                               info, env, n_pad_max, B, wk, uf, ld_uf, fused_substitution);
             if ((rc = (int)hipGetLastError())) return rc;
         }
         hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 2>), grid, block, 0, stream, S, n_free, ld, slab_stride,
-                           info, env, n_pad_max, B, wk, uf, ld_uf, g_fused_substitution);
+                           info, env, n_pad_max, B, wk, uf, ld_uf, fused_substitution);
         if ((rc = (int)hipGetLastError())) return rc;
         if (TRS_NARROW_RS4_ABOVE <= TRS_NARROW_MAX_BELOW) {  // (compile-time: see trs_common.h)
             hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 4>), grid, block, 0, stream, S, n_free, ld, slab_stride,
-                               info, env, n_pad_max, B, wk, uf, ld_uf, g_fused_substitution);
+                               info, env, n_pad_max, B, wk, uf, ld_uf, fused_substitution);
             if ((rc = (int)hipGetLastError())) return rc;
         }
     }

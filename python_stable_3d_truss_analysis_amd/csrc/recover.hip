@@ -222,19 +222,16 @@ __global__ __launch_bounds__(256) void trs_fitness_kernel(
 
 }  // namespace
 
-static int g_recover_unstaged = 0;  // trs_set_option("recover_unstaged", 1): tests force the large-truss path
-extern "C" void trs_recover_set_unstaged(int on) { g_recover_unstaged = on; }
-
 extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
                                   const double* E, const double* A, const double* loads,
                                   const int* free_index, const int* nJ, const int* nM,
                                   const double* uf, int ld_uf, double* u, double* f_ext, double* N,
-                                  const int* joint_out, hipStream_t stream) {
+                                  const int* joint_out, int force_unstaged, hipStream_t stream) {
     if (B <= 0) return 0;
     // u, f_ext (doubles) + member-end tables (ints)
     const size_t lds = ((size_t)6 * nJ_max * sizeof(double) +
                         ((size_t)2 * nJ_max + 1 + 2 * (size_t)nM_max) * sizeof(int) + 15) / 16 * 16;
-    if (lds > 160 * 1024 || g_recover_unstaged) {
+    if (lds > 160 * 1024 || force_unstaged) {
         hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), 0, stream, xyz, conn, E, A, loads,
                            free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out);
         return (int)hipGetLastError();

@@ -16,6 +16,8 @@ calls (`hetero_tensors_batch`), the features are built with array arithmetic, an
 `torch_geometric.data.HeteroData` when PyG is importable, otherwise the same nested mapping
 (`GraphStores`).  The reference solves twice per sample in Python (`data.py:20-23,107-114`).
 """
+import os
+
 import numpy as np
 
 from .batch import BatchResult, PackedBatch, pack_trusses
@@ -331,9 +333,12 @@ def solve_actual_and_prior(packed: PackedBatch, fixedMemberType=None, device=Non
     `fixedMemberType` (reference `data.py:107-114`).  The two solves differ only in A and E, so the
     geometry is uploaded, reordered (`batch.joint_order`) and bucketed ONCE (`solve_batch(..., sections=[...])`).
 
-    With more than one GPU (`devices` = list of device names, `pool` = a running
-    `shard.ShardedSolver`, or - when neither `device` nor `devices` is given - every visible GPU) the
-    batch is sharded over one worker process per GPU.
+    Sharding over several GPUs (one worker process per GPU) happens only when the caller
+    asks for it: `pool` = a running `shard.ShardedSolver` (keep one for a stream of batches) or `devices` = a
+    list of more than one device name (one-shot pool, started and stopped inside this call - worth it for
+    large batches only).  Otherwise the batch is solved in THIS process on `device` (default: `cuda:LOCAL_RANK`
+    under a launcher, else the current device) - a single truss of `TrussHeteroDataCreator` never starts
+    worker processes, and the ranks of a `torchrun` job do not fan out over each other's GPUs.
     `need_actual=False` skips the solve with the real sections (the truss is already solved)."""
     from .batch import solve_batch
     sections = ([None] if need_actual else []) + \
@@ -341,17 +346,18 @@ def solve_actual_and_prior(packed: PackedBatch, fixedMemberType=None, device=Non
                 if fixedMemberType is not None else [])
     if not sections:
         return None, None
-    if pool is None and devices is None and device is None:
-        from .shard import visible_devices
-        seen = visible_devices()
-        devices = seen if len(seen) > 1 else None
     if pool is not None:
         out = pool.solve(packed, reorder=reorder, sections=sections)
     elif devices is not None and len(devices) > 1:
         from .shard import solve_batch_sharded
         out = solve_batch_sharded(packed, devices, reorder=reorder, sections=sections)
     else:
-        out = solve_batch(packed, devices[0] if devices else device, reorder=reorder, sections=sections)
+        if devices:
+            device = devices[0]
+        if device is None and "LOCAL_RANK" in os.environ:
+            import torch
+            device = f"cuda:{int(os.environ['LOCAL_RANK']) % max(1, torch.cuda.device_count())}"
+        out = solve_batch(packed, device, reorder=reorder, sections=sections)
     actual = out[0] if need_actual else None
     prior = out[-1] if fixedMemberType is not None else None
     return actual, prior
@@ -371,14 +377,33 @@ def _dense_from_truss(truss):
     return BatchResult(u, f, n, np.zeros([1], dtype=np.int32))
 
 
+_SIZE_BLOCK = 4096   # polycube sizes are drawn in fixed blocks of global sample indices
+
+
+def dataset_sizes(seed, first, count, numCubeRange):
+    """Polycube sizes of the dataset samples first .. first + count - 1: sample i draws its size from a stream
+    keyed by (seed, i // 4096), at position i % 4096 - a function of the GLOBAL index only, so the dataset does
+    not depend on how it is cut into chunks or ranks (the native generator keys its per-truss stream by the
+    global index in the same way)."""
+    first, count = int(first), int(count)
+    out = np.empty([count], dtype=np.int64)
+    lo, hi = int(numCubeRange[0]), int(numCubeRange[1]) + 1
+    for blk in range(first // _SIZE_BLOCK, (first + count - 1) // _SIZE_BLOCK + 1 if count else 0):
+        block = np.random.default_rng([int(seed), blk]).integers(lo, hi, size=_SIZE_BLOCK)
+        a, b = max(first, blk * _SIZE_BLOCK), min(first + count, (blk + 1) * _SIZE_BLOCK)
+        out[a - first: b - first] = block[a - blk * _SIZE_BLOCK: b - blk * _SIZE_BLOCK]
+    return out
+
+
 def dataset_chunks(n_samples, rank=0, world=1, chunk=16384, seed=0, numCubeRange=(8, 190), gridRange=(6, 6, 6),
                    fixedMemberType=None, taskType=TaskType.OPTIMIZATION, forceScale=1., displaceScale=1.,
                    positionScale=1., device=None, reorder=True, prefetch=True, **generator_args):
     """BASELINE config 5 as a generator: this rank's share of a dataset of `n_samples` random cube trusses,
     chunk by chunk - native generation (`generate_cube_batch`), both solves and the feature kernel on
     `device` (`feature_tensors_device`).  Yields `(first_index, packed, tensors)`; nothing larger than one
-    chunk is ever held on the host.  The dataset is DEFINED by (seed, global sample index): any split into
-    ranks and chunks produces the same samples (rank r owns the chunks r, r + world, ...).  One process per
+    chunk is ever held on the host.  The dataset is DEFINED by (seed, global sample index) - polycube sizes
+    (`dataset_sizes`) and the generator's per-truss streams alike -: any split into ranks and chunks produces
+    the same samples (rank r owns the chunks r, r + world, ...).  One process per
     GPU, no communication: run it under `torchrun` with rank / world from the environment, or in a loop.
     The native host work of the next chunk (generation, joint order) overlaps the GPU work of the current one."""
     from concurrent.futures import ThreadPoolExecutor
@@ -390,7 +415,7 @@ def dataset_chunks(n_samples, rank=0, world=1, chunk=16384, seed=0, numCubeRange
     def host_side(k):   # native code (the GIL is released): generation and the joint order of chunk k
         first = k * chunk
         count = min(chunk, int(n_samples) - first)
-        sizes = np.random.default_rng([int(seed), k]).integers(numCubeRange[0], numCubeRange[1] + 1, size=chunk)[:count]
+        sizes = dataset_sizes(seed, first, count, numCubeRange)
         packed = generate_cube_batch(sizes, gridRange=gridRange, seed=seed, first_index=first, **generator_args)
         return first, packed, (joint_order(packed, reorder) if reorder is not False and reorder is not None else False)
 

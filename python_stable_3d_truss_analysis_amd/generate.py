@@ -46,6 +46,41 @@ def available_cpus():
     return max(1, n)
 
 
+_thread_share = None   # number of processes that share this host's CPUs with this one (set_host_thread_share)
+
+
+def host_thread_budget(sharers=None):
+    """Threads the native host helpers of THIS process may use: the CPUs the container really has
+    (`available_cpus`) divided by the number of processes that work side by side on this host - the ranks of a
+    `torchrun` launch (`LOCAL_WORLD_SIZE`) or the workers of a `shard.ShardedSolver`.  Eight ranks that each
+    start a team of every CPU oversubscribe the host eight times exactly where the ragged workloads are
+    host-bound (the joint order, the generator)."""
+    if sharers is None:
+        sharers = _thread_share
+    if sharers is None:
+        try:
+            sharers = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        except ValueError:
+            sharers = 1
+    return max(1, available_cpus() // max(1, int(sharers)))
+
+
+def set_host_thread_share(sharers):
+    """Declare that `sharers` processes share this host (a rank of an N-process job, a worker of a pool of
+    N): the OpenMP teams of the native helpers are sized to `host_thread_budget()` from now on
+    (`OMP_NUM_THREADS` in the environment still wins).  Returns the budget."""
+    global _thread_share
+    _thread_share = max(1, int(sharers))
+    if _gen is not None and "OMP_NUM_THREADS" not in os.environ:
+        _gen.trs_host_threads(host_thread_budget())
+    return host_thread_budget()
+
+
+def host_threads():
+    """Size of the OpenMP team the native helpers use right now."""
+    return int(_load().trs_host_threads(0))
+
+
 def _load():
     global _gen
     if _gen is None:
@@ -61,7 +96,7 @@ def _load():
         lib.trs_host_threads.restype = I
         lib.trs_host_threads.argtypes = [I]
         if "OMP_NUM_THREADS" not in os.environ:   # a team of every logical CPU is throttled under a CPU quota
-            lib.trs_host_threads(available_cpus())
+            lib.trs_host_threads(host_thread_budget())
         _gen = lib
     return _gen
 

@@ -60,22 +60,28 @@ def gather_results(local: BatchResult, idx, total, group=None):
     return out
 
 
-def solve_batch_distributed(packed: PackedBatch, device=None, gather=True, reorder=False, group=None,
-                            solver=None):
+def _solve_shard(shard, device, reorder, max_slab_bytes=64 << 30, sections=None):
+    """A shard through the HIP pipeline on `device` - the ONLY solver of this module (no CPU fallback: without
+    a GPU or the library `batch.solve_batch` raises)."""
+    from .batch import solve_batch
+    return solve_batch(shard, device=device, reorder=reorder, max_slab_bytes=max_slab_bytes, sections=sections)
+
+
+def solve_batch_distributed(packed: PackedBatch, device=None, gather=True, reorder=False, group=None):
     """SPMD entry point: call on every rank of an initialised `torch.distributed` group with the SAME
     `packed`.  Rank r solves its shard on `device` (default: `cuda:LOCAL_RANK % device_count`) with the
-    HIP pipeline (`batch.solve_batch`; `solver` replaces it in CPU tests of the plumbing) and returns
-    the full-batch result (gather=True, identical on every rank) or `(local_result, idx)`."""
+    HIP pipeline (`batch.solve_batch`) and returns the full-batch result (gather=True, identical on every
+    rank) or `(local_result, idx)`.  The native host helpers of this rank (joint order, generator) size
+    their thread teams by the rank's share of the host CPUs (`generate.set_host_thread_share`)."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     mine, idx = shard_batch(packed, rank, world)
-    if solver is None:
+    if device is None:
         import torch
-        from .batch import solve_batch
-        if device is None:
-            device = f"cuda:{int(os.environ.get('LOCAL_RANK', rank)) % max(1, torch.cuda.device_count())}"
-        solver = lambda shard: solve_batch(shard, device=device, reorder=reorder)
-    local = solver(mine) if mine.B else BatchResult(
+        device = f"cuda:{int(os.environ.get('LOCAL_RANK', rank)) % max(1, torch.cuda.device_count())}"
+    from .generate import set_host_thread_share
+    set_host_thread_share(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    local = _solve_shard(mine, device, reorder) if mine.B else BatchResult(
         np.zeros([0, packed.nJ_max, 3]), np.zeros([0, packed.nJ_max, 3]), np.zeros([0, packed.nM_max]),
         np.zeros([0], dtype=np.int32))
     if not gather:
@@ -99,47 +105,38 @@ def _attach(name, shape, dtype):
     return np.ndarray(shape, dtype=dtype, buffer=shm.buf), shm
 
 
-def _import_callable(path):
-    import importlib
-    mod, name = path.split(":")
-    return getattr(importlib.import_module(mod), name)
-
-
-def _worker_main(device, conn, test_solver):
-    """Worker loop: receives shard descriptors (shared-memory names), solves on `device`, writes the
-    rows of its shard into the shared result arrays.  No fallback: a missing GPU/library raises in
-    the worker and the error text travels back to the controller.  `test_solver` ("module:function",
-    CPU tests of this plumbing only) replaces the HIP pipeline by a stand-in."""
+def _worker_main(device, conn, n_workers=1):
+    """Entry point of a worker process: the HIP pipeline on `device` (no fallback: a missing GPU or library
+    raises here and the error text travels back to the controller), then the request loop."""
     try:
-        if test_solver is None:
-            from .batch import DeviceBatch, solve_batch
-            import torch
-            torch.cuda.set_device(torch.device(device))
-            # every solve of the shard's geometry in one call: one upload, one reordering
-            solver = lambda shard, opts: solve_batch(
-                shard, device=device, reorder=opts.get("reorder", False),
-                max_slab_bytes=opts.get("max_slab_bytes", 64 << 30),
-                sections=opts.get("sections") if opts.get("sections") is not None else [None])
-        else:
-            stand_in = _import_callable(test_solver)
-
-            def solver(shard, opts):
-                import dataclasses
-                out = []
-                for sec in (opts.get("sections") if opts.get("sections") is not None else [None]):
-                    ones = np.ones_like(shard.A)
-                    out.append(stand_in(shard if sec is None else dataclasses.replace(
-                        shard, A=ones * sec[0], E=ones * sec[1], rho=ones * sec[2])))
-                return out
-        conn.send(("ready", None))
+        import torch
+        torch.cuda.set_device(torch.device(device))
+        # every solve of the shard's geometry in one call: one upload, one reordering
+        solver = lambda shard, opts: _solve_shard(
+            shard, device, opts.get("reorder", False), opts.get("max_slab_bytes", 64 << 30),
+            opts.get("sections") if opts.get("sections") is not None else [None])
     except Exception:  # pragma: no cover - reported to the parent
         conn.send(("error", traceback.format_exc()))
         return
-    resident = {}  # geometry key -> DeviceBatch kept between calls (GA: only the sections change)
+    _worker_loop(device, conn, solver, n_workers)
+
+
+def _worker_loop(device, conn, solver, n_workers=1):
+    """Request loop of a worker: receives shard descriptors (shared-memory names), runs
+    `solver(shard, opts) -> [BatchResult per section variant]` and writes the rows of its shard into the
+    shared result arrays.  The worker's native host helpers (joint order, generator: OpenMP) get the
+    worker's share of the host CPUs, not all of them (`generate.set_host_thread_share`)."""
+    from .generate import host_threads, set_host_thread_share
+    set_host_thread_share(n_workers)
+    conn.send(("ready", None))
+    resident = None  # (geometry key, shapes, DeviceBatch) kept between calls (GA: only the sections change)
     while True:
         msg = conn.recv()
         if msg[0] == "stop":
             return
+        if msg[0] == "host_threads":
+            conn.send(("done", host_threads()))
+            continue
         _, inputs, outputs, idx_desc, opts = msg
         handles = []
         try:
@@ -155,15 +152,21 @@ def _worker_main(device, conn, test_solver):
                 outs[k], h = _attach(name, shape, dtype)
                 handles.append(h)
             if opts.get("fitness") is not None:
-                # GA generation (ga.py:139-160): the shard's geometry stays resident on this GPU
+                # GA generation (ga.py:139-160): the shard's geometry stays resident on this GPU - only for a
+                # caller who NAMES the geometry (geometry_key) and only while the padded shapes agree; without
+                # a key every call uploads the shard it was given
+                from .batch import DeviceBatch
                 key = opts.get("geometry_key")
-                dev = resident.get(key)
-                if dev is None or dev.B != shard.B:
-                    resident.clear()
-                    dev = resident[key] = DeviceBatch(shard, device)
-                    dev.packed = None  # the host arrays are views of shared memory that goes away
-                else:
+                shapes = (shard.B, shard.nJ_max, shard.nM_max)
+                if key is not None and resident is not None and resident[:2] == (key, shapes):
+                    dev = resident[2]
                     dev.set_sections(shard.A, shard.E, shard.rho)
+                else:
+                    resident = None
+                    dev = DeviceBatch(shard, device)
+                    dev.packed = None  # the host arrays are views of shared memory that goes away
+                    if key is not None:
+                        resident = (key, shapes, dev)
                 w, sv, dv = dev.solve_fitness(*opts["fitness"])
                 outs["fit"][idx, 0] = w.cpu().numpy()
                 outs["fit"][idx, 1] = sv.cpu().numpy()
@@ -199,7 +202,10 @@ class ShardedSolver:
     `devices=None` takes every visible GPU.  The same device may be listed twice (two workers share
     it): that is how the multi-process path is tested on a 1-GPU box."""
 
-    def __init__(self, devices=None, _test_solver=None):
+    #: entry point of the worker processes (module-level function, pickled by name for `spawn`)
+    _worker_target = staticmethod(_worker_main)
+
+    def __init__(self, devices=None):
         import multiprocessing as mp
         if devices is None:
             import torch
@@ -212,7 +218,7 @@ class ShardedSolver:
         self._workers = []
         for dev in self.devices:
             parent, child = ctx.Pipe()
-            proc = ctx.Process(target=_worker_main, args=(dev, child, _test_solver), daemon=True)
+            proc = ctx.Process(target=self._worker_target, args=(dev, child, len(self.devices)), daemon=True)
             proc.start()
             child.close()
             self._workers.append((proc, parent))
@@ -227,11 +233,21 @@ class ShardedSolver:
     def world_size(self):
         return len(self.devices)
 
+    def host_threads(self):
+        """OpenMP team size of the native host helpers in every worker (together at most the CPUs the
+        container has, or one each when there are fewer CPUs than workers)."""
+        out = []
+        for proc, conn in self._workers:
+            conn.send(("host_threads",))
+            out.append(int(conn.recv()[1]))
+        return out
+
     def fitness(self, packed: PackedBatch, allow_stress, allow_displace, geometry_key=None):
         """GA population evaluation (`ga.py:139-160`) sharded over the workers: one batched solve plus
         the `trs_fitness` reductions per shard.  Returns (fit [B,3] = weight, stress violation,
-        displacement violation; info [B]).  With the same `geometry_key` and batch size as the
-        previous call only the member sections cross to the GPUs."""
+        displacement violation; info [B]).  With a `geometry_key` (any hashable that names the geometry, e.g.
+        `id(truss)`) equal to the previous call's, and the same padded shapes, the geometry stays resident on
+        the workers' GPUs and only the member sections cross; without one every call uploads the batch."""
         fit, info = self._run(packed, {"fitness": (float(allow_stress), float(allow_displace)),
                                        "geometry_key": geometry_key}, 1, want_fit=True)
         return fit, info[0]

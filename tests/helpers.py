@@ -76,3 +76,37 @@ def oracle_batch_solver(packed):
 
 def failing_solver(packed):
     raise RuntimeError("stand-in failure")
+
+
+def _variants_solver(stand_in):
+    """`solver(shard, opts)` of `shard._worker_loop` from a one-batch stand-in: one result per section variant."""
+    def solver(shard, opts):
+        import dataclasses
+        out = []
+        for sec in (opts.get("sections") if opts.get("sections") is not None else [None]):
+            ones = np.ones_like(shard.A)
+            out.append(stand_in(shard if sec is None else dataclasses.replace(
+                shard, A=ones * sec[0], E=ones * sec[1], rho=ones * sec[2])))
+        return out
+    return solver
+
+
+def oracle_worker_main(device, conn, n_workers=1):
+    """Worker entry point for CPU tests of the sharding plumbing: the product's request loop
+    (`shard._worker_loop`) around the oracle instead of the HIP pipeline."""
+    from python_stable_3d_truss_analysis_amd import shard
+    shard._worker_loop(device, conn, _variants_solver(oracle_batch_solver), n_workers)
+
+
+def failing_worker_main(device, conn, n_workers=1):
+    from python_stable_3d_truss_analysis_amd import shard
+    shard._worker_loop(device, conn, _variants_solver(failing_solver), n_workers)
+
+
+def sharded_solver_class(worker_main):
+    """`shard.ShardedSolver` whose worker processes run `worker_main` (test seam, lives in the tests)."""
+    from python_stable_3d_truss_analysis_amd import shard
+
+    class _Pool(shard.ShardedSolver):
+        _worker_target = staticmethod(worker_main)
+    return _Pool

@@ -27,13 +27,13 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_host_side_helpers_of_the_abi():
     lib = _capi.load()
-    assert lib.trs_abi_version() == _capi.ABI_VERSION == 6
+    assert lib.trs_abi_version() == _capi.ABI_VERSION == 7
     assert lib.trs_assemble_work_bytes(244, 942, 696) % 256 == 0
     assert lib.trs_slab_rows(696) == 704 and lib.trs_slab_ld(696) == 720
     assert lib.trs_slab_rows(64) == 64 and lib.trs_slab_rows(65) == 128 and lib.trs_slab_rows(0) == 64
     # argument validation happens before any launch: bad leading dimension is refused
     assert lib.trs_potrf_batched(1, None, 100, 64, None, None, None, None, None, 64, 0, None) != 0
-    assert lib.trs_get_option(b"fused_substitution") == 1 and lib.trs_get_option(b"no_such_option") == -1
+    assert not hasattr(lib, "trs_set_option")        # ABI 7: no process-wide switches, flags per call
     assert lib.trs_env_ints(696) == 2 * (704 // 16) + 704 // 64 + 8
 
 

@@ -198,6 +198,17 @@ def test_bar25_through_the_device_feature_path_matches_the_reference_capture(gol
         assert float(t["weight"][0]) == pytest.approx(float(z[f"{tag}_noimp/originWeight"]), rel=1e-12)
 
 
+def test_dataset_sizes_depend_on_the_global_index_only():
+    whole = data.dataset_sizes(3, 0, 10000, (8, 190))
+    assert whole.min() >= 8 and whole.max() <= 190 and len(np.unique(whole)) > 150
+    for chunk in (1, 100, 4096, 5000):
+        parts = [data.dataset_sizes(3, a, min(chunk, 10000 - a), (8, 190)) for a in range(0, 10000, chunk)][:200]
+        np.testing.assert_array_equal(np.concatenate(parts), whole[:len(np.concatenate(parts))])
+    np.testing.assert_array_equal(data.dataset_sizes(3, 4090, 12, (8, 190)), whole[4090:4102])   # across a block
+    assert not np.array_equal(data.dataset_sizes(4, 0, 100, (8, 190)), whole[:100])
+    assert len(data.dataset_sizes(3, 7, 0, (8, 190))) == 0
+
+
 @pytest.mark.gpu
 def test_dataset_chunks_sharding_is_invariant():
     """`data.dataset_chunks` (config 5 as a per-rank generator): the samples of two ranks interleaved are
@@ -219,8 +230,9 @@ def test_dataset_chunks_sharding_is_invariant():
         assert not t0["info"].any()
         for key in ("joint_x", "member_x", "joint_y", "member_y"):
             assert torch.equal(t0[key], t1[key])
-    # other chunk size: same samples (compare the first 128 of the dataset)
-    first, p, t = next(iter(data.dataset_chunks(700, chunk=128, **kw)))
-    np.testing.assert_array_equal(p.nM, single[0][0].nM[:128])
-    nJ = int(p.nJ.max())
-    np.testing.assert_array_equal(p.xyz[:, :nJ], single[0][0].xyz[:128, :nJ])
+    # other chunk size: same samples, in every chunk (the sizes are keyed by the global index, not the chunk)
+    for first, p, t in data.dataset_chunks(700, chunk=128, **kw):
+        base, off = single[first // 256 * 256][0], first % 256
+        np.testing.assert_array_equal(p.nM, base.nM[off: off + p.B])
+        nJ = int(p.nJ.max())
+        np.testing.assert_array_equal(p.xyz[:, :nJ], base.xyz[off: off + p.B, :nJ])

@@ -28,8 +28,8 @@ def gpu():
     return batch
 
 
-def _device_batch(gpu, datas):
-    return gpu.DeviceBatch(gpu.pack_json(datas))
+def _device_batch(gpu, datas, **kw):
+    return gpu.DeviceBatch(gpu.pack_json(datas), **kw)
 
 
 def _upper_from_slab(S, npad):
@@ -38,23 +38,13 @@ def _upper_from_slab(S, npad):
     return U, S[:npad, npad].copy()
 
 
-@pytest.fixture
-def compact_mode(request):
-    """Run a test with trs_set_option("compact", value) and restore the default afterwards."""
-    from python_stable_3d_truss_analysis_amd import _capi
-    lib = _capi.load()
-    assert lib.trs_set_option(b"compact", int(request.param)) == 0
-    yield bool(request.param)
-    lib.trs_set_option(b"compact", 0)
-
-
-@pytest.mark.parametrize("compact_mode", [0, 1], indirect=True, ids=["slab", "compact"])
+@pytest.mark.parametrize("compact_mode", [False, True], ids=["slab", "compact"])
 @pytest.mark.parametrize("name", ["bar-6_input_0", "bar-25_input_0", "bar-47_input_0", "bar-120_input_0",
                                   "bar-942_input_0"])
 def test_stages_against_oracle(gpu, name, compact_mode):
     data = H.load_json(name)
     ref = orc.solve(data)
-    dev = _device_batch(gpu, [data])
+    dev = _device_batch(gpu, [data], options={"compact": compact_mode})   # per-batch switch -> per-call flags
     n = int(dev.packed.n_free[0])
     npad = (n + 63) // 64 * 64
 
@@ -172,11 +162,11 @@ def test_stages_against_oracle(gpu, name, compact_mode):
 
     # --- potrf: U^T U = K_ff, y = L^-1 f ------------------------------------------------------
     # (the stages apart: by default the wave that factors a narrow-envelope matrix substitutes it as well)
-    assert dev.lib.trs_set_option(b"fused_substitution", 0) == 0
+    dev.options["fused_substitution"] = False
     try:
         dev.potrf()
     finally:
-        dev.lib.trs_set_option(b"fused_substitution", 1)
+        dev.options["fused_substitution"] = True
     assert int(dev.info.cpu()[0]) == 0
     S = dev.S.cpu().numpy()[0]
     U, _ = _upper_from_slab(S, npad)
@@ -248,12 +238,10 @@ def test_all_data_cases_one_ragged_batch_vs_reference_goldens(gpu):
             assert not res.displace[b, :, 2].any() and not res.internal[b, nM:].any()
 
 
-@pytest.mark.parametrize("compact_mode", [1], indirect=True, ids=["compact"])
-def test_fused_factorisation_end_to_end(gpu, compact_mode):
+def test_fused_factorisation_end_to_end(gpu):
     """The opt-in compact form (K_ff as per-tile entry lists, tiles formed inside the factorisation): every
     bundled case and the ragged cube fixtures against the golden vectors, and bit for bit against the slab
     form - the tiles it forms are the tiles the slab form stores."""
-    from python_stable_3d_truss_analysis_amd import _capi
     names = H.data_case_names()
     datas = [H.load_json(nm) for nm in names] + [d for _, d, _ in H.ragged_cube_cases()]
     packed = gpu.pack_json(datas)
@@ -262,9 +250,7 @@ def test_fused_factorisation_end_to_end(gpu, compact_mode):
             [g for _, _, g in H.ragged_cube_cases()]
     res = {}
     for reorder in (False, True):
-        _capi.load().trs_set_option(b"compact", 1)
-        fused = gpu.solve_batch(packed, reorder=reorder)
-        _capi.load().trs_set_option(b"compact", 0)
+        fused = gpu.solve_batch(packed, reorder=reorder, options={"compact": True})
         slab = gpu.solve_batch(packed, reorder=reorder)
         assert not fused.info.any()
         for b, (data, gold) in enumerate(zip(datas, golds)):
@@ -278,13 +264,11 @@ def test_fused_factorisation_end_to_end(gpu, compact_mode):
     # at BASELINE's batch: bar-942 x 4096, every copy identical to the slab form's
     data = H.load_json("bar-942_input_0")
     big = gpu.pack_json([data]).replicate(4096)
-    _capi.load().trs_set_option(b"compact", 1)
-    dev = gpu.DeviceBatch(big)
+    dev = gpu.DeviceBatch(big, options={"compact": True})
     dev.solve()
     a = dev.result()
     slack = int(dev.env.cpu().numpy()[0][dev.rows // 16 + dev.rows // 64])
     assert slack & 0x100 and (slack & 0xff) == 1
-    _capi.load().trs_set_option(b"compact", 0)
     dev2 = gpu.DeviceBatch(big.take(np.arange(8)))
     dev2.solve()
     b8 = dev2.result()
@@ -465,13 +449,14 @@ def test_recover_without_lds_staging_matches(gpu):
     dev = _device_batch(gpu, [data, data, data])
     dev.solve()
     ref = dev.result()
-    assert dev.lib.trs_set_option(b"recover_unstaged", 1) == 0
-    try:
-        dev.recover()
-        got = dev.result()
-    finally:
-        dev.lib.trs_set_option(b"recover_unstaged", 0)
-    assert dev.lib.trs_set_option(b"no_such_option", 1) != 0
+    dev.options["recover_unstaged"] = True
+    dev.recover()
+    got = dev.result()
+    dev.u.fill_(float("nan")); dev.f_ext.fill_(float("nan"))
+    dev.solve()                       # the hint travels through trs_solve as well
+    again = dev.result()
+    np.testing.assert_array_equal(again.displace, ref.displace)
+    np.testing.assert_array_equal(again.internal, ref.internal)
     np.testing.assert_array_equal(got.displace, ref.displace)
     np.testing.assert_array_equal(got.internal, ref.internal)
     assert np.abs(got.external - ref.external).max() <= 1e-12 * np.abs(ref.external).max()
@@ -500,12 +485,12 @@ def test_resident_batch_with_a_joint_order_delivers_results_in_the_given_numberi
             if how == "one call":
                 dev.solve()
             else:
-                dev.lib.trs_set_option(b"recover_unstaged", int(how == "unstaged recover"))
+                dev.options["recover_unstaged"] = how == "unstaged recover"
                 try:
                     dev.dofmap(); dev.assemble(); dev.potrf(); dev.potrs(); dev.recover()
                     dev.torch.cuda.synchronize()
                 finally:
-                    dev.lib.trs_set_option(b"recover_unstaged", 0)
+                    dev.options["recover_unstaged"] = False
             got = dev.result()
             assert not got.info.any()
             for b, (data, gold) in enumerate(zip(datas, golds)):
@@ -573,13 +558,40 @@ def test_launch_hints_and_forced_narrow_routing(gpu):
     assert gpu.envelope_reach(cubes)[b] > gpu.NARROW_MAX_BELOW
     data = gen.packed_to_json(cubes, b)
     want = orc.solve(data)
-    dev = gpu.DeviceBatch(cubes.take(np.array([b])))
-    dev.all_narrow = True
-    dev.solve()
-    got = dev.result()
     nJ, nM = len(data["joint"]), len(data["member"])
-    assert H.max_scaled_err(got.displace[0, :nJ], want["u"]) <= 1e-8
-    assert H.max_scaled_err(got.internal[0, :nM], want["N"]) <= 1e-8
+    # ... also with the compact form asked for: a matrix only FORCED narrow may hold more tiles per chunk than
+    # the entry lists are sized for, so it keeps the slab (round 2 overran the list tables there); the
+    # narrow-by-reach neighbour in the same batch does leave as lists
+    for options in (None, {"compact": True}):
+        dev = gpu.DeviceBatch(cubes.take(np.array([b, int(np.argmin(gpu.envelope_reach(cubes)))])), options=options)
+        dev.all_narrow = True
+        dev.solve()
+        got = dev.result()
+        assert not got.info.any()
+        assert H.max_scaled_err(got.displace[0, :nJ], want["u"]) <= 1e-8
+        assert H.max_scaled_err(got.internal[0, :nM], want["N"]) <= 1e-8
+        route = dev.env.cpu().numpy()[:, dev.rows // 16 + dev.rows // 64]
+        assert (route & 0xff == 1).all() and not route[0] & 0x100
+        assert bool(route[1] & 0x100) == (options is not None and
+                                          gpu.envelope_reach(cubes).min() <= gpu.NARROW_MAX_BELOW)
+
+
+def test_streamed_solver_drops_the_templates_launch_hints(gpu):
+    """`StreamedSolver` builds its resident slots from a template; batches submitted later may have other
+    envelopes, so the template's `all_narrow` must not stay (round 2: it did, and wide envelopes ran
+    forced-narrow).  `same_topology=True` keeps it for streams that only vary coordinates / sections / loads."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    narrow = gpu.pack_json([H.load_json("bar-942_input_0")]).replicate(4)
+    assert gpu.DeviceBatch(narrow).all_narrow
+    pipe = gpu.StreamedSolver(narrow)
+    assert not any(d.all_narrow for d in pipe.dev)
+    keep = gpu.StreamedSolver(narrow, same_topology=True)
+    assert all(d.all_narrow for d in keep.dev)
+    for p in (pipe, keep):
+        p.submit(p.stage(narrow))
+        res = p.drain()[0]
+        ref = gpu.solve_batch(narrow)
+        np.testing.assert_array_equal(res.displace, ref.displace)
 
 
 def test_empty_batch_and_fully_constrained_truss(gpu):

@@ -123,3 +123,33 @@ def test_ga_population_sharded_over_two_workers():
     finally:
         two.close()
     assert a == b and b2 == a[::-1]
+
+
+def test_fitness_without_a_geometry_key_never_reuses_a_resident_batch():
+    """Two geometries of the SAME padded shapes through `ShardedSolver.fitness` back to back: without a
+    `geometry_key` every call uploads its own batch (round 2 reused the first one's geometry and returned the
+    fitness of the wrong trusses); with a key the geometry stays and only the sections change."""
+    import dataclasses
+    from python_stable_3d_truss_analysis_amd import batch, shard
+    base = batch.pack_json([H.load_json("bar-120_input_0")]).replicate(8)
+    stretched = dataclasses.replace(base, xyz=base.xyz * 1.5)
+
+    def single(packed):
+        dev = batch.DeviceBatch(packed, "cuda:0")
+        w, sv, dv = dev.solve_fitness(30000., 10.)
+        return np.stack([w.cpu().numpy(), sv.cpu().numpy(), dv.cpu().numpy()], axis=1)
+
+    want_a, want_b = single(base), single(stretched)
+    assert not np.array_equal(want_a, want_b)
+    with shard.ShardedSolver(_devices()) as pool:
+        got_a, _ = pool.fitness(base, 30000., 10.)
+        got_b, _ = pool.fitness(stretched, 30000., 10.)
+        keyed_a, _ = pool.fitness(base, 30000., 10., geometry_key="a")
+        thicker = dataclasses.replace(base, A=base.A * 2.0)
+        keyed_a2, _ = pool.fitness(thicker, 30000., 10., geometry_key="a")   # sections only
+        keyed_b, _ = pool.fitness(stretched, 30000., 10., geometry_key="b")  # another key: re-uploaded
+    np.testing.assert_array_equal(got_a, want_a)
+    np.testing.assert_array_equal(got_b, want_b)
+    np.testing.assert_array_equal(keyed_a, want_a)
+    np.testing.assert_array_equal(keyed_a2, single(thicker))
+    np.testing.assert_array_equal(keyed_b, want_b)

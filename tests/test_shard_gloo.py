@@ -28,7 +28,9 @@ def _worker(rank, world, port, names, out_dir):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     packed = batch.pack_json([H.load_json(n) for n in names])
-    full = shard.solve_batch_distributed(packed, solver=H.oracle_batch_solver)
+    # the stand-in for the HIP pipeline is patched in HERE, in the test process of this rank
+    shard._solve_shard = lambda mine, device, reorder, *a, **k: H.oracle_batch_solver(mine)
+    full = shard.solve_batch_distributed(packed, device="cpu")
     dist.barrier()
     np.savez(os.path.join(out_dir, f"full{rank}.npz"), u=full.displace, f=full.external, n=full.internal,
              info=full.info)
@@ -60,7 +62,7 @@ def test_sharded_solver_pool_two_workers():
     from python_stable_3d_truss_analysis_amd import batch, shard
     names = [n for n in H.data_case_names() if "942" not in n]
     packed = batch.pack_json([H.load_json(n) for n in names])
-    with shard.ShardedSolver(["cpu", "cpu"], _test_solver="tests.helpers:oracle_batch_solver") as pool:
+    with H.sharded_solver_class(H.oracle_worker_main)(["cpu", "cpu"]) as pool:
         assert pool.world_size == 2
         one = pool.solve(packed)
         two = pool.solve(packed, sections=[None, (1.0, 1e7, 0.1)])
@@ -82,6 +84,31 @@ def test_sharded_solver_reports_worker_errors():
     from python_stable_3d_truss_analysis_amd import batch, shard
     from python_stable_3d_truss_analysis_amd.utils import HipExtensionError
     packed = batch.pack_json([H.load_json("bar-6_input_0")])
-    with shard.ShardedSolver(["cpu"], _test_solver="tests.helpers:failing_solver") as pool:
+    with H.sharded_solver_class(H.failing_worker_main)(["cpu"]) as pool:
         with pytest.raises(HipExtensionError, match="stand-in failure"):
             pool.solve(packed)
+
+
+def test_eight_workers_share_the_host_cpus():
+    """Eight workers (one per GPU of a node) together never start more OpenMP threads than the container has
+    CPUs (one each when it has fewer than eight): `generate.host_thread_budget`."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    cpus = gen.available_cpus()
+    assert gen.host_thread_budget(1) == cpus and gen.host_thread_budget(8) == max(1, cpus // 8)
+    assert gen.host_thread_budget(10 ** 6) == 1
+    if "OMP_NUM_THREADS" in os.environ:
+        return
+    with H.sharded_solver_class(H.oracle_worker_main)(["cpu"] * 8) as pool:
+        teams = pool.host_threads()
+    assert len(teams) == 8 and all(t == max(1, cpus // 8) for t in teams), teams
+    assert sum(teams) <= max(cpus, 8)
+
+
+def test_rank_of_a_launch_takes_its_share(monkeypatch):
+    """Under `torchrun` (LOCAL_WORLD_SIZE ranks on this host) a rank's default budget is its share."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    monkeypatch.setattr(gen, "_thread_share", None)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert gen.host_thread_budget() == max(1, gen.available_cpus() // 4)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert gen.host_thread_budget() == gen.available_cpus()

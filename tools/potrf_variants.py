@@ -37,40 +37,36 @@ def main():
     ap.add_argument("--case", default="bar-942_input_0")
     ap.add_argument("--dense", action="store_true", help="no envelope tile skipping")
     ap.add_argument("--fused", action="append", default=[],
-                    help="tags (repeatable) that run with trs_set_option('compact', 1): compact entry lists + fused factorisation")
+                    help="tags (repeatable) that run with the option compact=1: compact entry lists + fused factorisation")
     ap.add_argument("--option", action="append", default=[],
-                    help="tag:name=value[/restore] (repeatable): trs_set_option(name, value) while that tag runs, restore (0) otherwise")
+                    help="tag:name=value (repeatable): DeviceBatch.options[name] = value while that tag runs "
+                         "(batch.DEFAULT_OPTIONS otherwise); the options travel as per-call flags")
     args = ap.parse_args()
     with open(os.path.join(ROOT, "tests", "golden", "data", args.case + ".json")) as fh:
         data = json.load(fh)
     dev = batch.DeviceBatch(batch.pack_json([data]).replicate(args.batch), use_envelope=not args.dense)
     libs = {t: load_variant(t.split("@")[0]) for t in args.tags}   # 'tag@x' = a second instance of a build
-    for t in args.fused:
-        libs[t].trs_set_option(b"compact", 1)
     stages = ("dofmap", "assemble", "potrf", "potrs", "recover")
     times = {t: {s: [] for s in stages} for t in args.tags}
     ref_u = None
     narrow_known = dev.all_narrow
-    options = {}
+    options = {t: {"compact": True} for t in args.fused}
     for spec in args.option:
         tag, kv = spec.split(":")
         name, value = kv.split("=")
-        value, _, reset = value.partition("/")          # name=value[/value to restore afterwards, default 0]
-        options.setdefault(tag, []).append((name.encode(), int(value), int(reset or 0)))
+        options.setdefault(tag, {})[name] = bool(int(value.partition("/")[0]))
+    base_options = dict(dev.options)
     for rnd in range(args.rounds + 1):
         for tag in args.tags:
             dev.lib = libs[tag]
             dev.all_narrow = narrow_known and not tag.endswith("nohint")   # 'tag@nohint': every kernel is launched
-            for name, value, _ in options.get(tag, []):
-                assert libs[tag].trs_set_option(name, value) == 0, name
+            dev.options = dict(base_options, **options.get(tag, {}))
             evs = []
             for s in stages:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); getattr(dev, s)(); e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
-            for name, _, reset in options.get(tag, []):
-                libs[tag].trs_set_option(name, reset)
             if rnd == 0:   # warm-up round + correctness
                 u = dev.u[0].cpu().numpy()
                 info = int(dev.info.abs().sum().item())

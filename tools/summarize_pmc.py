@@ -39,8 +39,14 @@ def main(src, dst):
         if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             rec["hbm_bytes_per_launch"] = 2.0 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024
             rec["hbm_bytes_note"] = "2*FETCH_SIZE KiB (gfx950 half-count correction) + WRITE_SIZE KiB"
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in pmc and "SQ_BUSY_CYCLES" in pmc and pmc["SQ_BUSY_CYCLES"]:
-            rec["mfma_busy_over_sq_busy"] = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / pmc["SQ_BUSY_CYCLES"]
+        # matrix-core busy FRACTION: SQ_VALU_MFMA_BUSY_CYCLES is in shader cycles summed over the chip's 1024
+        # SIMDs (256 CUs x 4; guide: "counts cycles"), GRBM_GUI_ACTIVE (another pass, same launches) is the
+        # kernel's duration in cycles summed over the 8 XCDs -> busy / (1024 * GUI_ACTIVE / 8) lies in [0, 1]
+        if pmc.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and pmc.get("GRBM_GUI_ACTIVE"):
+            rec["mfma_busy_frac_per_simd"] = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * pmc["GRBM_GUI_ACTIVE"] / 8.0)
+            rec["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)"
+        if pmc.get("SQ_WAIT_ANY") is not None and pmc.get("SQ_WAVE_CYCLES"):
+            rec["wait_any_over_wave_cycles"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     with open(dst, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
