@@ -216,6 +216,34 @@ int trs_graph_features_dev(int B, int nJ_max, int nM_max, const double *xyz, con
                            double displaceScale, double positionScale, int regression, float *joint_x,
                            float *member_x, float *joint_y, float *member_y, double *weight, void *stream);
 
+/* Joint order on the device (no reference counterpart: slientruss3d numbers joints in insertion order,
+ * truss.py:175; the workload is its GenerateRandomCubeTrusses loop, generate.py:342-374, whose trusses are far
+ * from banded in generator order).  The cost of a solve is set by the row envelope of K_ff, i.e. by the joint
+ * numbering, so the numbering is the solver's to choose: per truss the cheapest of reverse Cuthill-McKee, its
+ * reverse and twelve binned coordinate sweeps, priced by the 16 x 16-tile envelope the factorisation works in
+ * (cost = sum over row chunks of w (w + 12), w = tiles from the first coupled tile to the diagonal) - the same
+ * candidates, cost and tie-breaks as trs_profile_order of trs_host.h, whose permutation it reproduces, with
+ * no host pass.  One work-group per truss, everything in LDS (csrc/order.hip).
+ *   perm  [B][nJ_max]   out: old id of the joint that becomes joint k (identity on the padding); this is also the
+ *                       joint_out of trs_recover / trs_solve that delivers results in the ORIGINAL numbering
+ *   choice [B] or NULL  out: winning candidate (0 RCM, 1 its reverse, 2 + 2 p + r: sweep with axis order p,
+ *                       r = 1 backwards)
+ *   reach  [B] or NULL  out: how many 16-row chunks the envelope of the CHOSEN order reaches below its 64 x 64
+ *                       diagonal blocks - a batch that stays <= 24 everywhere may be solved with
+ *                       TRS_ASM_ALL_NARROW / TRS_HINT_NO_WIDE
+ *   xyz_out, conn_out, cbits_out, loads_out (all four or all NULL; not the input arrays): the renumbered trusses,
+ *                       joint k := old joint perm[k]; members keep their order (N needs no mapping), their end
+ *                       joints are renumbered, padding members stay (0, 0)
+ *   effort              0: RCM and its reverse, 1: + the sweep along the longest extent, 2: all sweeps
+ * trs_joint_order_fits says whether a batch shape can be ordered on the device (tables within a CU's LDS,
+ * nJ_max < 8192); trs_joint_order returns hipErrorInvalidValue for a shape that cannot (callers then use the host
+ * version). */
+int trs_joint_order_fits(int nJ_max, int nM_max);
+int trs_joint_order(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn, const uint8_t *cbits,
+                    const double *loads /* may be NULL when loads_out is */, const int32_t *nJ, const int32_t *nM,
+                    int32_t *perm, int32_t *choice, int32_t *reach, double *xyz_out, int32_t *conn_out,
+                    uint8_t *cbits_out, double *loads_out, int effort, void *stream);
+
 /* The whole Truss.Solve() pipeline (truss.py:329-364) on one stream: trs_solve_small when the batch
  * shape qualifies (the slab, uf, work and env arguments are then not touched), otherwise
  * dofmap -> assemble -> potrf -> potrs -> recover.  Workspace pointers as above; joint_out as in

@@ -33,6 +33,8 @@ SIGNATURES = {
                              _D, _D, _P, _P, _P, _P]),
     "trs_graph_features_dev": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D,
                                     _I, _P, _P, _P, _P, _P, _P]),
+    "trs_joint_order_fits": (_I, [_I, _I]),
+    "trs_joint_order": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "trs_solve": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
                        _P, _P, _P, _P, _P, _P, _P, _I, _P]),
 }

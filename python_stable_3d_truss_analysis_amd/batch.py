@@ -268,6 +268,59 @@ def default_options():
     return opts
 
 
+def order_plan(reorder, nJ_max, nM_max):
+    """How a `reorder=` argument is carried out: None (no renumbering), ("given", perm array), ("device", effort)
+    - `trs_joint_order` on the GPU, no host pass - or ("host", name) - `joint_order` on the host.
+
+    True / "profile" = every candidate, "fast" = RCM, its reverse and one sweep: on the device whenever the
+    batch shape fits its kernel (`trs_joint_order_fits`), else on the host.  "rcm" = plain reverse Cuthill-McKee
+    (host).  "host-profile" / "host-fast" force the host versions (comparisons, tests); "device" insists on the
+    device version and raises when the shape does not fit."""
+    if reorder is False or reorder is None:
+        return None
+    if isinstance(reorder, np.ndarray):
+        return ("given", reorder)
+    if reorder in ("host-profile", "host-fast", "rcm"):
+        return ("host", {"host-profile": "profile", "host-fast": "fast"}.get(reorder, reorder))
+    if reorder is True or reorder in ("profile", "fast", "device"):
+        fits = bool(_capi.load().trs_joint_order_fits(int(nJ_max), int(nM_max)))
+        if fits:
+            return ("device", 1 if reorder == "fast" else 2)
+        if reorder == "device":
+            raise ValueError(f"joint order on the device: batch shape ({nJ_max} joints, {nM_max} members) does not "
+                             "fit trs_joint_order (see trs_joint_order_fits)")
+        return ("host", "fast" if reorder == "fast" else "profile")
+    raise ValueError(f"unknown joint order {reorder!r} (True, 'profile', 'fast', 'rcm', 'device', 'host-profile', "
+                     "'host-fast' or a permutation array)")
+
+
+def joint_order_device(torch, tensors, effort=2, apply=True, want_choice=False):
+    """`trs_joint_order` on resident inputs (`tensors`: xyz, conn, cbits, loads, nJ, nM on one device, padded
+    shapes of `PackedBatch`): the cheapest joint order of every truss found ON THE GPU, asynchronously on the
+    current stream.  Returns a dict: `perm` int32 [B, nJ_max] (old id of the joint that becomes joint k = the
+    `joint_out` of the recovery), `reach` int32 [B] (envelope reach of the chosen order, the launch hint),
+    `choice` (if asked) and, with `apply`, the renumbered `xyz`, `conn`, `cbits`, `loads`."""
+    lib = _capi.load()
+    xyz, conn, cbits, loads = (tensors[k].contiguous() for k in ("xyz", "conn", "cbits", "loads"))
+    dev = xyz.device
+    B, nJ_max, nM_max = int(xyz.shape[0]), int(xyz.shape[1]), int(conn.shape[1])
+    out = {"perm": torch.empty([B, nJ_max], dtype=torch.int32, device=dev),
+           "reach": torch.empty([B], dtype=torch.int32, device=dev)}
+    if want_choice:
+        out["choice"] = torch.empty([B], dtype=torch.int32, device=dev)
+    if apply:
+        out.update(xyz=torch.empty_like(xyz), conn=torch.empty_like(conn), cbits=torch.empty_like(cbits),
+                   loads=torch.empty_like(loads))
+    ptr = lambda k: out[k].data_ptr() if k in out else None
+    with torch.cuda.device(dev):
+        _capi.check(lib.trs_joint_order(
+            B, nJ_max, nM_max, xyz.data_ptr(), conn.data_ptr(), cbits.data_ptr(), loads.data_ptr(),
+            tensors["nJ"].data_ptr(), tensors["nM"].data_ptr(), out["perm"].data_ptr(), ptr("choice"),
+            out["reach"].data_ptr(), ptr("xyz"), ptr("conn"), ptr("cbits"), ptr("loads"), int(effort),
+            torch.cuda.current_stream(dev).cuda_stream), "trs_joint_order")
+    return out
+
+
 class DeviceBatch:
     """A packed batch resident in HBM plus the workspace of the pipeline.
 
@@ -286,19 +339,32 @@ class DeviceBatch:
         torch, dev = _require_gpu(device)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.packed = packed
-        perm, resident = None, packed
-        wants = reorder is not False and reorder is not None
-        if wants and not (use_small and _capi.load().trs_solve_small_fits(packed.nJ_max, packed.nM_max, packed.n_max)):
-            perm = joint_order(packed, "profile" if reorder is True else reorder)   # found once: every candidate
+        plan = order_plan(reorder, packed.nJ_max, packed.nM_max)
+        if plan is not None and use_small and _capi.load().trs_solve_small_fits(packed.nJ_max, packed.nM_max, packed.n_max):
+            plan = None   # the fused small-system kernel keeps its matrix in LDS: nothing to gain from an order
+        perm, resident, ordered = None, packed, None
+        if plan is not None and plan[0] != "device":
+            perm = joint_order(packed, plan[1])   # found once, on the host
             resident = permute_joints(packed, perm)
-        self._setup(torch, dev, {f: up(getattr(resident, f)) for f in self.INPUT_FIELDS},
-                    packed.B, packed.nJ_max, packed.nM_max, packed.n_max, use_envelope, use_small)
+        tensors = {f: up(getattr(resident, f)) for f in self.INPUT_FIELDS}
+        if plan is not None and plan[0] == "device" and packed.B:
+            # found, applied and priced on the GPU (trs_joint_order): no host pass over the batch
+            ordered = joint_order_device(torch, tensors, effort=plan[1])
+            tensors.update({k: ordered[k] for k in ("xyz", "conn", "cbits", "loads")})
+        self._setup(torch, dev, tensors, packed.B, packed.nJ_max, packed.nM_max, packed.n_max, use_envelope, use_small)
         self.options.update(options or {})
         if perm is not None:
             self.joint_out = up(perm)
-        # what the host can tell the launches about this batch (see `all_narrow`)
+        # what the launches may be told about this batch (see `all_narrow`): the reach of its envelopes - from
+        # the device order's own pricing, else from the host's envelope analysis
         if use_envelope and not self.small and packed.B:
-            self.all_narrow = bool(envelope_reach(resident).max() <= NARROW_MAX_BELOW)
+            if ordered is not None:
+                self.joint_out = ordered["perm"]
+                self.all_narrow = bool(int(ordered["reach"].max().item()) <= NARROW_MAX_BELOW)
+            else:
+                self.all_narrow = bool(envelope_reach(resident).max() <= NARROW_MAX_BELOW)
+        elif ordered is not None:
+            self.joint_out = ordered["perm"]
 
     @classmethod
     def from_device(cls, tensors, n_max, use_envelope=True, use_small=True, joint_out=None, all_narrow=False):
@@ -712,6 +778,44 @@ def permute_joints(packed: PackedBatch, perm):
                        packed.dim, packed.n_free)
 
 
+def global_stiffness(trusses_or_packed, device=None):
+    """The FULL global stiffness matrix of every truss, `Truss.GetKMatrix()` of the reference
+    (`truss.py:307-316`: zero-initialised nDOF x nDOF, four dim x dim blocks added per member, DOF = joint * dim
+    + axis, parallel members accumulate), assembled on the GPU by the same kernel as the solve: `trs_dofmap`
+    on a batch with NO constraint frees every DOF (reduced index = DOF index) and `trs_assemble` with
+    TRS_ASM_FULL_SYMMETRIC and no envelope writes the whole symmetric matrix.  Returns a list of B dense
+    `np.ndarray`s of shape `[nJoint * dim, nJoint * dim]` (a 2D truss drops the embedded z axis)."""
+    if not isinstance(trusses_or_packed, PackedBatch) and len(trusses_or_packed) == 0:
+        return []
+    packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
+        else pack_trusses(list(trusses_or_packed))
+    if packed.B == 0:
+        return []
+    torch, dev = _require_gpu(device)
+    import dataclasses
+    free = dataclasses.replace(packed, cbits=np.zeros_like(packed.cbits), n_free=(3 * packed.nJ).astype(np.int32))
+    out = []
+    # one slab per truss is nDOF^2 doubles: a few trusses at a time keep the workspace below ~1 GiB
+    per = max(1, int((1 << 30) // max(1, (3 * packed.nJ_max + 80) ** 2 * 8)))
+    with torch.cuda.device(dev):
+        for lo in range(0, packed.B, per):
+            part = free.take(np.arange(lo, min(packed.B, lo + per)))
+            db = DeviceBatch(part, dev, use_envelope=False, use_small=False)
+            db.dofmap()
+            db.assemble(flags=ASM_FULL_SYMMETRIC)
+            torch.cuda.synchronize(dev)
+            S = db.S.cpu().numpy()
+            for b in range(part.B):
+                nJ, dim = int(part.nJ[b]), int(part.dim[b])
+                K = S[b, :3 * nJ, :3 * nJ]
+                if dim == 2:
+                    keep = (np.arange(3 * nJ) % 3) < 2
+                    K = K[keep][:, keep]
+                out.append(np.ascontiguousarray(K))
+            del db
+    return out
+
+
 SMALL_N = 128  # largest reduced system of the fused small-system kernel (csrc/small.hip)
 
 
@@ -853,9 +957,10 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     (`size_buckets`) and every bucket is gathered, solved and scattered back ON THE DEVICE
     (`index_select` / `index_copy_`), inputs trimmed to the bucket's own maxima; the dense results come
     down once.  `reorder=True` renumbers the joints of every truss first, by the cheapest of reverse
-    Cuthill-McKee and coordinate sweeps (`joint_order`: True / "fast", "profile", "rcm"; the order is found
-    on the host, natively; inputs are permuted and results mapped back on the device): worth it when the
-    trusses are not numbered along their long axis, e.g. generated cube trusses.
+    Cuthill-McKee and coordinate sweeps (`order_plan`: True / "profile", "fast", "rcm", ...): found, applied
+    and undone (`trs_recover`'s `joint_out`) ON THE DEVICE by `trs_joint_order` whenever the batch shape fits
+    that kernel, otherwise found on the host (natively, while the inputs go up).  Worth it when the trusses
+    are not numbered along their long axis, e.g. generated cube trusses.
 
     `sections=[None, (a, e, density), ...]` solves the same trusses several times - `None` with their
     own member sections, a triple with every member set to it (the "fixed member type" prior of the
@@ -879,26 +984,31 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
         out = _solve_small_host(packed, torch, dev, variants, on_device)
         return out[0] if sections is None else out
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
-    wants_order = reorder is not False and reorder is not None
+    plan = order_plan(reorder, nJ_max, nM_max) if B else None
     ordering = None
-    if wants_order and not isinstance(reorder, np.ndarray) and B >= 1024:
+    if plan is not None and plan[0] == "host" and B >= 1024:
         # native code (the GIL is released): the order is found while the inputs go up
         from concurrent.futures import ThreadPoolExecutor
         worker = ThreadPoolExecutor(max_workers=1)
-        ordering = worker.submit(joint_order, packed, reorder)
+        ordering = worker.submit(joint_order, packed, plan[1])
     # the densities play no part in the solve (weights and graph features only): they go up for on-device
     # consumers; otherwise the field is not transferred at all (a fifth of the upload of a cube-truss batch)
     needs_rho = on_device
     full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS if f != "rho" or needs_rho}
     original = dict(full)   # the caller's joint order (the reordering below makes new tensors)
     perm32 = None
-    if wants_order:
+    if plan is not None and plan[0] == "device":
+        # found and applied on the GPU, behind the upload on the same stream: no host pass over the batch
+        ordered = joint_order_device(torch, full, effort=plan[1])
+        perm32 = ordered["perm"]                                             # [B, nJ_max] int32, joint k := old perm[k]
+        full.update({k: ordered[k] for k in ("xyz", "conn", "cbits", "loads")})
+    elif plan is not None:
         if ordering is not None:
             host_perm = ordering.result()
             worker.shutdown(wait=False)
         else:
-            host_perm = joint_order(packed, reorder)
-        perm32 = up(host_perm)                                               # [B, nJ_max] int32, joint k := old perm[k]
+            host_perm = joint_order(packed, plan[1])
+        perm32 = up(host_perm)
         perm = perm32.long()
         inverse = torch.empty_like(perm)
         inverse.scatter_(1, perm, torch.arange(nJ_max, device=dev).expand(B, -1))

@@ -16,6 +16,8 @@ int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, 
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, const int*, const double*, int, double*,
                        double*, double*, const int*, int, hipStream_t);
+int trs_joint_order_launch(int, int, int, const double*, const int*, const unsigned char*, const double*, const int*,
+                           const int*, int*, int*, int*, double*, int*, unsigned char*, double*, int, hipStream_t);
 int trs_solve_small_fits(int, int, int);
 int trs_solve_small_launch(int, int, int, int, const double*, const int*, const double*, const double*,
                            const uint8_t*, const double*, const int*, const int*, double*, double*, double*,
@@ -107,6 +109,19 @@ int trs_fitness(int B, int nJ_max, int nM_max, const double* xyz, const int32_t*
     if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
     return trs_fitness_launch(B, nJ_max, nM_max, xyz, conn, A, rho, nJ, nM, u, N, allow_stress,
                               allow_displace, weight, stress_vio, disp_vio, (hipStream_t)stream);
+}
+
+int trs_joint_order(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const uint8_t* cbits,
+                    const double* loads, const int32_t* nJ, const int32_t* nM, int32_t* perm, int32_t* choice,
+                    int32_t* reach, double* xyz_out, int32_t* conn_out, uint8_t* cbits_out, double* loads_out,
+                    int effort, void* stream) {
+    if (B < 0 || nJ_max <= 0 || nM_max < 0 || (B > 0 && perm == nullptr)) return (int)hipErrorInvalidValue;
+    const int outs = (xyz_out != nullptr) + (conn_out != nullptr) + (cbits_out != nullptr) + (loads_out != nullptr);
+    if (outs != 0 && (outs != 4 || loads == nullptr)) return (int)hipErrorInvalidValue;   // all four or none
+    if (outs == 4 && (xyz_out == xyz || conn_out == conn || cbits_out == cbits || loads_out == loads))
+        return (int)hipErrorInvalidValue;                                                  // out of place only
+    return trs_joint_order_launch(B, nJ_max, nM_max, xyz, conn, cbits, loads, nJ, nM, perm, choice, reach, xyz_out,
+                                  conn_out, cbits_out, loads_out, effort, (hipStream_t)stream);
 }
 
 int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz, const int32_t* conn,

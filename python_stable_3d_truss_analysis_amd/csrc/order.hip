@@ -1,0 +1,578 @@
+// Joint order on the device: the renumbering of every truss's joints that makes the row envelope of K_ff -
+// and with it the 16 x 16 tiles the factorisation touches (trs_common.h) - cheapest, found, applied and priced
+// without a host pass.  No reference counterpart (slientruss3d numbers joints in insertion order,
+// truss.py:175); the workload is the reference's GenerateRandomCubeTrusses loop (generate.py:342-374), whose
+// trusses are far from banded in generator order.
+//
+// Same candidates, same cost and same tie-breaks as the host version csrc/reorder.c (trs_profile_order), so the
+// two return the SAME permutation (asserted in tests/test_gpu_order.py):
+//   candidates   reverse Cuthill-McKee (per component: pseudo-peripheral root by two breadth-first sweeps from a
+//                minimum-degree joint, neighbours by ascending (degree, id)), its reverse, and the joints sorted
+//                lexicographically by coordinates binned to a quarter of the RMS member length, in each of the
+//                six axis orders, forwards and backwards;
+//   cost         w_q = tiles of row chunk q from its first coupled tile (made non-decreasing from the bottom) to
+//                the diagonal, cost = sum_q w_q (w_q + 12).
+//
+// One 256-thread work-group per truss, everything in LDS:
+//   phase A (work-group)  free-joint adjacency (counting sort, lists ordered by (degree, id) with a rank sort),
+//                         Cuthill-McKee LEVEL-SYNCHRONOUSLY: a level's joints discover the next level with
+//                         integer atomics (max for the visit stamp, min for the parent's position) and the new
+//                         level is rank-sorted by (parent position, degree, id) - which IS the queue order of
+//                         the serial algorithm; three sweeps per component;
+//   phase B (per WAVE)    the four waves take different candidates at the same time, no work-group barriers: a
+//                         sweep is ONE rank sort of 64-bit keys (bin, bin, bin, id), pricing is a wave scan of
+//                         the free-DOF counts, a neighbour minimum per joint, integer atomic minima per row
+//                         chunk and a suffix minimum with shuffles;
+//   phase C (work-group)  the cheapest (cost, evaluation order) wins; permutation, envelope reach (the launch hint
+//                         of trs_solver.h) and, if asked, the renumbered inputs go to HBM.
+#include "trs_common.h"
+#include "../../include/trs_solver.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NWAVE = NT / 64;
+constexpr int ID_BITS = 13;                 // joint ids in the sort keys: nJ_max < 8192
+constexpr int PERMANENT = 0x40000000;       // visit stamp of a joint that has its final Cuthill-McKee number
+constexpr unsigned long long NO_COST = ~0ull;
+
+// LDS carve-up shared by host and device (byte offsets, 16-byte aligned parts)
+struct OrdLds {
+    size_t nfr, deg, start, fill, lvl, ppos, queue, nextq, order, ids, frank, bins, adj, adjU, owner, keys,
+        cand, best, newidx, c0, c1, cmin, ctrl, red, total;
+    int nch_max;
+};
+__host__ __device__ inline size_t ord_up(size_t v) { return (v + 15) / 16 * 16; }
+__host__ __device__ inline OrdLds ord_layout(int nJ_max, int nM_max) {
+    OrdLds l;
+    const size_t n = (size_t)nJ_max, e = 2 * (size_t)(nM_max < 1 ? 1 : nM_max);
+    l.nch_max = 3 * nJ_max / 16 + 8;
+    size_t p = 0;
+    auto take = [&](size_t bytes) { const size_t at = p; p += ord_up(bytes); return at; };
+    l.nfr = take(n);                        // u8  [n]    free DOFs of a joint (0: fully constrained)
+    l.deg = take(4 * n);                    // int [n]    adjacency entries of a joint (parallel members count)
+    l.start = take(4 * (n + 1));            // int [n+1]
+    l.fill = take(4 * n);                   // int [n]    fill cursor; later: inverse permutation
+    l.lvl = take(4 * n);                    // int [n]    visit stamps of the breadth-first sweeps
+    l.ppos = take(4 * n);                   // int [n]    queue position of the earliest parent
+    l.queue = take(4 * n);                  // int [n]    Cuthill-McKee queue of the running sweep
+    l.nextq = take(4 * n);                  // int [n]    the level being discovered, unsorted
+    l.order = take(4 * n);                  // int [n]    Cuthill-McKee order of all components so far
+    l.ids = take(2 * n);                    // u16 [n]    free joints by ascending id
+    l.frank = take(2 * (n + 1));            // u16 [n+1]  number of free joints with a smaller id
+    l.bins = take(2 * 3 * n);               // u16 [n][3] coordinate bins
+    l.adj = take(2 * e);                    // u16 [2 nM] neighbour lists, by (degree, id)
+    // the unsorted lists are dead once `adj` is sorted, before any key or candidate exists: they share their space
+    const size_t shared_at = p;
+    l.adjU = take(2 * e);                   // u16 [2 nM] ... as filled
+    l.owner = take(2 * e);                  // u16 [2 nM] owner joint of an adjacency entry
+    const size_t lists_end = p;
+    p = shared_at;
+    l.keys = take(8 * n * NWAVE);           // u64 [4][n] sort keys (phase A: one array of 4 n for the levels)
+    l.cand = take(2 * n * NWAVE);           // u16 [4][n] candidate order of a wave
+    l.best = take(2 * n * NWAVE);           // u16 [4][n] cheapest order a wave has seen
+    l.newidx = take(2 * n * NWAVE);         // u16 [4][n]
+    l.c0 = take(2 * n * NWAVE);             // u16 [4][n] first / last row chunk of a joint
+    l.c1 = take(2 * n * NWAVE);
+    p = p > lists_end ? p : lists_end;
+    l.cmin = take(4 * (size_t)l.nch_max * NWAVE);  // int [4][nch]
+    l.ctrl = take(4 * 32);
+    l.red = take(8 * 64);
+    l.total = p;
+    return l;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(v, off);
+        if (lane >= off) v += up;
+    }
+    return v;
+}
+
+// ---- work-group reductions (256 threads; every thread receives the result) ---------------------------------
+template <typename T, typename F>
+__device__ __forceinline__ T block_reduce(T v, T* red, F op) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off));
+    __syncthreads();  // red may still be read from an earlier reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T r = red[0];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) r = op(r, red[w]);
+    return r;
+}
+
+struct Tables {
+    unsigned char* nfr;
+    int *deg, *start, *fill, *lvl, *ppos, *queue, *nextq, *order;
+    unsigned short *ids, *frank, *bins, *adj, *adjU, *owner;
+    unsigned long long* keys;
+    unsigned short *cand, *best, *newidx, *c0, *c1;
+    int *cmin, *ctrl;
+    unsigned long long* red;
+};
+
+// One Cuthill-McKee sweep from `root` by the whole work-group.  On return queue[0 .. count) holds the joints of
+// root's component in the order the serial algorithm (reorder.c bfs_levels over (degree, id)-sorted lists)
+// enqueues them; *last_begin = index of the first joint of the deepest level.
+__device__ int cm_sweep(const Tables& t, int nj, int root, int stamp, int* last_begin) {
+    const int tid = threadIdx.x;
+    int* tail_next = t.ctrl;  // [0]
+    for (int j = tid; j < nj; j += NT) t.ppos[j] = 0x7fffffff;
+    if (tid == 0) {
+        t.queue[0] = root;
+        t.lvl[root] = stamp;
+        *tail_next = 1;
+    }
+    __syncthreads();
+    int head = 0, tail = 1, depth = 0, begin = 0;
+    while (head < tail) {
+        begin = head;
+        const int mark = stamp + depth + 1;
+        for (int i = head + tid; i < tail; i += NT) {
+            const int v = t.queue[i];
+            for (int e = t.start[v]; e < t.start[v + 1]; ++e) {
+                const int w = t.adj[e];
+                const int old = atomicMax(&t.lvl[w], mark);
+                if (old < stamp) t.nextq[atomicAdd(tail_next, 1)] = w;       // first to reach w
+                if (old < stamp || old == mark) atomicMin(&t.ppos[w], i);     // w's earliest parent
+            }
+        }
+        __syncthreads();
+        const int new_tail = *tail_next;
+        const int m = new_tail - tail;
+        if (m > 1) {
+            // the level in queue order: by (position of the earliest parent, degree, id)
+            for (int x = tid; x < m; x += NT) {
+                const int w = t.nextq[tail + x];
+                t.keys[x] = ((unsigned long long)t.ppos[w] << 40) | ((unsigned long long)t.deg[w] << 20) |
+                            (unsigned long long)w;
+            }
+            __syncthreads();
+            for (int x = tid; x < m; x += NT) {
+                const unsigned long long mine = t.keys[x];
+                int rank = 0;
+                for (int y = 0; y < m; ++y) rank += t.keys[y] < mine ? 1 : 0;
+                t.queue[tail + rank] = (int)(mine & 0xfffffu);
+            }
+        } else if (m == 1 && tid == 0) {
+            t.queue[tail] = t.nextq[tail];
+        }
+        __syncthreads();
+        head = tail;
+        tail = new_tail;
+        ++depth;
+    }
+    *last_begin = begin;
+    return tail;
+}
+
+// Cost of an order of the nf free joints (reorder.c envelope_cost), by ONE wave on its own scratch.
+// ord(k) = old id of the joint at position k.  Returns sum_q w_q (w_q + 12); *n_out = free DOFs.
+template <typename Ord>
+__device__ unsigned long long price_order(const Tables& t, int nf, Ord ord, unsigned short* newidx,
+                                          unsigned short* c0, unsigned short* c1, int* cmin, int lane, int* n_out) {
+    int carry = 0;
+    for (int base = 0; base < nf; base += 64) {
+        const int k = base + lane;
+        const int old = k < nf ? ord(k) : 0;
+        const int v = k < nf ? (int)t.nfr[old] : 0;
+        const int incl = wave_incl_scan(v, lane);
+        const int ds = carry + incl - v;
+        if (k < nf) {
+            newidx[old] = (unsigned short)k;
+            c0[k] = (unsigned short)(ds >> 4);
+            c1[k] = (unsigned short)((ds + v - 1) >> 4);
+        }
+        carry += __shfl(incl, 63);
+    }
+    const int n = carry, nch = (n + 15) >> 4;
+    for (int q = lane; q < nch; q += 64) cmin[q] = q;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < nf; k += 64) {
+        const int old = ord(k);
+        int m = k;  // a joint's own rows may straddle two chunks
+        for (int e = t.start[old]; e < t.start[old + 1]; ++e) m = min(m, (int)newidx[t.adj[e]]);
+        const int col = c0[m];
+        atomicMin(&cmin[c0[k]], col);
+        atomicMin(&cmin[c1[k]], col);
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long cost = 0;
+    int run = nch;
+    for (int base = (nch - 1) / 64 * 64; base >= 0; base -= 64) {
+        const int q = base + lane;
+        int v = q < nch ? cmin[q] : 0x7fffffff;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_down(v, off);
+            if (lane + off < 64) v = min(v, o);
+        }
+        v = min(v, run);
+        if (q < nch) {
+            const unsigned long long w = (unsigned long long)(q - v + 1);
+            cost += w * (w + 12ull);
+        }
+        run = __shfl(v, 0);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cost += __shfl_xor(cost, off);
+    __builtin_amdgcn_wave_barrier();
+    *n_out = n;
+    return cost;
+}
+
+__global__ __launch_bounds__(NT) void trs_joint_order_kernel(
+    const double* __restrict__ xyz, const int* __restrict__ conn, const unsigned char* __restrict__ cbits,
+    const double* __restrict__ loads, const int* __restrict__ nJ_arr, const int* __restrict__ nM_arr,
+    const int nJ_max, const int nM_max, int* __restrict__ perm_out, int* __restrict__ choice_out,
+    int* __restrict__ reach_out, double* __restrict__ xyz_out, int* __restrict__ conn_out,
+    unsigned char* __restrict__ cbits_out, double* __restrict__ loads_out, const int effort) {
+    extern __shared__ unsigned char lds[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nj = nJ_arr[b], nm = nM_arr[b];
+    const OrdLds lay = ord_layout(nJ_max, nM_max);
+    Tables t;
+    t.nfr = lds + lay.nfr;
+    t.deg = reinterpret_cast<int*>(lds + lay.deg);
+    t.start = reinterpret_cast<int*>(lds + lay.start);
+    t.fill = reinterpret_cast<int*>(lds + lay.fill);
+    t.lvl = reinterpret_cast<int*>(lds + lay.lvl);
+    t.ppos = reinterpret_cast<int*>(lds + lay.ppos);
+    t.queue = reinterpret_cast<int*>(lds + lay.queue);
+    t.nextq = reinterpret_cast<int*>(lds + lay.nextq);
+    t.order = reinterpret_cast<int*>(lds + lay.order);
+    t.ids = reinterpret_cast<unsigned short*>(lds + lay.ids);
+    t.frank = reinterpret_cast<unsigned short*>(lds + lay.frank);
+    t.bins = reinterpret_cast<unsigned short*>(lds + lay.bins);
+    t.adj = reinterpret_cast<unsigned short*>(lds + lay.adj);
+    t.adjU = reinterpret_cast<unsigned short*>(lds + lay.adjU);
+    t.owner = reinterpret_cast<unsigned short*>(lds + lay.owner);
+    t.keys = reinterpret_cast<unsigned long long*>(lds + lay.keys);
+    t.cand = reinterpret_cast<unsigned short*>(lds + lay.cand);
+    t.best = reinterpret_cast<unsigned short*>(lds + lay.best);
+    t.newidx = reinterpret_cast<unsigned short*>(lds + lay.newidx);
+    t.c0 = reinterpret_cast<unsigned short*>(lds + lay.c0);
+    t.c1 = reinterpret_cast<unsigned short*>(lds + lay.c1);
+    t.cmin = reinterpret_cast<int*>(lds + lay.cmin);
+    t.ctrl = reinterpret_cast<int*>(lds + lay.ctrl);
+    t.red = reinterpret_cast<unsigned long long*>(lds + lay.red);
+
+    const unsigned char* CB = cbits + (size_t)b * nJ_max;
+    const int* CN = conn + (size_t)b * 2 * nM_max;
+    const double* X = xyz + (size_t)b * 3 * nJ_max;
+    int* P = perm_out + (size_t)b * nJ_max;
+
+    // ---- phase A.0: free DOFs per joint, degrees, member lengths -------------------------------------------
+    for (int j = tid; j < nj; j += NT) {
+        const int cb = CB[j];
+        t.nfr[j] = (unsigned char)(3 - ((cb & 1) + ((cb >> 1) & 1) + ((cb >> 2) & 1)));
+        t.deg[j] = 0;
+        t.lvl[j] = 0;
+    }
+    __syncthreads();
+    double len2 = 0.0;
+    int nlen = 0;
+    for (int m = tid; m < nm; m += NT) {
+        const int a = CN[2 * m], c = CN[2 * m + 1];
+        const double dx = X[3 * c] - X[3 * a], dy = X[3 * c + 1] - X[3 * a + 1], dz = X[3 * c + 2] - X[3 * a + 2];
+        const double l2 = dx * dx + dy * dy + dz * dz;
+        if (l2 > 0.0) {
+            len2 += l2;
+            ++nlen;
+        }
+        if (a == c || t.nfr[a] == 0 || t.nfr[c] == 0) continue;  // couples nothing in K_ff
+        atomicAdd(&t.deg[a], 1);
+        atomicAdd(&t.deg[c], 1);
+    }
+    __syncthreads();
+    // scans by wave 0: adjacency offsets, and the free joints by ascending id
+    if (tid < 64) {
+        int base = 0, fbase = 0;
+        for (int j0 = 0; j0 < nj; j0 += 64) {
+            const int j = j0 + tid;
+            const int v = j < nj ? t.deg[j] : 0;
+            const int f = j < nj && t.nfr[j] != 0 ? 1 : 0;
+            const int incl = wave_incl_scan(v, tid), fincl = wave_incl_scan(f, tid);
+            if (j < nj) {
+                t.start[j] = base + incl - v;
+                t.frank[j] = (unsigned short)(fbase + fincl - f);
+                if (f) t.ids[fbase + fincl - f] = (unsigned short)j;
+            }
+            base += __shfl(incl, 63);
+            fbase += __shfl(fincl, 63);
+        }
+        if (tid == 0) {
+            t.start[nj] = base;
+            t.frank[nj] = (unsigned short)fbase;
+        }
+    }
+    for (int j = tid; j < nj; j += NT) t.fill[j] = 0;
+    __syncthreads();
+    const int nf = t.frank[nj];  // joints that keep a free DOF: they come first in every candidate
+    for (int m = tid; m < nm; m += NT) {
+        const int a = CN[2 * m], c = CN[2 * m + 1];
+        if (a == c || t.nfr[a] == 0 || t.nfr[c] == 0) continue;
+        const int ea = t.start[a] + atomicAdd(&t.fill[a], 1), ec = t.start[c] + atomicAdd(&t.fill[c], 1);
+        t.adjU[ea] = (unsigned short)c;
+        t.owner[ea] = (unsigned short)a;
+        t.adjU[ec] = (unsigned short)a;
+        t.owner[ec] = (unsigned short)c;
+    }
+    __syncthreads();
+    // neighbour lists by ascending (degree, id): rank of an entry inside its list (equal keys = parallel
+    // members: interchangeable, ordered by position)
+    const int nadj = t.start[nj];
+    for (int e = tid; e < nadj; e += NT) {
+        const int a = t.owner[e], s = t.start[a], d = t.deg[a], other = t.adjU[e];
+        const unsigned key = ((unsigned)t.deg[other] << ID_BITS) | (unsigned)other;
+        int rank = 0;
+        for (int i = 0; i < d; ++i) {
+            const int o = t.adjU[s + i];
+            const unsigned k2 = ((unsigned)t.deg[o] << ID_BITS) | (unsigned)o;
+            rank += (k2 < key || (k2 == key && s + i < e)) ? 1 : 0;
+        }
+        t.adj[s + rank] = (unsigned short)other;
+    }
+    __syncthreads();
+
+    // ---- phase A.1: Cuthill-McKee, component by component ---------------------------------------------------
+    int n_order = 0, stamp = 1;
+    for (;;) {
+        unsigned best = 0xffffffffu;  // minimum-degree unvisited free joint, smallest id first
+        for (int j = tid; j < nj; j += NT)
+            if (t.nfr[j] != 0 && t.lvl[j] == 0) best = min(best, ((unsigned)t.deg[j] << ID_BITS) | (unsigned)j);
+        best = block_reduce(best, reinterpret_cast<unsigned*>(t.red), [](unsigned x, unsigned y) { return min(x, y); });
+        if (best == 0xffffffffu) break;
+        int root = (int)(best & ((1u << ID_BITS) - 1)), begin = 0, count = 0;
+        for (int sweep = 0; sweep < 3; ++sweep) {
+            stamp += nj + 2;
+            count = cm_sweep(t, nj, root, stamp, &begin);
+            if (sweep < 2) {  // restart from the first minimum-degree joint of the deepest level
+                unsigned long long pick = NO_COST;
+                for (int i = begin + tid; i < count; i += NT)
+                    pick = min(pick, ((unsigned long long)t.deg[t.queue[i]] << 32) | (unsigned long long)i);
+                pick = block_reduce(pick, t.red, [](unsigned long long x, unsigned long long y) { return min(x, y); });
+                root = t.queue[(int)(pick & 0xffffffffull)];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < count; i += NT) {
+            const int v = t.queue[i];
+            t.order[n_order + i] = v;
+            t.lvl[v] = PERMANENT;
+        }
+        n_order += count;
+        __syncthreads();
+    }
+    // (n_order == nf: every free joint belongs to a component)
+
+    // ---- phase A.2: coordinate bins of the sweeps -----------------------------------------------------------
+    len2 = block_reduce(len2, reinterpret_cast<double*>(t.red), [](double x, double y) { return x + y; });
+    nlen = block_reduce(nlen, reinterpret_cast<int*>(t.red), [](int x, int y) { return x + y; });
+    // a quarter of the RMS member length, rounded to single precision: the sum above runs in another order than
+    // the host's, and the bins must not depend on its last bits
+    const double h = nlen ? (double)(float)(0.25 * sqrt(len2 / (double)nlen)) : 0.0;
+    const bool sweeps = h > 0.0 && h < 1e300 && nf > 1 && effort >= 1;
+    const int bin_cap = 4 * nJ_max + 64;
+    int nb[3] = {1, 1, 1};
+    if (sweeps) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double lo = X[a], hi = X[a];
+            for (int j = tid; j < nj; j += NT) {
+                const double x = X[3 * j + a];
+                lo = x < lo ? x : lo;
+                hi = x > hi ? x : hi;
+            }
+            lo = block_reduce(lo, reinterpret_cast<double*>(t.red), [](double x, double y) { return y < x ? y : x; });
+            hi = block_reduce(hi, reinterpret_cast<double*>(t.red), [](double x, double y) { return y > x ? y : x; });
+            double ha = h;
+            if (!((hi - lo) / ha < (double)(bin_cap - 2))) ha = (hi - lo) / (double)(bin_cap - 2);
+            int top = 1;
+            for (int j = tid; j < nj; j += NT) {
+                double q = ha > 0.0 ? (X[3 * j + a] - lo) / ha + 0.5 : 0.0;
+                if (!(q >= 0.0)) q = 0.0;  // NaN coordinates: any bin
+                if (q > (double)(bin_cap - 1)) q = (double)(bin_cap - 1);
+                t.bins[3 * j + a] = (unsigned short)(int)q;
+                top = max(top, (int)q + 1);
+            }
+            nb[a] = block_reduce(top, reinterpret_cast<int*>(t.red), [](int x, int y) { return max(x, y); });
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: the candidates, four at a time (one per wave, no work-group barrier) ----------------------
+    const int axes[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    int first_ax = 0;  // the sweep along the longest extent is evaluated first (evaluation order breaks ties)
+    for (int ax = 1; ax < 6; ++ax)
+        if (nb[axes[ax][0]] > nb[axes[first_ax][0]] ||
+            (nb[axes[ax][0]] == nb[axes[first_ax][0]] && nb[axes[ax][1]] > nb[axes[first_ax][1]]))
+            first_ax = ax;
+    const int n_sweep = sweeps ? (effort >= 2 ? 6 : 1) : 0;
+    unsigned short* cand = t.cand + (size_t)wave * nJ_max;
+    unsigned short* wbest = t.best + (size_t)wave * nJ_max;
+    unsigned short* newidx = t.newidx + (size_t)wave * nJ_max;
+    unsigned short* c0 = t.c0 + (size_t)wave * nJ_max;
+    unsigned short* c1 = t.c1 + (size_t)wave * nJ_max;
+    int* cmin = t.cmin + (size_t)wave * lay.nch_max;
+    unsigned long long* keys = t.keys + (size_t)wave * nJ_max;
+    unsigned long long my_cost = NO_COST;
+    int my_rank = 0x7fffffff, my_choice = 0, ndof = 0;
+    auto consider = [&](unsigned long long cost, int eval_rank, int choice, auto ord) {
+        if (cost < my_cost || (cost == my_cost && eval_rank < my_rank)) {
+            my_cost = cost;
+            my_rank = eval_rank;
+            my_choice = choice;
+            for (int k = lane; k < nf; k += 64) wbest[k] = (unsigned short)ord(k);
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    if (nf > 0) {
+        if (wave == (n_sweep > 1 ? 2 : 0)) {  // reverse Cuthill-McKee
+            auto ord = [&](int k) { return t.order[nf - 1 - k]; };
+            consider(price_order(t, nf, ord, newidx, c0, c1, cmin, lane, &ndof), 0, 0, ord);
+        }
+        if (wave == (n_sweep > 1 ? 3 : 1)) {  // plain Cuthill-McKee
+            auto ord = [&](int k) { return t.order[k]; };
+            consider(price_order(t, nf, ord, newidx, c0, c1, cmin, lane, &ndof), 1, 1, ord);
+        }
+        for (int i = wave; i < n_sweep; i += NWAVE) {
+            const int ax = i == 0 ? first_ax : (i <= first_ax ? i - 1 : i);
+            const int a0 = axes[ax][0], a1 = axes[ax][1], a2 = axes[ax][2];
+            // lexicographic by (bin a0, bin a1, bin a2, id): one rank sort of 64-bit keys
+            for (int x = lane; x < nf; x += 64) {
+                const int j = t.ids[x];
+                keys[x] = ((unsigned long long)t.bins[3 * j + a0] << (32 + ID_BITS)) |
+                          ((unsigned long long)t.bins[3 * j + a1] << (16 + ID_BITS)) |
+                          ((unsigned long long)t.bins[3 * j + a2] << ID_BITS) | (unsigned long long)j;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int x = lane; x < nf; x += 64) {
+                const unsigned long long mine = keys[x];
+                int rank = 0;
+                int y = 0;
+                for (; y + 1 < nf; y += 2) {  // two keys per LDS read (broadcast: every lane reads the same pair)
+                    const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(keys + y);
+                    rank += (kk.x < mine ? 1 : 0) + (kk.y < mine ? 1 : 0);
+                }
+                if (y < nf) rank += keys[y] < mine ? 1 : 0;
+                cand[rank] = (unsigned short)(mine & ((1ull << ID_BITS) - 1));
+            }
+            __builtin_amdgcn_wave_barrier();
+            auto fwd = [&](int k) { return (int)cand[k]; };
+            auto rev = [&](int k) { return (int)cand[nf - 1 - k]; };
+            consider(price_order(t, nf, fwd, newidx, c0, c1, cmin, lane, &ndof), 2 + 2 * i, 2 + 2 * ax, fwd);
+            consider(price_order(t, nf, rev, newidx, c0, c1, cmin, lane, &ndof), 3 + 2 * i, 3 + 2 * ax, rev);
+        }
+    }
+    // ---- phase C: the winner ---------------------------------------------------------------------------------
+    if (lane == 0) {
+        t.red[wave] = my_cost;
+        t.ctrl[4 + wave] = my_rank;
+        t.ctrl[8 + wave] = my_choice;
+    }
+    __syncthreads();
+    int win = 0;
+    for (int w = 1; w < NWAVE; ++w)
+        if (t.red[w] < t.red[win] || (t.red[w] == t.red[win] && t.ctrl[4 + w] < t.ctrl[4 + win])) win = w;
+    const unsigned short* wperm = t.best + (size_t)win * nJ_max;
+    int* inverse = t.fill;
+    for (int k = tid; k < nJ_max; k += NT) {
+        if (k < nf) {
+            const int old = wperm[k];
+            P[k] = old;
+            inverse[old] = k;
+        } else if (k >= nj) {
+            P[k] = k;  // identity on the padding
+        }
+    }
+    for (int j = tid; j < nj; j += NT)
+        if (t.nfr[j] == 0) {  // fully constrained joints follow the free ones in their given order
+            const int k = nf + j - (int)t.frank[j];
+            P[k] = j;
+            inverse[j] = k;
+        }
+    if (tid == 0 && choice_out != nullptr) choice_out[b] = nf > 0 ? t.ctrl[8 + win] : 0;
+    __syncthreads();
+    // envelope reach of the chosen order below the 64 x 64 diagonal blocks (reorder.c trs_envelope_reach; what
+    // trs_assemble will derive): by wave 0 on its scratch
+    if (reach_out != nullptr && wave == 0) {
+        int widest = 0;
+        if (nf > 0) {
+            auto ord = [&](int k) { return (int)wperm[k]; };
+            int n = 0;
+            price_order(t, nf, ord, newidx, c0, c1, cmin, lane, &n);
+            const int nch = (n + 15) >> 4, nchp = (n + 63) / 64 * 4;
+            int* ft = cmin;  // cmin -> ft: running minimum from the end (padding chunks couple to themselves)
+            for (int q = nch + lane; q < nchp; q += 64) ft[q] = q;
+            __builtin_amdgcn_wave_barrier();
+            int run = nchp;
+            for (int base = (nchp - 1) / 64 * 64; base >= 0; base -= 64) {
+                const int q = base + lane;
+                int v = q < nchp ? ft[q] : 0x7fffffff;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_down(v, off);
+                    if (lane + off < 64) v = min(v, o);
+                }
+                v = min(v, run);
+                if (q < nchp) ft[q] = v;
+                run = __shfl(v, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int j = lane; j < nchp / 4; j += 64) {  // last chunk q with ft[q] <= 4 j + 3 (ft is non-decreasing)
+                const int tcol = 4 * j + 3;
+                int q = tcol;
+                while (q + 1 < nchp && ft[q + 1] <= tcol) ++q;
+                widest = max(widest, q - tcol);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) widest = max(widest, __shfl_xor(widest, off));
+        }
+        if (lane == 0) reach_out[b] = widest;
+    }
+    // the renumbered inputs (reorder.c trs_apply_joint_order): joint k := old joint perm[k], members keep their
+    // order with renumbered ends, padding members stay (0, 0)
+    if (xyz_out != nullptr) {
+        const double* F = loads + (size_t)b * 3 * nJ_max;
+        double* XO = xyz_out + (size_t)b * 3 * nJ_max;
+        double* FO = loads_out + (size_t)b * 3 * nJ_max;
+        unsigned char* CO = cbits_out + (size_t)b * nJ_max;
+        for (int x = tid; x < 3 * nJ_max; x += NT) {
+            const int k = x / 3, a = x - 3 * k;
+            const int old = k < nj ? P[k] : k;   // (P was written by this work-group: visible after the barrier)
+            XO[x] = X[3 * old + a];
+            FO[x] = F[3 * old + a];
+        }
+        for (int k = tid; k < nJ_max; k += NT) CO[k] = CB[k < nj ? P[k] : k];
+        int* CNO = conn_out + (size_t)b * 2 * nM_max;
+        for (int x = tid; x < 2 * nM_max; x += NT) CNO[x] = (x >> 1) < nm ? inverse[CN[x]] : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int trs_joint_order_fits(int nJ_max, int nM_max) {
+    if (nJ_max <= 0 || nM_max < 0 || nJ_max >= (1 << ID_BITS) || nM_max >= 65536) return 0;
+    return ord_layout(nJ_max, nM_max).total <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int trs_joint_order_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
+                                      const unsigned char* cbits, const double* loads, const int* nJ, const int* nM,
+                                      int* perm, int* choice, int* reach, double* xyz_out, int* conn_out,
+                                      unsigned char* cbits_out, double* loads_out, int effort, hipStream_t stream) {
+    if (B <= 0) return 0;
+    if (!trs_joint_order_fits(nJ_max, nM_max)) return (int)hipErrorInvalidValue;
+    static const int lds_limit_set = (int)hipFuncSetAttribute(   // once per process, not per launch
+        reinterpret_cast<const void*>(trs_joint_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)lds_limit_set;
+    const size_t lds = ord_layout(nJ_max, nM_max).total;
+    hipLaunchKernelGGL(trs_joint_order_kernel, dim3(B), dim3(NT), lds, stream, xyz, conn, cbits, loads, nJ, nM, nJ_max,
+                       nM_max, perm, choice, reach, xyz_out, conn_out, cbits_out, loads_out, effort);
+    return (int)hipGetLastError();
+}

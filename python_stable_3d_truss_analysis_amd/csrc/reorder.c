@@ -286,7 +286,9 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
                 const double l2 = dx * dx + dy * dy + dz * dz;
                 if (l2 > 0.0) { len2 += l2; ++nlen; }
             }
-            const double h = nlen ? 0.25 * __builtin_sqrt(len2 / nlen) : 0.0;
+            /* rounded to single precision: the device version (order.hip) sums the squares in another order,
+             * and the bins - hence the permutation - must not depend on the last bits of that sum */
+            const double h = nlen ? (double)(float)(0.25 * __builtin_sqrt(len2 / nlen)) : 0.0;
             if (h > 0.0 && h < 1e300 && nf > 1) {
                 int nb[3];
                 for (int a = 0; a < 3; ++a) {

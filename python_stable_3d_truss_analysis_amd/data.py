@@ -405,9 +405,10 @@ def dataset_chunks(n_samples, rank=0, world=1, chunk=16384, seed=0, numCubeRange
     (`dataset_sizes`) and the generator's per-truss streams alike -: any split into ranks and chunks produces
     the same samples (rank r owns the chunks r, r + world, ...).  One process per
     GPU, no communication: run it under `torchrun` with rank / world from the environment, or in a loop.
-    The native host work of the next chunk (generation, joint order) overlaps the GPU work of the current one."""
+    The native host work of the next chunk (generation; the joint order only where it cannot run on the GPU)
+    overlaps the GPU work of the current one."""
     from concurrent.futures import ThreadPoolExecutor
-    from .batch import joint_order
+    from .batch import joint_order, order_plan
     from .generate import generate_cube_batch
     n_chunks = (int(n_samples) + chunk - 1) // chunk
     mine = list(range(rank, n_chunks, world))
@@ -417,7 +418,10 @@ def dataset_chunks(n_samples, rank=0, world=1, chunk=16384, seed=0, numCubeRange
         count = min(chunk, int(n_samples) - first)
         sizes = dataset_sizes(seed, first, count, numCubeRange)
         packed = generate_cube_batch(sizes, gridRange=gridRange, seed=seed, first_index=first, **generator_args)
-        return first, packed, (joint_order(packed, reorder) if reorder is not False and reorder is not None else False)
+        # the joint order: on the GPU with the solves (`trs_joint_order`) whenever the chunk's shape fits that
+        # kernel - nothing to do here then -, otherwise natively on this thread while the GPU works on chunk k - 1
+        plan = order_plan(reorder, packed.nJ_max, packed.nM_max)
+        return first, packed, (joint_order(packed, plan[1]) if plan is not None and plan[0] == "host" else reorder)
 
     def device_side(packed, order):
         return feature_tensors_device(packed, fixedMemberType, taskType, forceScale, displaceScale,

@@ -300,6 +300,14 @@ class Truss:
             f[jointID] = vec
         return f.ravel()
 
+    def GetKMatrix(self):
+        """The dense global stiffness matrix, `[nJoint * dim, nJoint * dim]` (`truss.py:307-316`): every
+        member's four dim x dim blocks `+- k c c^T` added at its joints' DOFs (DOF = joint * dim + axis),
+        supports NOT eliminated.  Assembled on the GPU by the solve's own assembly kernel
+        (`batch.global_stiffness`); no CPU fallback."""
+        from .batch import global_stiffness  # late import: keeps the model importable without torch
+        return global_stiffness([self])[0]
+
     def GetDisplacementUnknownMask(self):
         """True where the DOF is free (`truss.py:319-326`)."""
         mask = np.ones([len(self._pos) * self._dim], dtype=np.bool_)

@@ -1,0 +1,169 @@
+"""Joint order ON THE DEVICE (`trs_joint_order`, csrc/order.hip) - `-m gpu`.
+
+The device kernel evaluates the candidates of the host version `trs_profile_order` (csrc/reorder.c) with the same
+cost and the same tie-breaks, so the two must return the SAME permutation; the permuted inputs must equal the
+host's `trs_apply_joint_order`; the reach it reports must equal the host's envelope analysis of the permuted
+batch (= what `trs_assemble` derives); stored tiles never exceed the host profile order's; and the solve under
+the device order must match the goldens / the oracle in the caller's numbering.
+"""
+import numpy as np
+import pytest
+
+from oracle import truss_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from python_stable_3d_truss_analysis_amd import batch
+    return batch
+
+
+def _device_order(gpu, packed, effort=2):
+    import torch
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tensors = {f: up(getattr(packed, f)) for f in ("xyz", "conn", "cbits", "loads", "nJ", "nM")}
+    out = gpu.joint_order_device(torch, tensors, effort=effort, want_choice=True)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _fixture_batches(gpu):
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    bundled = gpu.pack_json([H.load_json(n) for n in H.data_case_names()])          # 2D and 3D, 5 .. 696 free DOFs
+    fixtures = gpu.pack_json([d for _, d, _ in H.ragged_cube_cases()])              # the reference's own cube trusses
+    rng = np.random.default_rng(3)
+    cubes = gen.generate_cube_batch(rng.integers(8, 191, size=512), gridRange=(6, 6, 6), seed=11)
+    tiny = gen.generate_cube_batch([1, 1, 2, 3, 5], gridRange=(3, 3, 3), seed=2)
+    return {"bundled": bundled, "cube fixtures": fixtures, "512 random cubes": cubes, "tiny": tiny}
+
+
+def _stored_tiles(gpu, packed):
+    """Tiles trs_assemble stores for a batch in the numbering it comes in (sum over chunks of cend[t] - t)."""
+    dev = gpu.DeviceBatch(packed, use_small=False)
+    dev.dofmap(); dev.assemble()
+    env = dev.env.cpu().numpy()
+    nchm = dev.rows // 16
+    cend = env[:, nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nchm]
+    nch = (packed.n_free + 63) // 64 * 4
+    return np.array([int((cend[b, :nch[b]] - np.arange(nch[b])).sum()) for b in range(packed.B)])
+
+
+@pytest.mark.parametrize("effort", [2, 1, 0])
+def test_device_order_reproduces_the_host_profile_order(gpu, effort):
+    for name, packed in _fixture_batches(gpu).items():
+        got = _device_order(gpu, packed, effort)
+        perm, choice = gpu.profile_permutation(packed, return_choice=True, effort=effort)
+        for b in range(packed.B):
+            nJ = int(packed.nJ[b])
+            assert sorted(got["perm"][b, :nJ].tolist()) == list(range(nJ)), (name, b)     # a permutation
+        np.testing.assert_array_equal(got["choice"], choice, err_msg=name)
+        np.testing.assert_array_equal(got["perm"], perm, err_msg=name)
+        want = gpu.permute_joints(packed, perm)
+        for field in ("xyz", "conn", "cbits", "loads"):
+            np.testing.assert_array_equal(got[field], getattr(want, field), err_msg=f"{name} {field}")
+        np.testing.assert_array_equal(got["reach"], gpu.envelope_reach(packed, perm), err_msg=name)
+
+
+def test_device_order_never_stores_more_tiles_than_the_host_order(gpu):
+    for name, packed in _fixture_batches(gpu).items():
+        if name == "tiny":
+            continue
+        got = _device_order(gpu, packed)
+        mine = _stored_tiles(gpu, gpu.permute_joints(packed, got["perm"]))
+        host = _stored_tiles(gpu, gpu.permute_joints(packed, gpu.profile_permutation(packed)))
+        rcm = _stored_tiles(gpu, gpu.permute_joints(packed, gpu.rcm_permutation(packed)))
+        assert (mine <= host).all(), name
+        assert mine.sum() <= rcm.sum(), name
+    cubes = _fixture_batches(gpu)["512 random cubes"]
+    given = _stored_tiles(gpu, cubes)
+    best = _stored_tiles(gpu, gpu.permute_joints(cubes, _device_order(gpu, cubes)["perm"]))
+    assert best.sum() < 0.5 * given.sum()       # generator order is far from banded
+
+
+def test_solves_under_the_device_order_match_goldens_in_the_callers_numbering(gpu):
+    names = H.data_case_names()
+    datas = [H.load_json(nm) for nm in names] + [d for _, d, _ in H.ragged_cube_cases()]
+    z = H.dense_golden()
+    golds = [{k: z[f"{nm}/{k}"] for k in ("u", "f_ext", "N")} for nm in names] + [g for _, _, g in H.ragged_cube_cases()]
+    packed = gpu.pack_json(datas)
+    assert gpu.order_plan(True, packed.nJ_max, packed.nM_max) == ("device", 2)
+    plain = gpu.solve_batch(packed)
+    for how in ("solve_batch", "resident"):
+        if how == "solve_batch":
+            res = gpu.solve_batch(packed, reorder=True)
+        else:
+            dev = gpu.DeviceBatch(packed, reorder="device", use_small=False)
+            assert dev.joint_out is not None
+            np.testing.assert_array_equal(dev.joint_out.cpu().numpy(), gpu.profile_permutation(packed))
+            dev.u.fill_(float("nan")); dev.f_ext.fill_(float("nan"))
+            dev.solve()
+            res = dev.result()
+        assert not res.info.any()
+        for b, (data, gold) in enumerate(zip(datas, golds)):
+            dim, nJ, nM = orc.truss_dim(data), len(data["joint"]), len(data["member"])
+            assert H.max_scaled_err(res.displace[b, :nJ, :dim], gold["u"]) <= 1e-9, (how, b)
+            assert H.max_scaled_err(res.external[b, :nJ, :dim], gold["f_ext"]) <= 1e-9, (how, b)
+            assert H.max_scaled_err(res.internal[b, :nM], gold["N"]) <= 1e-9, (how, b)
+        assert H.max_scaled_err(res.displace, plain.displace) <= 1e-8
+    # the device order and the host order are the same permutation, so the results are the same bits
+    host = gpu.solve_batch(packed, reorder="host-profile")
+    dev = gpu.solve_batch(packed, reorder="profile")
+    for k in ("displace", "external", "internal"):
+        np.testing.assert_array_equal(getattr(dev, k), getattr(host, k))
+
+
+def test_device_order_edge_cases(gpu):
+    """A fully pinned truss (no free joint), disconnected components, members to pinned joints only, parallel
+    members, a 2D truss, and a shape the kernel refuses."""
+    mt = [1.0, 1e7, 0.1]
+    pinned = {"joint": [[[0.0, 0.0, 0.0], "PIN"], [[1.0, 0.0, 0.0], "PIN"]], "force": [], "member": [[[0, 1], mt]]}
+    two_parts = {"joint": [[[0, 0, 0], "PIN"], [[1, 0, 0], "PIN"], [[0, 1, 0], "PIN"], [[0.3, 0.3, 1], "NO"],
+                           [[10, 0, 0], "PIN"], [[11, 0, 0], "PIN"], [[10, 1, 0], "PIN"], [[10.3, 0.3, 1], "NO"],
+                           [[10.3, 0.3, 2], "NO"]],
+                 "force": [[3, [1.0, 2.0, -3.0]], [8, [0.0, 0.0, -5.0]]],
+                 "member": [[[0, 3], mt], [[1, 3], mt], [[2, 3], mt], [[3, 0], mt], [[4, 7], mt], [[5, 7], mt],
+                            [[6, 7], mt], [[7, 8], mt], [[4, 8], mt], [[5, 8], mt], [[6, 8], mt], [[8, 7], mt]]}
+    datas = [pinned, two_parts, H.load_json("bar-47_input_0"), H.edge_cases()["3d_parallel_members"]["input"]]
+    packed = gpu.pack_json(datas)
+    got = _device_order(gpu, packed)
+    perm, choice = gpu.profile_permutation(packed, return_choice=True)
+    np.testing.assert_array_equal(got["perm"], perm)
+    np.testing.assert_array_equal(got["choice"], choice)
+    res = gpu.solve_batch(packed, reorder="device")
+    for b, data in enumerate(datas[1:], start=1):
+        ref = orc.solve(data)
+        dim, nJ = orc.truss_dim(data), len(data["joint"])
+        assert H.max_scaled_err(res.displace[b, :nJ, :dim], ref["u"]) <= 1e-9
+    lib = gpu._capi.load()
+    assert lib.trs_joint_order_fits(343, 2100) == 1 and lib.trs_joint_order_fits(8192, 100) == 0
+    assert lib.trs_joint_order_fits(4000, 60000) == 0
+    assert gpu.order_plan(True, 9000, 100) == ("host", "profile")
+    with pytest.raises(ValueError):
+        gpu.order_plan("device", 9000, 100)
+
+
+def test_device_order_at_the_benchmark_batch(gpu):
+    """bar-942 x 4096 and 16 384 mixed cube trusses: every copy of bar-942 gets the host's order; the cube
+    batch solved under the device order satisfies equilibrium and matches the oracle on a sample."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    one = gpu.pack_json([H.load_json("bar-942_input_0")])
+    got = _device_order(gpu, one.replicate(4096))
+    want = gpu.profile_permutation(one)
+    assert (got["perm"] == want[0]).all() and (got["reach"] == got["reach"][0]).all()
+    rng = np.random.default_rng(0)
+    cubes = gen.generate_cube_batch(rng.integers(8, 191, size=16384), gridRange=(6, 6, 6), seed=7)
+    res = gpu.solve_batch(cubes, reorder=True)
+    assert not res.info.any()
+    total = res.external.sum(axis=1)
+    assert np.abs(total).max() <= 1e-6 * np.abs(res.external).max()
+    for b in (0, 5000, 16383):
+        data = gen.packed_to_json(cubes, b)
+        ref = orc.solve(data)
+        nJ, nM = int(cubes.nJ[b]), int(cubes.nM[b])
+        assert H.max_scaled_err(res.displace[b, :nJ], ref["u"]) <= 1e-8
+        assert H.max_scaled_err(res.internal[b, :nM], ref["N"]) <= 1e-8

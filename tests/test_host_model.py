@@ -177,6 +177,22 @@ def test_solve_without_gpu_fails_loudly():
     t = Truss(3).LoadFromJSON(data=H.load_json("bar-25_input_0"))
     with pytest.raises(HipExtensionError):
         t.Solve()
+    with pytest.raises(HipExtensionError):   # the reference's GetKMatrix (truss.py:307-316) is device work too
+        t.GetKMatrix()
+
+
+def test_public_method_names_of_the_reference_truss_are_all_offered():
+    """Every public method / property of the reference's `Truss` (slientruss3d/truss.py:109-462, names listed
+    here as data) exists on the drop-in class."""
+    names = """dim nJoint nMember nForce nResistance isStable weight isSolved AddNewJoint AddExternalForce
+        AddNewMember SetJointPosition SetJointPositions SetSupportType SetSupportTypes SetMemberType
+        SetMemberTypes GetJointPosition GetJointPositions GetSupportType GetSupportTypes GetMemberType
+        GetMemberTypes GetMemberConnect GetMemberFromConnect GetForce GetJoints GetMembers GetForces
+        GetDisplacements GetExternalForces GetInternalForces GetInternalStresses GetResistances GetJointIDs
+        GetMemberIDs GetUsedMemberTypes GetExternalForceVector GetKMatrix GetDisplacementUnknownMask Solve
+        Serialize LoadFromJSON DumpIntoJSON Copy IsInternalStressAllowed IsDisplacementAllowed""".split()
+    missing = [n for n in names if not hasattr(Truss, n)]
+    assert not missing, missing
 
 
 def test_size_buckets_and_trimmed_cover_a_ragged_batch():
