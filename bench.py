@@ -67,7 +67,7 @@ def algorithmic_counts(n, nJ, nM, env_cend=None, narrow=False):
     upper = sum((row_end(c) + col - (c // 16) * 16) for c in range(npad)) * 8
     vec = 8 * npad if narrow else 0
     return {
-        "potrf_flops": n ** 3 / 3.0 + n ** 2,           # factor + fused forward substitution
+        "potrf_flops": n ** 3 / 3.0 + 2 * n ** 2,       # factor + two triangular solves
         "assemble_bytes": inputs + upper + vec,         # K written once (upper part), f, + inputs
         "assemble_bytes_full_contract": inputs + 8 * n * n + 8 * n,  # SURVEY section 8d figure
         "potrf_bytes": 2 * upper + 2 * vec,             # stored part of K read once, U written once; f in, y out
@@ -167,35 +167,152 @@ def cpu_baseline_all_cores(data, seconds=8.0):
             "sample": f"{runs} oracle.solve() calls on bar-942 by {n} single-threaded processes (of {os.cpu_count()} logical CPUs) in {dt:.1f} s"}
 
 
-def cube_batch_rate(device, B, torch, batch):
-    """Informational: resident-batch throughput on a mixed GenerateRandomCubeTrusses-like batch
-    (native generator, joints renumbered by the profile order of csrc/reorder.c, bucketed by padded size; BASELINE config 3)."""
+def envelope_counts_batch(n_free, nJ, nM, ft, last, cend, narrow):
+    """Per-truss executed MFMA FLOP of the factorisation and algorithmic bytes of every stage for a bucket of
+    NARROW-envelope matrices, from the envelope metadata trs_assemble left (arrays [Bb, ...]): the vectorised
+    form of `potrf_tile_flops(narrow=True)` and `algorithmic_counts(narrow=True)` (asserted equal in
+    tests/test_bench_helpers.py).  Returns dict of float arrays [Bb]."""
+    import numpy as np
+    n_free = np.asarray(n_free, dtype=np.int64)
+    Bb = len(n_free)
+    npad = (n_free + 63) // 64 * 64
+    nch, npan = npad // 16, npad // 64
+    ft, last, cend = (np.asarray(a, dtype=np.int64) for a in (ft, last, cend))
+    width = ft.shape[1]
+    mfma = np.zeros(Bb, dtype=np.int64)
+    rows = np.arange(Bb)
+    for j in range(int(npan.max(initial=0))):
+        act = j < npan
+        r0 = 64 * j
+        cols = np.minimum(4 * j + np.arange(4), width - 1)
+        ftj = ft[:, cols]
+        kd = 16 * ftj[:, 0]
+        for u in range(4):
+            mfma += act * (u + 1) * (np.maximum(0, r0 - np.maximum(kd, 16 * ftj[:, u])) // 4)
+        mfma += act * 104
+        lastq = last[:, min(j, last.shape[1] - 1)]
+        below = np.where(act, lastq - (4 * j + 3), 0)
+        end = 4 * j + 4 + below
+        cj = cend[:, cols]                                             # stored extents of the panel's four chunks
+        for i in range(int((below.max(initial=0) + 1) // 2)):
+            c0 = 4 * j + 4 + 2 * i
+            valid = c0 < end
+            nv = np.minimum(2, end - c0)
+            ks = 16 * ft[rows, np.minimum(c0, width - 1)]
+            mfma += valid * nv * (r0 - ks)
+            for q in (c0, c0 + 1):
+                has = valid & (q < c0 + nv)
+                e = (q < cj).sum(axis=1)
+                mfma += has * (4 * e + 2 * e * (e - 1))
+    t = np.arange(width)[None, :]
+    tiles = ((cend - t) * (t < nch[:, None])).sum(axis=1)
+    upper = tiles * 2048
+    vec = 8 * npad
+    inputs = 24 * np.asarray(nM, dtype=np.int64) + 49 * np.asarray(nJ, dtype=np.int64)
+    return {"potrf_tile_flops": 2048.0 * mfma, "tiles": tiles,
+            "assemble_bytes": inputs + upper + vec,
+            "potrf_bytes": 3 * upper + 4 * vec,            # factor + substitution by the same wave
+            "recover_bytes": 24 * np.asarray(nM) + 24 * np.asarray(nJ) + 8 * n_free + 48 * np.asarray(nJ) + 8 * np.asarray(nM),
+            "order_bytes": 2 * (49 * np.asarray(nJ, dtype=np.int64) + 8 * np.asarray(nM, dtype=np.int64)) + 4 * np.asarray(nJ)}
+
+
+def cube_workload(B, rank, seed=7):
+    """BASELINE config 3: B random cube trusses as `GenerateRandomCubeTrusses(gridRange=(6,6,6), numCube ~ U{8..190},
+    LinkType.Random, GenerateMethod.Random)` (native generator, csrc/cubegen.c; distribution pinned against the
+    reference in tests/test_generate.py).  Rank r draws the trusses with global indices r B .. (r + 1) B - 1."""
     import numpy as np
     from python_stable_3d_truss_analysis_amd import generate as gen
-    rng = np.random.default_rng(0)
+    from python_stable_3d_truss_analysis_amd.data import dataset_sizes
+    sizes = dataset_sizes(seed, rank * B, B, (8, 190))
+    return gen.generate_cube_batch(sizes, gridRange=(6, 6, 6), seed=seed, first_index=rank * B)
+
+
+def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world):
+    """The ragged workload north_star names (BASELINE config 3): `--cube-batch` random cube trusses per GPU,
+    resident in HBM in the GENERATOR's joint numbering; one step = joint order on the device + bucketed
+    assembly / factorisation / substitution / recovery + results back in the caller's order and numbering
+    (`batch.RaggedSolver`).  Timed like the headline: barrier, K steps, barrier, max over ranks."""
+    import numpy as np
     t0 = time.perf_counter()
-    packed = gen.generate_cube_batch(rng.integers(8, 191, size=B), gridRange=(6, 6, 6), seed=7)
+    packed = cube_workload(args.cube_batch, rank)
     t_gen = time.perf_counter() - t0
+    solver = batch.RaggedSolver(packed, device, reorder=True)
+    for _ in range(max(1, args.cube_warmup)):
+        solver.step()
+    torch.cuda.synchronize(device)
+    hinted = solver.adopt_launch_hints()
+    solver.step()
+    barrier()
     t0 = time.perf_counter()
-    packed = batch.permute_joints(packed, batch.profile_permutation(packed))
-    t_rcm = time.perf_counter() - t0
-    groups = batch.size_buckets(packed, 64 << 30)
-    total, bad = 0.0, 0
-    for idx in groups:
-        sub = batch.DeviceBatch(packed.take(idx).trimmed(), device)
-        sub.solve()
+    for _ in range(args.cube_steps):
+        solver.step()
+    barrier()
+    elapsed = reduce_max(time.perf_counter() - t0)
+    records = []
+    for _ in range(args.cube_steps):
+        solver.step(record=records)
+    torch.cuda.synchronize(device)
+    stage_ms = {}
+    for name, e0, e1 in records:
+        stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1) / args.cube_steps
+    info_bad = int((solver.info != 0).sum().item())
+    if rank != 0:
+        return None
+    # executed matrix-core work and algorithmic bytes of this rank's batch, from the envelope metadata of every
+    # bucket (the buckets share one workspace: re-assemble bucket by bucket to read it)
+    flops = bytes_alg = tiles = 0.0
+    n_wide = 0
+    per_stage = {"order": 0.0, "assemble": 0.0, "potrf": 0.0, "recover": 0.0}
+    for bk in solver.buckets:
+        db, idx = bk["dev"], bk["idx"]
+        nJ, nM, nf = packed.nJ[idx], packed.nM[idx], packed.n_free[idx]
+        if bk["renumbered"]:
+            per_stage["order"] += float((2 * (49 * nJ.astype(np.int64) + 8 * nM) + 4 * nJ).sum())
+        if db.small:   # the fused small-system kernel: inputs once, results once
+            per_stage["assemble"] += float((24 * nM.astype(np.int64) + 49 * nJ).sum())
+            per_stage["recover"] += float((8 * nM.astype(np.int64) + 48 * nJ).sum())
+            continue
+        # (the buckets share one workspace, which holds the LAST bucket's metadata: redo this bucket's first two
+        # stages on its own gathered inputs, which persist)
+        db.dofmap(); db.assemble()
         torch.cuda.synchronize(device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); sub.solve(); e1.record()
-        torch.cuda.synchronize(device)
-        total += e0.elapsed_time(e1) * 1e-3
-        bad += int((sub.info != 0).sum().item())
-        del sub
-    return {"workload": f"{B} random cube trusses, {int(packed.nM.min())}..{int(packed.nM.max())} members, "
-                        f"n_free {int(packed.n_free.min())}..{int(packed.n_free.max())}",
-            "solves_per_s": B / total, "buckets": len(groups), "info_nonzero": bad,
-            "host_generate_s": t_gen, "host_reorder_s": t_rcm,
-            "note": "inputs resident, one launch pipeline per size bucket; informational, not the headline"}
+        env = db.env.cpu().numpy()
+        nchm, npan = db.rows // 16, db.rows // 64
+        narrow = (env[:, nchm + npan] & 0xff) == 1
+        n_wide += int((~narrow).sum())
+        c = envelope_counts_batch(nf, nJ, nM, env[:, :nchm], env[:, nchm:nchm + npan],
+                                  env[:, nchm + npan + 8: nchm + npan + 8 + nchm], narrow)
+        flops += float(c["potrf_tile_flops"][narrow].sum())
+        tiles += float(c["tiles"].sum())
+        for k in ("assemble", "potrf", "recover"):
+            per_stage[k] += float(c[k + "_bytes"].sum())
+    bytes_alg = sum(per_stage.values())
+    step_s = elapsed / args.cube_steps
+    tf, gbs = flops / step_s / 1e12, bytes_alg / step_s / 1e9
+    intensity = flops / max(1.0, bytes_alg)
+    bound = "mfma" if intensity >= PEAK_FP64_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+    return {"workload": f"{packed.B} random cube trusses per GPU (grid 6x6x6, 8..190 cubes, seed 7): "
+                        f"{int(packed.nM.min())}..{int(packed.nM.max())} members, n_free {int(packed.n_free.min())}.."
+                        f"{int(packed.n_free.max())} (mean {float(packed.n_free.mean()):.0f})",
+            "value": world * packed.B * args.cube_steps / elapsed, "unit": "solves/s", "ms_per_step": step_s * 1e3,
+            "steps": args.cube_steps, "batch_per_gpu": packed.B, "buckets": len(solver.buckets),
+            "buckets_with_launch_hints": hinted, "info_nonzero": info_bad, "wide_envelopes": n_wide,
+            "joint_order": "trs_joint_order on the device, INSIDE the timed step (every candidate); results in the "
+                           "generator's numbering",
+            "stages_ms": stage_ms,
+            "roofline": {"bound": bound, "intensity_flop_per_byte": intensity,
+                         "mfma": {"achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_TFLOPS,
+                                  "flop_model": "MFMA work of the factorisation inside the 16x16-tile envelopes, "
+                                                "per step and GPU, over the WHOLE step time"},
+                         "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                 "byte_model": "order (inputs read, renumbered inputs + permutation written) + assembly "
+                                               "(inputs, stored tiles, load vector) + factorisation with fused "
+                                               "substitution (3 x tiles, vectors) + recovery, over the WHOLE step time; "
+                                               "the bucket gather / scatter copies are overhead, not counted",
+                                 "bytes_per_step": bytes_alg, "by_stage": per_stage},
+                         "stored_tiles_per_truss": tiles / max(1, packed.B)},
+            "host_generate_s": t_gen,
+            "note": "inputs resident in generator order; one launch pipeline per size bucket on a shared workspace"}
 
 
 def launch_ranks(n):
@@ -226,8 +343,10 @@ def main():
     ap.add_argument("--cpu-pool-seconds", type=float, default=8.0,
                     help="sample length of the all-host-cores oracle baseline (0 = skip)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational PCIe-inclusive pass")
-    ap.add_argument("--cube-batch", type=int, default=16384,
-                    help="size of the informational mixed cube-truss batch (0 = skip)")
+    ap.add_argument("--cube-batch", type=int, default=65536,
+                    help="trusses per GPU of the mixed cube-truss leg, BASELINE config 3 (0 = skip)")
+    ap.add_argument("--cube-steps", type=int, default=5)
+    ap.add_argument("--cube-warmup", type=int, default=1)
     ap.add_argument("--dense", action="store_true",
                     help="treat every stiffness matrix as dense (no envelope tile skipping)")
     ap.add_argument("--no-dense-ref", action="store_true",
@@ -300,6 +419,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def reduce_max(seconds):
+        if not distributed:
+            return seconds
+        tmax = torch.tensor([seconds], dtype=torch.float64, device=device if timing_group == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
     packed = batch.pack_json([data]).replicate(args.batch)
     order = False if args.joint_order == "given" or args.dense else args.joint_order
     dev = batch.DeviceBatch(packed, device, use_envelope=not args.dense, reorder=order,
@@ -340,11 +466,7 @@ def main():
         step(all_events[k])
     torch.cuda.synchronize(device)
 
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64,
-                            device=device if timing_group == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = reduce_max(elapsed)
 
     stage_ms = {s: float(np.mean([all_events[k][i][0].elapsed_time(all_events[k][i][1])
                                   for k in range(args.steps)])) for i, s in enumerate(STAGES)}
@@ -408,6 +530,16 @@ def main():
                         "batches; never the headline value"}
         del pipe
 
+    # the ragged workload of north_star (BASELINE config 3), on EVERY rank, with its own barrier-bracketed region
+    cube = None
+    if args.cube_batch > 0:
+        torch.cuda.empty_cache()
+        try:
+            cube = cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world)
+        except Exception as exc:  # never lose the headline line over it
+            cube = {"error": repr(exc)}
+            if distributed:
+                raise
     if rank == 0:
         total_trusses = world * args.batch * args.steps
         potrf_s = potrf_ms_timed * 1e-3   # the dominant kernel, measured inside the timed region
@@ -531,13 +663,8 @@ def main():
         }
         if pcie is not None:
             line["pcie_inclusive"] = pcie
-        if args.cube_batch > 0 and world == 1:
-            del dev
-            torch.cuda.empty_cache()
-            try:
-                line["cube_batch"] = cube_batch_rate(device, args.cube_batch, torch, batch)
-            except Exception as exc:  # informational only: never lose the headline line over it
-                line["cube_batch"] = {"error": repr(exc)}
+        if cube is not None:
+            line["cube_batch"] = cube
         if given is not None:
             line["given_joint_order"] = given
         if dense_ms is not None:
@@ -545,7 +672,12 @@ def main():
                 "avg_launch_ms": dense_ms,
                 "achieved_tflops": dense_flops * args.batch / (dense_ms * 1e-3) / 1e12,
                 "frac_of_peak": dense_flops * args.batch / (dense_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                "note": "same kernel with the envelope off: n^3/3 + n^2 FLOP per truss (SURVEY 8d)"}
+                "note": "same kernel with the envelope off: n^3/3 + 2 n^2 FLOP per truss (SURVEY 8d)"}
+            line["roofline"]["frac_dense_8d"] = line["dense_mode_potrf"]["frac_of_peak"]
+            line["roofline"]["frac_dense_8d_note"] = (
+                "SURVEY 8d's dense figure (n^3/3 + 2 n^2 FLOP per truss) over the DENSE-mode launch of the same "
+                "factorisation kernel (envelope off), as a fraction of the FP64 MFMA peak; the headline kernel "
+                "skips the structural zeros of K_ff and is priced by its own bytes (frac)")
         if not args.no_cpu_baseline and world == 1:  # the oracle leg (rank 0 at N = 1 only): CPU baseline + check
             line["cpu_baseline"], ref = cpu_baseline(data, args.cpu_seconds)
             if cpu_all is not None:

@@ -244,6 +244,19 @@ int trs_joint_order(int B, int nJ_max, int nM_max, const double *xyz, const int3
                     int32_t *perm, int32_t *choice, int32_t *reach, double *xyz_out, int32_t *conn_out,
                     uint8_t *cbits_out, double *loads_out, int effort, void *stream);
 
+/* Row gather / scatter between the padded arrays of a ragged batch and those of one of its size buckets
+ * (no reference counterpart: the reference solves one truss per call; its ragged workload is the
+ * GenerateRandomCubeTrusses loop, generate.py:342-374).  A bucket's arrays are the rows of its trusses trimmed
+ * to the bucket's own maxima; every trimmed field is a PREFIX of the full row, so both directions copy, for every
+ * field k < nfields (at most 12, one launch) and every i < count, `width[k]` bytes:
+ *   scatter == 0:  dst[k] + i * dst_pitch[k]        <-  src[k] + rows[i] * src_pitch[k]     (gather)
+ *   scatter != 0:  dst[k] + rows[i] * dst_pitch[k]  <-  src[k] + i * src_pitch[k]           (scatter)
+ * src / dst / pitches / widths are HOST arrays of device pointers and byte counts (read at call time);
+ * rows is a device array of int64 row indices (distinct for a scatter). */
+int trs_copy_rows(int nfields, const void *const *src, const size_t *src_pitch, void *const *dst,
+                  const size_t *dst_pitch, const size_t *width, int count, const int64_t *rows, int scatter,
+                  void *stream);
+
 /* The whole Truss.Solve() pipeline (truss.py:329-364) on one stream: trs_solve_small when the batch
  * shape qualifies (the slab, uf, work and env arguments are then not touched), otherwise
  * dofmap -> assemble -> potrf -> potrs -> recover.  Workspace pointers as above; joint_out as in

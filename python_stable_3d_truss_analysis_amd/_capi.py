@@ -35,6 +35,7 @@ SIGNATURES = {
                                     _I, _P, _P, _P, _P, _P, _P]),
     "trs_joint_order_fits": (_I, [_I, _I]),
     "trs_joint_order": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "trs_copy_rows": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "trs_solve": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
                        _P, _P, _P, _P, _P, _P, _P, _I, _P]),
 }

@@ -294,23 +294,25 @@ def order_plan(reorder, nJ_max, nM_max):
                      "'host-fast' or a permutation array)")
 
 
-def joint_order_device(torch, tensors, effort=2, apply=True, want_choice=False):
+def joint_order_device(torch, tensors, effort=2, apply=True, want_choice=False, out=None):
     """`trs_joint_order` on resident inputs (`tensors`: xyz, conn, cbits, loads, nJ, nM on one device, padded
     shapes of `PackedBatch`): the cheapest joint order of every truss found ON THE GPU, asynchronously on the
     current stream.  Returns a dict: `perm` int32 [B, nJ_max] (old id of the joint that becomes joint k = the
     `joint_out` of the recovery), `reach` int32 [B] (envelope reach of the chosen order, the launch hint),
-    `choice` (if asked) and, with `apply`, the renumbered `xyz`, `conn`, `cbits`, `loads`."""
+    `choice` (if asked) and, with `apply`, the renumbered `xyz`, `conn`, `cbits`, `loads`.  `out` = the dict
+    of an earlier call with the same shapes: its tensors are written again (no allocation)."""
     lib = _capi.load()
     xyz, conn, cbits, loads = (tensors[k].contiguous() for k in ("xyz", "conn", "cbits", "loads"))
     dev = xyz.device
     B, nJ_max, nM_max = int(xyz.shape[0]), int(xyz.shape[1]), int(conn.shape[1])
-    out = {"perm": torch.empty([B, nJ_max], dtype=torch.int32, device=dev),
-           "reach": torch.empty([B], dtype=torch.int32, device=dev)}
-    if want_choice:
-        out["choice"] = torch.empty([B], dtype=torch.int32, device=dev)
-    if apply:
-        out.update(xyz=torch.empty_like(xyz), conn=torch.empty_like(conn), cbits=torch.empty_like(cbits),
-                   loads=torch.empty_like(loads))
+    if out is None:
+        out = {"perm": torch.empty([B, nJ_max], dtype=torch.int32, device=dev),
+               "reach": torch.empty([B], dtype=torch.int32, device=dev)}
+        if want_choice:
+            out["choice"] = torch.empty([B], dtype=torch.int32, device=dev)
+        if apply:
+            out.update(xyz=torch.empty_like(xyz), conn=torch.empty_like(conn), cbits=torch.empty_like(cbits),
+                       loads=torch.empty_like(loads))
     ptr = lambda k: out[k].data_ptr() if k in out else None
     with torch.cuda.device(dev):
         _capi.check(lib.trs_joint_order(
@@ -849,6 +851,166 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30, granularity=64):
         step = max(1, max_slab_bytes // per_truss)
         groups.extend(idx[i: i + step] for i in range(0, len(idx), step))
     return groups
+
+
+class RaggedSolver:
+    """A RAGGED batch (trusses of very different sizes: the reference's `GenerateRandomCubeTrusses` loop,
+    `generate.py:342-374`, BASELINE config 3) resident on one device in the caller's order and numbering, set
+    up once and solved any number of times with everything on the GPU:
+
+        joint order (`trs_joint_order`: found, applied and priced on the device)
+        per size bucket:  gather the bucket's rows, trimmed (`trs_copy_rows`)  ->  `trs_solve`
+                          ->  scatter u / f_ext / N / info back to the caller's rows (`trs_copy_rows`)
+
+    The buckets (`size_buckets`) share ONE workspace (slab, reduced vectors, assembly tables, envelope
+    metadata) sized for the largest of them; their launches follow each other on the current stream.  Results
+    stay resident (`u`, `f_ext`, `N`, `info`: full-batch tensors in the caller's numbering) until `result()`
+    downloads them.  `reorder` as `order_plan`; a host-side plan is carried out once, at set-up."""
+
+    GATHER = ("xyz", "conn", "E", "A", "cbits", "loads", "nJ", "nM")
+
+    def __init__(self, packed: PackedBatch, device=None, reorder=True, max_slab_bytes=48 << 30, granularity=64,
+                 options=None):
+        torch, dev = _require_gpu(device)
+        self.torch, self.device, self.packed, self.lib = torch, dev, packed, _capi.load()
+        B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
+        self.B = B
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.inputs = {f: up(getattr(packed, f)) for f in self.GATHER}
+        plan = order_plan(reorder, nJ_max, nM_max) if B else None
+        self.plan = plan
+        self.ordered = None        # renumbered xyz / conn / cbits / loads + perm (+ reach), device tensors
+        if plan is not None and plan[0] != "device":
+            perm = joint_order(packed, plan[1])
+            renum = permute_joints(packed, perm)
+            self.ordered = {k: up(getattr(renum, k)) for k in ("xyz", "conn", "cbits", "loads")}
+            self.ordered["perm"] = up(perm)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # padding beyond a bucket's width stays 0
+        self.u, self.f_ext = z([B, nJ_max, 3], torch.float64), z([B, nJ_max, 3], torch.float64)
+        self.N, self.info = z([B, nM_max], torch.float64), z([B], torch.int32)
+        groups = size_buckets(packed, max_slab_bytes, granularity) if B else []
+        n_pad_of = lambda idx: (int(packed.n_free[idx].max()) + 63) // 64 * 64
+        groups.sort(key=lambda idx: -len(idx) * n_pad_of(idx) * (n_pad_of(idx) + 16))
+        self.buckets = []
+        need = {"S": 0, "uf": 0, "work": 0, "env": 0}
+        for idx in groups:
+            nJ_b, nM_b = max(1, int(packed.nJ[idx].max())), max(1, int(packed.nM[idx].max()))
+            n_b, Bb = int(packed.n_free[idx].max()), len(idx)
+            e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+            sub = {"xyz": e([Bb, nJ_b, 3], torch.float64), "loads": e([Bb, nJ_b, 3], torch.float64),
+                   "cbits": e([Bb, nJ_b], torch.uint8), "conn": e([Bb, nM_b, 2], torch.int32),
+                   "E": e([Bb, nM_b], torch.float64), "A": e([Bb, nM_b], torch.float64),
+                   "nJ": e([Bb], torch.int32), "nM": e([Bb], torch.int32)}
+            sub["rho"] = sub["A"]   # placeholder of the right shape: no kernel of the solve reads the densities
+            small = bool(self.lib.trs_solve_small_fits(nJ_b, nM_b, n_b))
+            renumbered = plan is not None and not small   # the fused small-system kernel gains nothing from an order
+            jout = e([Bb, nJ_b], torch.int32) if renumbered else None
+            db = DeviceBatch.from_device(sub, n_b, joint_out=jout)
+            db.options.update(options or {})
+            if not db.small:
+                need["S"] = max(need["S"], Bb * db.rows * db.ld)
+                need["uf"] = max(need["uf"], Bb * db.rows)
+                need["work"] = max(need["work"], Bb * self.lib.trs_assemble_work_bytes(nJ_b, nM_b, n_b))
+                need["env"] = max(need["env"], Bb * self.lib.trs_env_ints(n_b))
+            self.buckets.append({"rows": up(np.ascontiguousarray(idx, dtype=np.int64)), "dev": db, "count": Bb,
+                                 "renumbered": renumbered, "idx": idx})
+        # one workspace for all buckets (they run one after the other on the stream)
+        self._S = torch.empty([need["S"]], dtype=torch.float64, device=dev)
+        if os.environ.get("TRS_DEBUG_POISON"):
+            self._S.fill_(float("nan"))
+        self._uf = torch.empty([need["uf"]], dtype=torch.float64, device=dev)
+        self._work = torch.empty([need["work"]], dtype=torch.uint8, device=dev)
+        self._env = torch.zeros([need["env"]], dtype=torch.int32, device=dev)
+        for bk in self.buckets:
+            db, Bb = bk["dev"], bk["count"]
+            if not db.small:
+                wb = self.lib.trs_assemble_work_bytes(db.nJ_max, db.nM_max, db.n_max)
+                ei = self.lib.trs_env_ints(db.n_max)
+                db._slab = (self._S[:Bb * db.rows * db.ld].view(Bb, db.rows, db.ld),
+                            self._uf[:Bb * db.rows].view(Bb, db.rows), self._work[:Bb * wb].view(Bb, wb),
+                            self._env[:Bb * ei].view(Bb, ei))
+        self._tables = None
+
+    def _copy_tables(self):
+        """ctypes argument arrays of the gather / scatter launches of every bucket (device pointers are fixed
+        once the ordered tensors exist)."""
+        import ctypes
+        P, Z = ctypes.c_void_p, ctypes.c_size_t
+        row_bytes = lambda t: int(t[0].numel() * t.element_size()) if t.dim() > 1 else int(t.element_size())
+        tables = []
+        for bk in self.buckets:
+            db = bk["dev"]
+            pairs = []
+            for f in self.GATHER:
+                renum = bk["renumbered"] and f in ("xyz", "conn", "cbits", "loads")
+                pairs.append(((self.ordered if renum else self.inputs)[f], getattr(db, f)))
+            if bk["renumbered"]:
+                pairs.append((self.ordered["perm"], db.joint_out))
+            outs = [(db.u, self.u), (db.f_ext, self.f_ext), (db.N, self.N), (db.info, self.info)]
+
+            def pack(pairs, trimmed_is_dst):
+                n = len(pairs)
+                src, dst = (P * n)(*[a.data_ptr() for a, _ in pairs]), (P * n)(*[b.data_ptr() for _, b in pairs])
+                sp, dp = (Z * n)(*[row_bytes(a) for a, _ in pairs]), (Z * n)(*[row_bytes(b) for _, b in pairs])
+                width = (Z * n)(*[row_bytes(b if trimmed_is_dst else a) for a, b in pairs])
+                return n, src, sp, dst, dp, width
+            tables.append((pack(pairs, True), pack(outs, False)))
+        return tables
+
+    def step(self, record=None):
+        """One pass of the whole path over the batch, asynchronous on the current stream.  `record` (a list):
+        instrumented step - (stage name, start event, end event) of the order and of every bucket's gather,
+        solve and scatter are appended."""
+        torch = self.torch
+        if self.B == 0:
+            return
+
+        def timed(name, call):
+            if record is None:
+                return call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = call()
+            e1.record()
+            record.append((name, e0, e1))
+            return out
+
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            if self.plan is not None and self.plan[0] == "device":
+                self.ordered = timed("order", lambda: joint_order_device(
+                    torch, self.inputs, effort=self.plan[1], out=self.ordered))
+            if self._tables is None:
+                self._tables = self._copy_tables()
+            for bk, (gather, scatter) in zip(self.buckets, self._tables):
+                timed("gather", lambda: _capi.check(self.lib.trs_copy_rows(
+                    *gather, bk["count"], bk["rows"].data_ptr(), 0, stream), "trs_copy_rows (gather)"))
+                timed("solve", bk["dev"].solve)
+                timed("scatter", lambda: _capi.check(self.lib.trs_copy_rows(
+                    *scatter, bk["count"], bk["rows"].data_ptr(), 1, stream), "trs_copy_rows (scatter)"))
+
+    def adopt_launch_hints(self):
+        """After a step: read back the envelope reach the device order reported (B ints, one synchronisation)
+        and tell every bucket whose envelopes all stay within the wave-per-matrix kernels' range to skip the
+        launches that would find no matrix (`DeviceBatch.all_narrow`).  The order is a function of the resident
+        inputs, so the hint holds for every later step; it is safe in any case (a hinted batch is routed narrow
+        on the device regardless).  Returns the number of buckets hinted."""
+        if self.ordered is None or "reach" not in self.ordered:
+            return 0
+        reach = self.ordered["reach"].cpu().numpy()
+        hinted = 0
+        for bk in self.buckets:
+            db = bk["dev"]
+            if bk["renumbered"] and not db.small and db.use_envelope:
+                db.all_narrow = bool(reach[bk["idx"]].max() <= NARROW_MAX_BELOW)
+                hinted += int(db.all_narrow)
+        return hinted
+
+    def result(self):
+        """Synchronise and download the dense results (caller's order and numbering)."""
+        self.torch.cuda.synchronize(self.device)
+        return BatchResult(self.u.cpu().numpy(), self.f_ext.cpu().numpy(), self.N.cpu().numpy(),
+                           self.info.cpu().numpy())
 
 
 @dataclass

@@ -18,6 +18,8 @@ int trs_recover_launch(int, int, int, const double*, const int*, const double*, 
                        double*, double*, const int*, int, hipStream_t);
 int trs_joint_order_launch(int, int, int, const double*, const int*, const unsigned char*, const double*, const int*,
                            const int*, int*, int*, int*, double*, int*, unsigned char*, double*, int, hipStream_t);
+int trs_copy_rows_launch(int, const void* const*, const size_t*, void* const*, const size_t*, const size_t*, int,
+                         const long long*, int, hipStream_t);
 int trs_solve_small_fits(int, int, int);
 int trs_solve_small_launch(int, int, int, int, const double*, const int*, const double*, const double*,
                            const uint8_t*, const double*, const int*, const int*, double*, double*, double*,
@@ -109,6 +111,16 @@ int trs_fitness(int B, int nJ_max, int nM_max, const double* xyz, const int32_t*
     if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
     return trs_fitness_launch(B, nJ_max, nM_max, xyz, conn, A, rho, nJ, nM, u, N, allow_stress,
                               allow_displace, weight, stress_vio, disp_vio, (hipStream_t)stream);
+}
+
+int trs_copy_rows(int nfields, const void* const* src, const size_t* src_pitch, void* const* dst,
+                  const size_t* dst_pitch, const size_t* width, int count, const int64_t* rows, int scatter,
+                  void* stream) {
+    if (nfields < 0 || count < 0) return (int)hipErrorInvalidValue;
+    if (nfields > 0 && count > 0 && (!src || !src_pitch || !dst || !dst_pitch || !width || !rows))
+        return (int)hipErrorInvalidValue;
+    return trs_copy_rows_launch(nfields, src, src_pitch, dst, dst_pitch, width, count,
+                                reinterpret_cast<const long long*>(rows), scatter, (hipStream_t)stream);
 }
 
 int trs_joint_order(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const uint8_t* cbits,

@@ -27,7 +27,7 @@ def test_kernel_source_fingerprint_and_traffic_record():
 def test_byte_and_flop_models():
     n, nJ, nM = 696, 244, 942
     dense = bench.algorithmic_counts(n, nJ, nM)
-    assert dense["potrf_flops"] == n ** 3 / 3 + n ** 2
+    assert dense["potrf_flops"] == n ** 3 / 3 + 2 * n ** 2
     assert dense["assemble_bytes_full_contract"] > dense["assemble_bytes"] > 0
     # the executed tile work of the dense factorisation is at least the textbook count (tiles are padded)
     assert bench.potrf_tile_flops(n) >= dense["potrf_flops"]
@@ -37,6 +37,37 @@ def test_byte_and_flop_models():
     narrow = bench.algorithmic_counts(n, nJ, nM, cend, narrow=True)
     assert narrow["potrf_bytes"] < dense["potrf_bytes"] / 10
     assert bench.potrf_tile_flops(n, ft, last, cend, narrow=True) < bench.potrf_tile_flops(n) / 50
+
+
+def test_vectorised_envelope_counts_equal_the_scalar_models():
+    """`bench.envelope_counts_batch` (whole buckets at once, the cube-batch roofline) against the per-truss
+    `potrf_tile_flops` / `algorithmic_counts` on random consistent narrow envelopes."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    rows_pad = 896
+    nchm = rows_pad // 16
+    B = 40
+    n_free = rng.integers(1, rows_pad + 1, size=B)
+    nJ, nM = rng.integers(10, 300, size=B), rng.integers(30, 2000, size=B)
+    ft, last, cend = np.zeros([B, nchm], int), np.zeros([B, nchm // 4], int), np.zeros([B, nchm], int)
+    for b in range(B):
+        nch = (int(n_free[b]) + 63) // 64 * 4
+        reach = rng.integers(0, 20)
+        first = np.maximum(0, np.arange(nch) - rng.integers(0, reach + 1, size=nch))
+        f = np.minimum.accumulate(first[::-1])[::-1]                      # non-decreasing, ft[q] <= q
+        lastc = [max(q for q in range(nch) if f[q] <= t) for t in range(nch)]
+        ft[b, :nch] = f
+        last[b, :nch // 4] = [lastc[4 * j + 3] for j in range(nch // 4)]
+        cend[b, :nch] = [min(nch, max(lastc[t] + 1, (t | 3) + 1)) for t in range(nch)]
+    got = bench.envelope_counts_batch(n_free, nJ, nM, ft, last, cend, np.ones(B, bool))
+    for b in range(B):
+        n = int(n_free[b])
+        want = bench.algorithmic_counts(n, int(nJ[b]), int(nM[b]), cend[b], narrow=True)
+        assert got["potrf_tile_flops"][b] == bench.potrf_tile_flops(n, ft[b], last[b], cend[b], narrow=True), b
+        assert got["assemble_bytes"][b] == want["assemble_bytes"]
+        assert got["potrf_bytes"][b] == want["potrf_bytes"] + want["potrs_bytes"]   # fused substitution
+        assert got["recover_bytes"][b] == want["recover_bytes"]
+        assert got["tiles"][b] * 2048 == want["slab_tile_bytes"]
 
 
 def test_available_cpus_respects_affinity_and_is_positive():

@@ -92,7 +92,8 @@ def test_bench_launches_its_own_ranks():
     ndev = torch.cuda.device_count()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "256", "--no-cpu-baseline", "--no-pcie", "--cube-batch", "0", "--no-dense-ref"]
+           "--batch", "256", "--no-cpu-baseline", "--no-pcie", "--cube-batch", "384", "--cube-steps", "2",
+           "--no-dense-ref"]
     if ndev < 2:
         cmd.append("--oversubscribe")
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -103,6 +104,12 @@ def test_bench_launches_its_own_ranks():
     assert line["ranks"] == 2 and line["n_gpus"] == min(2, ndev)
     assert line["info_nonzero"] == 0 and line["value"] > 0
     assert line["scaling"] == "weak" and line["config"]["batch_per_gpu"] == 256
+    # the ragged cube-truss leg (BASELINE config 3) runs on every rank too: whole-job rate, roofline fractions
+    cube = line["cube_batch"]
+    assert "error" not in cube, cube
+    assert cube["batch_per_gpu"] == 384 and cube["info_nonzero"] == 0 and cube["value"] > 0
+    assert 0 < cube["roofline"]["hbm"]["frac"] < 1 and 0 < cube["roofline"]["mfma"]["frac"] < 1
+    assert set(cube["stages_ms"]) >= {"order", "gather", "solve", "scatter"}
 
 
 def test_ga_population_sharded_over_two_workers():
