@@ -27,6 +27,7 @@
 //                         of trs_solver.h) and, if asked, the renumbered inputs go to HBM.
 #include "trs_common.h"
 #include "../../include/trs_solver.h"
+#include <type_traits>
 
 namespace {
 
@@ -61,10 +62,10 @@ __host__ __device__ inline OrdLds ord_layout(int nJ_max, int nM_max) {
     l.ids = take(2 * n);                    // u16 [n]    free joints by ascending id
     l.frank = take(2 * (n + 1));            // u16 [n+1]  number of free joints with a smaller id
     l.bins = take(2 * 3 * n);               // u16 [n][3] coordinate bins
-    l.adj = take(2 * e);                    // u16 [2 nM] neighbour lists, by (degree, id)
+    l.adj = take(2 * (e + 4));              // u16 [2 nM + 4] neighbour lists, by (degree, id)
     // the unsorted lists are dead once `adj` is sorted, before any key or candidate exists: they share their space
     const size_t shared_at = p;
-    l.adjU = take(2 * e);                   // u16 [2 nM] ... as filled
+    l.adjU = take(4 * (e + 4));             // u32 [2 nM + 4] ... as filled: (degree of the neighbour << 13) | neighbour
     l.owner = take(2 * e);                  // u16 [2 nM] owner joint of an adjacency entry
     const size_t lists_end = p;
     p = shared_at;
@@ -105,63 +106,90 @@ __device__ __forceinline__ T block_reduce(T v, T* red, F op) {
     return r;
 }
 
+#ifdef TRS_ORDER_STAMPS  // diagnostic build (tools/build_variants.sh): wave-cycles per phase, summed over all waves
+__device__ unsigned long long g_ord_stamps[16];
+struct OrdStamp {
+    unsigned long long t0;
+    __device__ OrdStamp() : t0(__builtin_amdgcn_s_memtime()) {}
+    __device__ void mark(int slot) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_ord_stamps[slot], t - t0);
+        t0 = t;
+    }
+};
+#else
+struct OrdStamp {
+    __device__ void mark(int) {}
+};
+#endif
+
 struct Tables {
     unsigned char* nfr;
     int *deg, *start, *fill, *lvl, *ppos, *queue, *nextq, *order;
-    unsigned short *ids, *frank, *bins, *adj, *adjU, *owner;
+    unsigned short *ids, *frank, *bins, *adj, *owner;
+    unsigned* adjU;
     unsigned long long* keys;
     unsigned short *cand, *best, *newidx, *c0, *c1;
     int *cmin, *ctrl;
     unsigned long long* red;
 };
 
-// One Cuthill-McKee sweep from `root` by the whole work-group.  On return queue[0 .. count) holds the joints of
-// root's component in the order the serial algorithm (reorder.c bfs_levels over (degree, id)-sorted lists)
-// enqueues them; *last_begin = index of the first joint of the deepest level.
-__device__ int cm_sweep(const Tables& t, int nj, int root, int stamp, int* last_begin) {
+// One breadth-first sweep from `root` by the whole work-group, level by level; four lanes share a joint's
+// neighbour list.  On return queue[0 .. count) holds the joints of root's component level by level and
+// *last_begin = index of the first joint of the deepest level.
+//   SORTED   every level in the order the serial Cuthill-McKee (reorder.c bfs_levels over (degree, id)-sorted
+//            lists) enqueues it: by (queue position of the earliest parent, degree, id) - a rank sort per level;
+//   !SORTED  levels as sets only (the two sweeps that look for a pseudo-peripheral root): one barrier per level.
+template <bool SORTED>
+__device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last_begin) {
     const int tid = threadIdx.x;
     int* tail_next = t.ctrl;  // [0]
-    for (int j = tid; j < nj; j += NT) t.ppos[j] = 0x7fffffff;
+    if constexpr (SORTED)
+        for (int j = tid; j < nj; j += NT) t.ppos[j] = 0x7fffffff;
     if (tid == 0) {
         t.queue[0] = root;
         t.lvl[root] = stamp;
         *tail_next = 1;
     }
     __syncthreads();
+    int* found = SORTED ? t.nextq : t.queue;  // a sorted level is copied into the queue by rank
     int head = 0, tail = 1, depth = 0, begin = 0;
+    const int sub = tid & 3;
     while (head < tail) {
         begin = head;
         const int mark = stamp + depth + 1;
-        for (int i = head + tid; i < tail; i += NT) {
+        for (int i = head + (tid >> 2); i < tail; i += NT / 4) {
             const int v = t.queue[i];
-            for (int e = t.start[v]; e < t.start[v + 1]; ++e) {
+            const int e1 = t.start[v + 1];
+            for (int e = t.start[v] + sub; e < e1; e += 4) {
                 const int w = t.adj[e];
                 const int old = atomicMax(&t.lvl[w], mark);
-                if (old < stamp) t.nextq[atomicAdd(tail_next, 1)] = w;       // first to reach w
-                if (old < stamp || old == mark) atomicMin(&t.ppos[w], i);     // w's earliest parent
+                if (old < stamp) found[atomicAdd(tail_next, 1)] = w;                          // first to reach w
+                if (SORTED && (old < stamp || old == mark)) atomicMin(&t.ppos[w], i);          // w's earliest parent
             }
         }
         __syncthreads();
         const int new_tail = *tail_next;
-        const int m = new_tail - tail;
-        if (m > 1) {
-            // the level in queue order: by (position of the earliest parent, degree, id)
-            for (int x = tid; x < m; x += NT) {
-                const int w = t.nextq[tail + x];
-                t.keys[x] = ((unsigned long long)t.ppos[w] << 40) | ((unsigned long long)t.deg[w] << 20) |
-                            (unsigned long long)w;
+        if constexpr (SORTED) {
+            const int m = new_tail - tail;
+            if (m > 1) {
+                for (int x = tid; x < m; x += NT) {
+                    const int w = t.nextq[tail + x];
+                    t.keys[x] = ((unsigned long long)t.ppos[w] << 40) | ((unsigned long long)t.deg[w] << 20) |
+                                (unsigned long long)w;
+                }
+                __syncthreads();
+                for (int x = tid; x < m; x += NT) {
+                    const unsigned long long mine = t.keys[x];
+                    int rank = 0;
+                    for (int y = 0; y < m; ++y) rank += t.keys[y] < mine ? 1 : 0;
+                    t.queue[tail + rank] = (int)(mine & 0xfffffu);
+                }
+            } else if (m == 1 && tid == 0) {
+                t.queue[tail] = t.nextq[tail];
             }
             __syncthreads();
-            for (int x = tid; x < m; x += NT) {
-                const unsigned long long mine = t.keys[x];
-                int rank = 0;
-                for (int y = 0; y < m; ++y) rank += t.keys[y] < mine ? 1 : 0;
-                t.queue[tail + rank] = (int)(mine & 0xfffffu);
-            }
-        } else if (m == 1 && tid == 0) {
-            t.queue[tail] = t.nextq[tail];
         }
-        __syncthreads();
         head = tail;
         tail = new_tail;
         ++depth;
@@ -195,7 +223,13 @@ __device__ unsigned long long price_order(const Tables& t, int nf, Ord ord, unsi
     for (int k = lane; k < nf; k += 64) {
         const int old = ord(k);
         int m = k;  // a joint's own rows may straddle two chunks
-        for (int e = t.start[old]; e < t.start[old + 1]; ++e) m = min(m, (int)newidx[t.adj[e]]);
+        const int e1 = t.start[old + 1];
+        for (int e = t.start[old]; e < e1; e += 4) {  // four independent look-ups per step (slack behind the lists;
+            const int w0 = t.adj[e], w1 = t.adj[e + 1], w2 = t.adj[e + 2], w3 = t.adj[e + 3];   // ids stay < nJ_max)
+            const int i0 = newidx[w0], i1 = e + 1 < e1 ? (int)newidx[w1] : k, i2 = e + 2 < e1 ? (int)newidx[w2] : k,
+                      i3 = e + 3 < e1 ? (int)newidx[w3] : k;
+            m = min(min(m, i0), min(min(i1, i2), i3));
+        }
         const int col = c0[m];
         atomicMin(&cmin[c0[k]], col);
         atomicMin(&cmin[c1[k]], col);
@@ -225,7 +259,7 @@ __device__ unsigned long long price_order(const Tables& t, int nf, Ord ord, unsi
     return cost;
 }
 
-__global__ __launch_bounds__(NT) void trs_joint_order_kernel(
+__global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     const double* __restrict__ xyz, const int* __restrict__ conn, const unsigned char* __restrict__ cbits,
     const double* __restrict__ loads, const int* __restrict__ nJ_arr, const int* __restrict__ nM_arr,
     const int nJ_max, const int nM_max, int* __restrict__ perm_out, int* __restrict__ choice_out,
@@ -250,7 +284,7 @@ __global__ __launch_bounds__(NT) void trs_joint_order_kernel(
     t.frank = reinterpret_cast<unsigned short*>(lds + lay.frank);
     t.bins = reinterpret_cast<unsigned short*>(lds + lay.bins);
     t.adj = reinterpret_cast<unsigned short*>(lds + lay.adj);
-    t.adjU = reinterpret_cast<unsigned short*>(lds + lay.adjU);
+    t.adjU = reinterpret_cast<unsigned*>(lds + lay.adjU);
     t.owner = reinterpret_cast<unsigned short*>(lds + lay.owner);
     t.keys = reinterpret_cast<unsigned long long*>(lds + lay.keys);
     t.cand = reinterpret_cast<unsigned short*>(lds + lay.cand);
@@ -267,28 +301,57 @@ __global__ __launch_bounds__(NT) void trs_joint_order_kernel(
     const double* X = xyz + (size_t)b * 3 * nJ_max;
     int* P = perm_out + (size_t)b * nJ_max;
 
-    // ---- phase A.0: free DOFs per joint, degrees, member lengths -------------------------------------------
+    OrdStamp st;
+    // ---- phase A.0: free DOFs per joint, degrees, member lengths, coordinate bins ---------------------------
+    // Every global READ of the search happens here, coalesced and issued together: the coordinates go to an LDS
+    // stage (in the space the adjacency fill will take over later), the members' end joints are kept in
+    // registers for the two passes that need them.
+    double* Xs = reinterpret_cast<double*>(lds + lay.adjU);  // [3 nJ_max] staged coordinates (dead before the fill)
+    constexpr int MR = 8;
+    int2 cr[MR];
+    const int2* CNI = reinterpret_cast<const int2*>(CN);
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const int m = tid + r * NT;
+        cr[r] = m < nm ? CNI[m] : int2{0, 0};
+    }
+    auto for_members = [&](auto&& body) {  // body(a, c) for every member of this thread
+#pragma unroll
+        for (int r = 0; r < MR; ++r)
+            if (tid + r * NT < nm) body(cr[r].x, cr[r].y);
+        for (int m = tid + MR * NT; m < nm; m += NT) {
+            const int2 c = CNI[m];
+            body(c.x, c.y);
+        }
+    };
+    double lo[3] = {X[0], X[1], X[2]}, hi[3] = {X[0], X[1], X[2]};
     for (int j = tid; j < nj; j += NT) {
         const int cb = CB[j];
         t.nfr[j] = (unsigned char)(3 - ((cb & 1) + ((cb >> 1) & 1) + ((cb >> 2) & 1)));
         t.deg[j] = 0;
         t.lvl[j] = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double x = X[3 * j + a];
+            Xs[3 * j + a] = x;
+            lo[a] = x < lo[a] ? x : lo[a];
+            hi[a] = x > hi[a] ? x : hi[a];
+        }
     }
     __syncthreads();
     double len2 = 0.0;
     int nlen = 0;
-    for (int m = tid; m < nm; m += NT) {
-        const int a = CN[2 * m], c = CN[2 * m + 1];
-        const double dx = X[3 * c] - X[3 * a], dy = X[3 * c + 1] - X[3 * a + 1], dz = X[3 * c + 2] - X[3 * a + 2];
+    for_members([&](int a, int c) {
+        const double dx = Xs[3 * c] - Xs[3 * a], dy = Xs[3 * c + 1] - Xs[3 * a + 1], dz = Xs[3 * c + 2] - Xs[3 * a + 2];
         const double l2 = dx * dx + dy * dy + dz * dz;
         if (l2 > 0.0) {
             len2 += l2;
             ++nlen;
         }
-        if (a == c || t.nfr[a] == 0 || t.nfr[c] == 0) continue;  // couples nothing in K_ff
+        if (a == c || t.nfr[a] == 0 || t.nfr[c] == 0) return;  // couples nothing in K_ff
         atomicAdd(&t.deg[a], 1);
         atomicAdd(&t.deg[c], 1);
-    }
+    });
     __syncthreads();
     // scans by wave 0: adjacency offsets, and the free joints by ascending id
     if (tid < 64) {
@@ -314,32 +377,125 @@ __global__ __launch_bounds__(NT) void trs_joint_order_kernel(
     for (int j = tid; j < nj; j += NT) t.fill[j] = 0;
     __syncthreads();
     const int nf = t.frank[nj];  // joints that keep a free DOF: they come first in every candidate
-    for (int m = tid; m < nm; m += NT) {
-        const int a = CN[2 * m], c = CN[2 * m + 1];
-        if (a == c || t.nfr[a] == 0 || t.nfr[c] == 0) continue;
-        const int ea = t.start[a] + atomicAdd(&t.fill[a], 1), ec = t.start[c] + atomicAdd(&t.fill[c], 1);
-        t.adjU[ea] = (unsigned short)c;
-        t.owner[ea] = (unsigned short)a;
-        t.adjU[ec] = (unsigned short)a;
-        t.owner[ec] = (unsigned short)c;
+    // coordinate bins of the sweeps (while the staged coordinates are still there)
+    // member lengths and the bounding box in ONE work-group reduction (eight doubles per wave through LDS)
+    {
+        double cnt = (double)nlen;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            len2 += __shfl_xor(len2, off);
+            cnt += __shfl_xor(cnt, off);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double l = __shfl_xor(lo[a], off), u = __shfl_xor(hi[a], off);
+                lo[a] = l < lo[a] ? l : lo[a];
+                hi[a] = u > hi[a] ? u : hi[a];
+            }
+        }
+        double* red = reinterpret_cast<double*>(t.red);  // [NWAVE][8]
+        __syncthreads();
+        if (lane == 0) {
+            red[8 * wave] = len2;
+            red[8 * wave + 1] = cnt;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                red[8 * wave + 2 + a] = lo[a];
+                red[8 * wave + 5 + a] = hi[a];
+            }
+        }
+        __syncthreads();
+        len2 = red[0];
+        cnt = red[1];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = red[2 + a];
+            hi[a] = red[5 + a];
+        }
+        for (int w = 1; w < NWAVE; ++w) {  // fixed order: the same sum on every thread
+            len2 += red[8 * w];
+            cnt += red[8 * w + 1];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = red[8 * w + 2 + a] < lo[a] ? red[8 * w + 2 + a] : lo[a];
+                hi[a] = red[8 * w + 5 + a] > hi[a] ? red[8 * w + 5 + a] : hi[a];
+            }
+        }
+        nlen = (int)cnt;
     }
+    // a quarter of the RMS member length, rounded to single precision: the sum above runs in another order than
+    // the host's, and the bins must not depend on its last bits
+    const double h = nlen ? (double)(float)(0.25 * sqrt(len2 / (double)nlen)) : 0.0;
+    const bool sweeps = h > 0.0 && h < 1e300 && nf > 1 && effort >= 1;
+    const int bin_cap = 4 * nJ_max + 64;
+    int nb[3] = {1, 1, 1};
+    if (sweeps) {
+        int top[3] = {1, 1, 1};
+        double ha[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            ha[a] = h;
+            if (!((hi[a] - lo[a]) / ha[a] < (double)(bin_cap - 2))) ha[a] = (hi[a] - lo[a]) / (double)(bin_cap - 2);
+        }
+        for (int j = tid; j < nj; j += NT)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double q = ha[a] > 0.0 ? (Xs[3 * j + a] - lo[a]) / ha[a] + 0.5 : 0.0;
+                if (!(q >= 0.0)) q = 0.0;  // NaN coordinates: any bin
+                if (q > (double)(bin_cap - 1)) q = (double)(bin_cap - 1);
+                t.bins[3 * j + a] = (unsigned short)(int)q;
+                top[a] = max(top[a], (int)q + 1);
+            }
+        // nb[a] = bins in use along axis a: the three maxima in one pass
+        int t0 = top[0], t1 = top[1], t2 = top[2];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            t0 = max(t0, __shfl_xor(t0, off));
+            t1 = max(t1, __shfl_xor(t1, off));
+            t2 = max(t2, __shfl_xor(t2, off));
+        }
+        int* redi = reinterpret_cast<int*>(t.red);
+        __syncthreads();
+        if (lane == 0) {
+            redi[4 * wave] = t0;
+            redi[4 * wave + 1] = t1;
+            redi[4 * wave + 2] = t2;
+        }
+        __syncthreads();
+        for (int w = 0; w < NWAVE; ++w) {
+            nb[0] = max(nb[0], redi[4 * w]);
+            nb[1] = max(nb[1], redi[4 * w + 1]);
+            nb[2] = max(nb[2], redi[4 * w + 2]);
+        }
+    }
+    __syncthreads();  // the staged coordinates are dead: the adjacency fill takes their space
+    for_members([&](int a, int c) {
+        if (a == c || t.nfr[a] == 0 || t.nfr[c] == 0) return;
+        const int ea = t.start[a] + atomicAdd(&t.fill[a], 1), ec = t.start[c] + atomicAdd(&t.fill[c], 1);
+        t.adjU[ea] = ((unsigned)t.deg[c] << ID_BITS) | (unsigned)c;
+        t.owner[ea] = (unsigned short)a;
+        t.adjU[ec] = ((unsigned)t.deg[a] << ID_BITS) | (unsigned)a;
+        t.owner[ec] = (unsigned short)c;
+    });
     __syncthreads();
     // neighbour lists by ascending (degree, id): rank of an entry inside its list (equal keys = parallel
     // members: interchangeable, ordered by position)
     const int nadj = t.start[nj];
     for (int e = tid; e < nadj; e += NT) {
-        const int a = t.owner[e], s = t.start[a], d = t.deg[a], other = t.adjU[e];
-        const unsigned key = ((unsigned)t.deg[other] << ID_BITS) | (unsigned)other;
+        const int a = t.owner[e], s = t.start[a], d = t.deg[a];
+        const unsigned key = t.adjU[e];
         int rank = 0;
-        for (int i = 0; i < d; ++i) {
-            const int o = t.adjU[s + i];
-            const unsigned k2 = ((unsigned)t.deg[o] << ID_BITS) | (unsigned)o;
-            rank += (k2 < key || (k2 == key && s + i < e)) ? 1 : 0;
+        for (int i = 0; i < d; i += 4) {  // four independent reads per step (the list area has four entries of slack)
+            const unsigned k0 = t.adjU[s + i], k1 = t.adjU[s + i + 1], k2 = t.adjU[s + i + 2], k3 = t.adjU[s + i + 3];
+            rank += (k0 < key || (k0 == key && s + i < e)) ? 1 : 0;
+            rank += (i + 1 < d && (k1 < key || (k1 == key && s + i + 1 < e))) ? 1 : 0;
+            rank += (i + 2 < d && (k2 < key || (k2 == key && s + i + 2 < e))) ? 1 : 0;
+            rank += (i + 3 < d && (k3 < key || (k3 == key && s + i + 3 < e))) ? 1 : 0;
         }
-        t.adj[s + rank] = (unsigned short)other;
+        t.adj[s + rank] = (unsigned short)(key & ((1u << ID_BITS) - 1));
     }
     __syncthreads();
 
+    st.mark(0);
     // ---- phase A.1: Cuthill-McKee, component by component ---------------------------------------------------
     int n_order = 0, stamp = 1;
     for (;;) {
@@ -349,17 +505,19 @@ __global__ __launch_bounds__(NT) void trs_joint_order_kernel(
         best = block_reduce(best, reinterpret_cast<unsigned*>(t.red), [](unsigned x, unsigned y) { return min(x, y); });
         if (best == 0xffffffffu) break;
         int root = (int)(best & ((1u << ID_BITS) - 1)), begin = 0, count = 0;
-        for (int sweep = 0; sweep < 3; ++sweep) {
-            stamp += nj + 2;
-            count = cm_sweep(t, nj, root, stamp, &begin);
-            if (sweep < 2) {  // restart from the first minimum-degree joint of the deepest level
-                unsigned long long pick = NO_COST;
-                for (int i = begin + tid; i < count; i += NT)
-                    pick = min(pick, ((unsigned long long)t.deg[t.queue[i]] << 32) | (unsigned long long)i);
-                pick = block_reduce(pick, t.red, [](unsigned long long x, unsigned long long y) { return min(x, y); });
-                root = t.queue[(int)(pick & 0xffffffffull)];
+        for (int sweep = 0; sweep < 2; ++sweep) {  // pseudo-peripheral root: restart from the minimum-(degree, id)
+            stamp += nj + 2;                       // joint of the deepest level, twice
+            count = bfs_sweep<false>(t, nj, root, stamp, &begin);
+            unsigned pick = 0xffffffffu;
+            for (int i = begin + tid; i < count; i += NT) {
+                const int q = t.queue[i];
+                pick = min(pick, ((unsigned)t.deg[q] << ID_BITS) | (unsigned)q);
             }
+            pick = block_reduce(pick, reinterpret_cast<unsigned*>(t.red), [](unsigned x, unsigned y) { return min(x, y); });
+            root = (int)(pick & ((1u << ID_BITS) - 1));
         }
+        stamp += nj + 2;
+        count = bfs_sweep<true>(t, nj, root, stamp, &begin);  // neighbour lists are (degree, id)-sorted: Cuthill-McKee
         __syncthreads();
         for (int i = tid; i < count; i += NT) {
             const int v = t.queue[i];
@@ -371,49 +529,25 @@ __global__ __launch_bounds__(NT) void trs_joint_order_kernel(
     }
     // (n_order == nf: every free joint belongs to a component)
 
-    // ---- phase A.2: coordinate bins of the sweeps -----------------------------------------------------------
-    len2 = block_reduce(len2, reinterpret_cast<double*>(t.red), [](double x, double y) { return x + y; });
-    nlen = block_reduce(nlen, reinterpret_cast<int*>(t.red), [](int x, int y) { return x + y; });
-    // a quarter of the RMS member length, rounded to single precision: the sum above runs in another order than
-    // the host's, and the bins must not depend on its last bits
-    const double h = nlen ? (double)(float)(0.25 * sqrt(len2 / (double)nlen)) : 0.0;
-    const bool sweeps = h > 0.0 && h < 1e300 && nf > 1 && effort >= 1;
-    const int bin_cap = 4 * nJ_max + 64;
-    int nb[3] = {1, 1, 1};
-    if (sweeps) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            double lo = X[a], hi = X[a];
-            for (int j = tid; j < nj; j += NT) {
-                const double x = X[3 * j + a];
-                lo = x < lo ? x : lo;
-                hi = x > hi ? x : hi;
-            }
-            lo = block_reduce(lo, reinterpret_cast<double*>(t.red), [](double x, double y) { return y < x ? y : x; });
-            hi = block_reduce(hi, reinterpret_cast<double*>(t.red), [](double x, double y) { return y > x ? y : x; });
-            double ha = h;
-            if (!((hi - lo) / ha < (double)(bin_cap - 2))) ha = (hi - lo) / (double)(bin_cap - 2);
-            int top = 1;
-            for (int j = tid; j < nj; j += NT) {
-                double q = ha > 0.0 ? (X[3 * j + a] - lo) / ha + 0.5 : 0.0;
-                if (!(q >= 0.0)) q = 0.0;  // NaN coordinates: any bin
-                if (q > (double)(bin_cap - 1)) q = (double)(bin_cap - 1);
-                t.bins[3 * j + a] = (unsigned short)(int)q;
-                top = max(top, (int)q + 1);
-            }
-            nb[a] = block_reduce(top, reinterpret_cast<int*>(t.red), [](int x, int y) { return max(x, y); });
-        }
-    }
+    st.mark(1);
     __syncthreads();
 
+    st.mark(2);
     // ---- phase B: the candidates, four at a time (one per wave, no work-group barrier) ----------------------
-    const int axes[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    // axis orders 0..5: xyz xzy yxz yzx zxy zyx (first axis slowest), as bit fields 2 bits per axis
+    auto axis_of = [](int ax, int pos) { return (int)((0x192261624ull >> (6 * ax + 2 * pos)) & 3ull); };
+    auto nb_of = [&](int a) { return a == 0 ? nb[0] : (a == 1 ? nb[1] : nb[2]); };
     int first_ax = 0;  // the sweep along the longest extent is evaluated first (evaluation order breaks ties)
     for (int ax = 1; ax < 6; ++ax)
-        if (nb[axes[ax][0]] > nb[axes[first_ax][0]] ||
-            (nb[axes[ax][0]] == nb[axes[first_ax][0]] && nb[axes[ax][1]] > nb[axes[first_ax][1]]))
+        if (nb_of(axis_of(ax, 0)) > nb_of(axis_of(first_ax, 0)) ||
+            (nb_of(axis_of(ax, 0)) == nb_of(axis_of(first_ax, 0)) && nb_of(axis_of(ax, 1)) > nb_of(axis_of(first_ax, 1))))
             first_ax = ax;
     const int n_sweep = sweeps ? (effort >= 2 ? 6 : 1) : 0;
+    auto bits_for = [](int count) { int b = 1; while ((1 << b) < count) ++b; return b; };  // values 0 .. count-1
+    const int bits0 = bits_for(nb[0]), bits1 = bits_for(nb[1]), bits2 = bits_for(nb[2]);
+    auto bits_of = [&](int a) { return a == 0 ? bits0 : (a == 1 ? bits1 : bits2); };  // (no indexed private array)
+    const int xbits = bits_for(nf > 1 ? nf : 2);
+    const int key_bits = bits0 + bits1 + bits2 + xbits;
     unsigned short* cand = t.cand + (size_t)wave * nJ_max;
     unsigned short* wbest = t.best + (size_t)wave * nJ_max;
     unsigned short* newidx = t.newidx + (size_t)wave * nJ_max;
@@ -443,33 +577,78 @@ __global__ __launch_bounds__(NT) void trs_joint_order_kernel(
         }
         for (int i = wave; i < n_sweep; i += NWAVE) {
             const int ax = i == 0 ? first_ax : (i <= first_ax ? i - 1 : i);
-            const int a0 = axes[ax][0], a1 = axes[ax][1], a2 = axes[ax][2];
-            // lexicographic by (bin a0, bin a1, bin a2, id): one rank sort of 64-bit keys
-            for (int x = lane; x < nf; x += 64) {
-                const int j = t.ids[x];
-                keys[x] = ((unsigned long long)t.bins[3 * j + a0] << (32 + ID_BITS)) |
-                          ((unsigned long long)t.bins[3 * j + a1] << (16 + ID_BITS)) |
-                          ((unsigned long long)t.bins[3 * j + a2] << ID_BITS) | (unsigned long long)j;
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (int x = lane; x < nf; x += 64) {
-                const unsigned long long mine = keys[x];
-                int rank = 0;
-                int y = 0;
-                for (; y + 1 < nf; y += 2) {  // two keys per LDS read (broadcast: every lane reads the same pair)
-                    const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(keys + y);
-                    rank += (kk.x < mine ? 1 : 0) + (kk.y < mine ? 1 : 0);
+            const int a0 = axis_of(ax, 0), a1 = axis_of(ax, 1), a2 = axis_of(ax, 2);
+            // lexicographic by (bin a0, bin a1, bin a2, id): ONE rank sort.  x = position in the ascending id
+            // list, so (bins, x) orders like (bins, id).  32-bit keys when the three bin fields and x fit (any
+            // lattice-like truss: a few dozen bins per axis) - four keys per LDS read, one compare each -,
+            // 64-bit keys otherwise.
+            if (key_bits <= 32) {
+                unsigned* k32 = reinterpret_cast<unsigned*>(keys);
+                for (int x = lane; x < nf; x += 64) {
+                    const int j = t.ids[x];
+                    k32[x] = ((((unsigned)t.bins[3 * j + a0] << bits_of(a1) | (unsigned)t.bins[3 * j + a1]) << bits_of(a2) |
+                               (unsigned)t.bins[3 * j + a2]) << xbits) | (unsigned)x;
                 }
-                if (y < nf) rank += keys[y] < mine ? 1 : 0;
-                cand[rank] = (unsigned short)(mine & ((1ull << ID_BITS) - 1));
+                for (int x = nf + lane; x < ((nf + 3) & ~3); x += 64) k32[x] = 0xffffffffu;  // pad the last quad
+                __builtin_amdgcn_wave_barrier();
+                // a lane ranks up to R of its keys in ONE pass over the list: a quad of keys per LDS read is
+                // compared with all of them (the reads, not the compares, are what a rank sort waits for)
+                auto rank_pass = [&](auto rc, int x0) {
+                    constexpr int R = decltype(rc)::value;
+                    unsigned mine[R];
+                    int rank[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int x = x0 + lane + 64 * r;
+                        mine[r] = x < nf ? k32[x] : 0u;
+                        rank[r] = 0;
+                    }
+#pragma unroll 2
+                    for (int y = 0; y < nf; y += 4) {  // (broadcast reads: every lane the same four keys)
+                        const uint4 kk = *reinterpret_cast<const uint4*>(k32 + y);
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            rank[r] += (kk.x < mine[r] ? 1 : 0) + (kk.y < mine[r] ? 1 : 0) + (kk.z < mine[r] ? 1 : 0) +
+                                       (kk.w < mine[r] ? 1 : 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (x0 + lane + 64 * r < nf) cand[rank[r]] = t.ids[mine[r] & ((1u << xbits) - 1)];
+                };
+                int x0 = 0;
+                for (; nf - x0 > 128; x0 += 256) rank_pass(std::integral_constant<int, 4>{}, x0);
+                if (nf - x0 > 64) rank_pass(std::integral_constant<int, 2>{}, x0);
+                else if (nf - x0 > 0) rank_pass(std::integral_constant<int, 1>{}, x0);
+            } else {
+                for (int x = lane; x < nf; x += 64) {
+                    const int j = t.ids[x];
+                    keys[x] = ((unsigned long long)t.bins[3 * j + a0] << (32 + ID_BITS)) |
+                              ((unsigned long long)t.bins[3 * j + a1] << (16 + ID_BITS)) |
+                              ((unsigned long long)t.bins[3 * j + a2] << ID_BITS) | (unsigned long long)j;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int x = lane; x < nf; x += 64) {
+                    const unsigned long long mine = keys[x];
+                    int rank = 0;
+                    int y = 0;
+                    for (; y + 1 < nf; y += 2) {  // two keys per LDS read
+                        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(keys + y);
+                        rank += (kk.x < mine ? 1 : 0) + (kk.y < mine ? 1 : 0);
+                    }
+                    if (y < nf) rank += keys[y] < mine ? 1 : 0;
+                    cand[rank] = (unsigned short)(mine & ((1ull << ID_BITS) - 1));
+                }
             }
             __builtin_amdgcn_wave_barrier();
+            st.mark(3);
             auto fwd = [&](int k) { return (int)cand[k]; };
             auto rev = [&](int k) { return (int)cand[nf - 1 - k]; };
             consider(price_order(t, nf, fwd, newidx, c0, c1, cmin, lane, &ndof), 2 + 2 * i, 2 + 2 * ax, fwd);
             consider(price_order(t, nf, rev, newidx, c0, c1, cmin, lane, &ndof), 3 + 2 * i, 3 + 2 * ax, rev);
+            st.mark(4);
         }
     }
+    st.mark(5);
     // ---- phase C: the winner ---------------------------------------------------------------------------------
     if (lane == 0) {
         t.red[wave] = my_cost;
@@ -477,28 +656,31 @@ __global__ __launch_bounds__(NT) void trs_joint_order_kernel(
         t.ctrl[8 + wave] = my_choice;
     }
     __syncthreads();
+    st.mark(6);
     int win = 0;
     for (int w = 1; w < NWAVE; ++w)
         if (t.red[w] < t.red[win] || (t.red[w] == t.red[win] && t.ctrl[4 + w] < t.ctrl[4 + win])) win = w;
     const unsigned short* wperm = t.best + (size_t)win * nJ_max;
     int* inverse = t.fill;
+    int* fullperm = t.queue;  // [nJ_max] the whole permutation (the sweeps' queue is dead)
     for (int k = tid; k < nJ_max; k += NT) {
         if (k < nf) {
             const int old = wperm[k];
-            P[k] = old;
+            fullperm[k] = old;
             inverse[old] = k;
         } else if (k >= nj) {
-            P[k] = k;  // identity on the padding
+            fullperm[k] = k;  // identity on the padding
         }
     }
     for (int j = tid; j < nj; j += NT)
         if (t.nfr[j] == 0) {  // fully constrained joints follow the free ones in their given order
             const int k = nf + j - (int)t.frank[j];
-            P[k] = j;
+            fullperm[k] = j;
             inverse[j] = k;
         }
     if (tid == 0 && choice_out != nullptr) choice_out[b] = nf > 0 ? t.ctrl[8 + win] : 0;
     __syncthreads();
+    for (int k = tid; k < nJ_max; k += NT) P[k] = fullperm[k];
     // envelope reach of the chosen order below the 64 x 64 diagonal blocks (reorder.c trs_envelope_reach; what
     // trs_assemble will derive): by wave 0 on its scratch
     if (reach_out != nullptr && wave == 0) {
@@ -536,6 +718,7 @@ __global__ __launch_bounds__(NT) void trs_joint_order_kernel(
         }
         if (lane == 0) reach_out[b] = widest;
     }
+    st.mark(7);
     // the renumbered inputs (reorder.c trs_apply_joint_order): joint k := old joint perm[k], members keep their
     // order with renumbered ends, padding members stay (0, 0)
     if (xyz_out != nullptr) {
@@ -543,19 +726,41 @@ __global__ __launch_bounds__(NT) void trs_joint_order_kernel(
         double* XO = xyz_out + (size_t)b * 3 * nJ_max;
         double* FO = loads_out + (size_t)b * 3 * nJ_max;
         unsigned char* CO = cbits_out + (size_t)b * nJ_max;
-        for (int x = tid; x < 3 * nJ_max; x += NT) {
-            const int k = x / 3, a = x - 3 * k;
-            const int old = k < nj ? P[k] : k;   // (P was written by this work-group: visible after the barrier)
-            XO[x] = X[3 * old + a];
-            FO[x] = F[3 * old + a];
+        for (int j = tid; j < nJ_max; j += NT) {  // a joint per thread, coalesced reads: old joint j -> row inverse[j]
+            const int k = j < nj ? inverse[j] : j;
+            const double x0 = X[3 * j], x1 = X[3 * j + 1], x2 = X[3 * j + 2];
+            const double f0 = F[3 * j], f1 = F[3 * j + 1], f2 = F[3 * j + 2];
+            const unsigned char cb = CB[j];
+            XO[3 * k] = x0; XO[3 * k + 1] = x1; XO[3 * k + 2] = x2;
+            FO[3 * k] = f0; FO[3 * k + 1] = f1; FO[3 * k + 2] = f2;
+            CO[k] = cb;
         }
-        for (int k = tid; k < nJ_max; k += NT) CO[k] = CB[k < nj ? P[k] : k];
-        int* CNO = conn_out + (size_t)b * 2 * nM_max;
-        for (int x = tid; x < 2 * nM_max; x += NT) CNO[x] = (x >> 1) < nm ? inverse[CN[x]] : 0;
+        int2* CNO = reinterpret_cast<int2*>(conn_out + (size_t)b * 2 * nM_max);
+        for (int m = tid; m < nM_max; m += NT) {
+            int2 c = {0, 0};
+            if (m < nm) {
+                c = CNI[m];
+                c.x = inverse[c.x];
+                c.y = inverse[c.y];
+            }
+            CNO[m] = c;
+        }
     }
+    st.mark(8);
 }
 
 }  // namespace
+
+#ifdef TRS_ORDER_STAMPS
+extern "C" int trs_order_debug_stamps(unsigned long long* host_out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ord_stamps), sizeof(g_ord_stamps));
+    if (reset) {
+        unsigned long long zero[16] = {0};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ord_stamps), zero, sizeof(zero));
+    }
+    return rc;
+}
+#endif
 
 extern "C" int trs_joint_order_fits(int nJ_max, int nM_max) {
     if (nJ_max <= 0 || nM_max < 0 || nJ_max >= (1 << ID_BITS) || nM_max >= 65536) return 0;

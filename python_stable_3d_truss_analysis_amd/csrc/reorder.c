@@ -6,7 +6,8 @@
  *
  * The graph has one node per joint that keeps at least one free DOF and one edge per member between
  * two such joints (a member to a fully pinned joint couples nothing in K_ff).  Per connected
- * component: pseudo-peripheral start node (two BFS sweeps from a minimum-degree node), Cuthill-McKee
+ * component: pseudo-peripheral start node (two BFS sweeps from a minimum-degree node, each restarting from
+ * the minimum-(degree, id) joint of the deepest level), Cuthill-McKee
  * breadth-first numbering with neighbours taken by ascending degree, the whole order reversed.
  * Fully constrained joints are numbered last.  perm[b][k] = old id of the joint that becomes joint k.
  */
@@ -118,9 +119,14 @@ static void rcm_one(rcm_scratch_t *sc, int nJ, int nM, const int32_t *conn, cons
         for (int sweep = 0; sweep < 2; ++sweep) {
             stamp += nJ + 2;
             bfs_levels(sc, root, stamp, &begin, &count);
+            /* a minimum-degree joint of the deepest level, the smallest id among equals: a rule that does not
+             * depend on the order INSIDE the level, so the device version (order.hip) needs no sorted queue for
+             * these two sweeps */
             int best = sc->queue[begin];
-            for (int i = begin; i < count; ++i)
-                if (sc->deg[sc->queue[i]] < sc->deg[best]) best = sc->queue[i];
+            for (int i = begin; i < count; ++i) {
+                const int q = sc->queue[i];
+                if (sc->deg[q] < sc->deg[best] || (sc->deg[q] == sc->deg[best] && q < best)) best = q;
+            }
             root = best;
         }
         stamp += nJ + 2;
