@@ -315,6 +315,35 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world)
             "note": "inputs resident in generator order; one launch pipeline per size bucket on a shared workspace"}
 
 
+def dataset_leg(args, device, torch, barrier, reduce_max, rank, world):
+    """BASELINE config 5: this rank's share of a cube-truss dataset streamed through `data.dataset_chunks` -
+    native generation on the host (prefetched), joint order + TWO solves per sample (actual sections and the
+    fixed prior, reference data.py:107-114) + the HeteroData feature kernel on the device, float32 tensors left
+    resident per chunk.  `--dataset-samples` per GPU; rate = samples of all ranks / max rank time."""
+    from python_stable_3d_truss_analysis_amd import MemberType, TaskType
+    from python_stable_3d_truss_analysis_amd import data as gdata
+    chunk = min(16384, args.dataset_samples)
+    total = args.dataset_samples * world
+    kw = dict(seed=11, numCubeRange=(8, 190), gridRange=(6, 6, 6), fixedMemberType=MemberType(1., 1e7, 0.1),
+              taskType=TaskType.REGRESSION, device=device, forceScale=1e3, displaceScale=0.1, positionScale=100.)
+    for _ in gdata.dataset_chunks(min(chunk, 2048), rank=0, world=1, chunk=min(chunk, 2048), **kw):   # warm
+        pass
+    barrier()
+    t0 = time.perf_counter()
+    seen = bad = 0
+    for first, packed, tensors in gdata.dataset_chunks(total, rank=rank, world=world, chunk=chunk, **kw):
+        seen += packed.B
+        bad += int(tensors["info"].ne(0).sum().item())
+    barrier()
+    elapsed = reduce_max(time.perf_counter() - t0)
+    if rank != 0:
+        return None
+    return {"value": total / elapsed, "unit": "samples/s", "samples_per_gpu": args.dataset_samples, "chunk": chunk,
+            "seconds": elapsed, "solves_per_sample": 2, "info_nonzero_rank0": bad, "rank0_samples": seen,
+            "note": "data.dataset_chunks: generation (host, prefetched) + joint order, two solves and graph features "
+                    "(device) per sample, tensors left on the device; mixed cube trusses of 8..190 cubes"}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) with
     torch.distributed.run as a CHILD process and pass its output and exit code through.  This process
@@ -345,6 +374,8 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational PCIe-inclusive pass")
     ap.add_argument("--cube-batch", type=int, default=65536,
                     help="trusses per GPU of the mixed cube-truss leg, BASELINE config 3 (0 = skip)")
+    ap.add_argument("--dataset-samples", type=int, default=32768,
+                    help="samples per GPU of the dataset leg, BASELINE config 5 (0 = skip)")
     ap.add_argument("--cube-steps", type=int, default=5)
     ap.add_argument("--cube-warmup", type=int, default=1)
     ap.add_argument("--dense", action="store_true",
@@ -540,6 +571,14 @@ def main():
             cube = {"error": repr(exc)}
             if distributed:
                 raise
+    dataset = None
+    if args.dataset_samples > 0:
+        try:
+            dataset = dataset_leg(args, device, torch, barrier, reduce_max, rank, world)
+        except Exception as exc:
+            dataset = {"error": repr(exc)}
+            if distributed:
+                raise
     if rank == 0:
         total_trusses = world * args.batch * args.steps
         potrf_s = potrf_ms_timed * 1e-3   # the dominant kernel, measured inside the timed region
@@ -665,6 +704,8 @@ def main():
             line["pcie_inclusive"] = pcie
         if cube is not None:
             line["cube_batch"] = cube
+        if dataset is not None:
+            line["dataset"] = dataset
         if given is not None:
             line["given_joint_order"] = given
         if dense_ms is not None:

@@ -93,7 +93,7 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "256", "--no-cpu-baseline", "--no-pcie", "--cube-batch", "384", "--cube-steps", "2",
-           "--no-dense-ref"]
+           "--dataset-samples", "512", "--no-dense-ref"]
     if ndev < 2:
         cmd.append("--oversubscribe")
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -110,6 +110,8 @@ def test_bench_launches_its_own_ranks():
     assert cube["batch_per_gpu"] == 384 and cube["info_nonzero"] == 0 and cube["value"] > 0
     assert 0 < cube["roofline"]["hbm"]["frac"] < 1 and 0 < cube["roofline"]["mfma"]["frac"] < 1
     assert set(cube["stages_ms"]) >= {"order", "gather", "solve", "scatter"}
+    assert line["dataset"]["value"] > 0 and line["dataset"]["info_nonzero_rank0"] == 0
+    assert line["dataset"]["rank0_samples"] == 512
 
 
 def test_ga_population_sharded_over_two_workers():
