@@ -856,18 +856,21 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30, granularity=64):
 class RaggedSolver:
     """A RAGGED batch (trusses of very different sizes: the reference's `GenerateRandomCubeTrusses` loop,
     `generate.py:342-374`, BASELINE config 3) resident on one device in the caller's order and numbering, set
-    up once and solved any number of times with everything on the GPU:
+    up once and solved any number of times with everything on the GPU.  Per size bucket (`size_buckets`):
 
-        joint order (`trs_joint_order`: found, applied and priced on the device)
-        per size bucket:  gather the bucket's rows, trimmed (`trs_copy_rows`)  ->  `trs_solve`
-                          ->  scatter u / f_ext / N / info back to the caller's rows (`trs_copy_rows`)
+        gather the bucket's rows, trimmed to its own maxima (`trs_copy_rows`)
+        -> joint order of the bucket (`trs_joint_order`: found, applied and priced on the device; its LDS tables
+           are sized by the BUCKET's maxima, so buckets of small trusses run more work-groups per CU)
+        -> `trs_solve`
+        -> scatter u / f_ext / N / info back to the caller's rows (`trs_copy_rows`)
 
-    The buckets (`size_buckets`) share ONE workspace (slab, reduced vectors, assembly tables, envelope
-    metadata) sized for the largest of them; their launches follow each other on the current stream.  Results
-    stay resident (`u`, `f_ext`, `N`, `info`: full-batch tensors in the caller's numbering) until `result()`
-    downloads them.  `reorder` as `order_plan`; a host-side plan is carried out once, at set-up."""
+    The buckets share ONE workspace (slab, reduced vectors, assembly tables, envelope metadata, the gathered
+    un-ordered inputs) sized for the largest of them; their launches follow each other on the current stream.
+    Results stay resident (`u`, `f_ext`, `N`, `info`: full-batch tensors in the caller's numbering) until
+    `result()` downloads them.  `reorder` as `order_plan`; a host-side plan is carried out once, at set-up."""
 
     GATHER = ("xyz", "conn", "E", "A", "cbits", "loads", "nJ", "nM")
+    JOINT_ORDERED = ("xyz", "conn", "cbits", "loads")
 
     def __init__(self, packed: PackedBatch, device=None, reorder=True, max_slab_bytes=48 << 30, granularity=64,
                  options=None):
@@ -879,11 +882,11 @@ class RaggedSolver:
         self.inputs = {f: up(getattr(packed, f)) for f in self.GATHER}
         plan = order_plan(reorder, nJ_max, nM_max) if B else None
         self.plan = plan
-        self.ordered = None        # renumbered xyz / conn / cbits / loads + perm (+ reach), device tensors
+        self.ordered = None        # host plan: renumbered xyz / conn / cbits / loads + perm of the FULL batch
         if plan is not None and plan[0] != "device":
             perm = joint_order(packed, plan[1])
             renum = permute_joints(packed, perm)
-            self.ordered = {k: up(getattr(renum, k)) for k in ("xyz", "conn", "cbits", "loads")}
+            self.ordered = {k: up(getattr(renum, k)) for k in self.JOINT_ORDERED}
             self.ordered["perm"] = up(perm)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # padding beyond a bucket's width stays 0
         self.u, self.f_ext = z([B, nJ_max, 3], torch.float64), z([B, nJ_max, 3], torch.float64)
@@ -892,11 +895,11 @@ class RaggedSolver:
         n_pad_of = lambda idx: (int(packed.n_free[idx].max()) + 63) // 64 * 64
         groups.sort(key=lambda idx: -len(idx) * n_pad_of(idx) * (n_pad_of(idx) + 16))
         self.buckets = []
-        need = {"S": 0, "uf": 0, "work": 0, "env": 0}
+        need = {"S": 0, "uf": 0, "work": 0, "env": 0, "raw_j": 0, "raw_m": 0}
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
         for idx in groups:
             nJ_b, nM_b = max(1, int(packed.nJ[idx].max())), max(1, int(packed.nM[idx].max()))
             n_b, Bb = int(packed.n_free[idx].max()), len(idx)
-            e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
             sub = {"xyz": e([Bb, nJ_b, 3], torch.float64), "loads": e([Bb, nJ_b, 3], torch.float64),
                    "cbits": e([Bb, nJ_b], torch.uint8), "conn": e([Bb, nM_b, 2], torch.int32),
                    "E": e([Bb, nM_b], torch.float64), "A": e([Bb, nM_b], torch.float64),
@@ -912,8 +915,12 @@ class RaggedSolver:
                 need["uf"] = max(need["uf"], Bb * db.rows)
                 need["work"] = max(need["work"], Bb * self.lib.trs_assemble_work_bytes(nJ_b, nM_b, n_b))
                 need["env"] = max(need["env"], Bb * self.lib.trs_env_ints(n_b))
+            on_device = renumbered and plan[0] == "device"
+            if on_device:   # the bucket's rows in the caller's numbering: input of its trs_joint_order
+                need["raw_j"], need["raw_m"] = max(need["raw_j"], Bb * nJ_b), max(need["raw_m"], Bb * nM_b)
             self.buckets.append({"rows": up(np.ascontiguousarray(idx, dtype=np.int64)), "dev": db, "count": Bb,
-                                 "renumbered": renumbered, "idx": idx})
+                                 "renumbered": renumbered, "order_on_device": on_device, "idx": idx,
+                                 "reach": e([Bb], torch.int32) if on_device else None})
         # one workspace for all buckets (they run one after the other on the stream)
         self._S = torch.empty([need["S"]], dtype=torch.float64, device=dev)
         if os.environ.get("TRS_DEBUG_POISON"):
@@ -921,6 +928,8 @@ class RaggedSolver:
         self._uf = torch.empty([need["uf"]], dtype=torch.float64, device=dev)
         self._work = torch.empty([need["work"]], dtype=torch.uint8, device=dev)
         self._env = torch.zeros([need["env"]], dtype=torch.int32, device=dev)
+        raw = {"xyz": e([need["raw_j"] * 3], torch.float64), "loads": e([need["raw_j"] * 3], torch.float64),
+               "cbits": e([need["raw_j"]], torch.uint8), "conn": e([need["raw_m"] * 2], torch.int32)}
         for bk in self.buckets:
             db, Bb = bk["dev"], bk["count"]
             if not db.small:
@@ -929,11 +938,20 @@ class RaggedSolver:
                 db._slab = (self._S[:Bb * db.rows * db.ld].view(Bb, db.rows, db.ld),
                             self._uf[:Bb * db.rows].view(Bb, db.rows), self._work[:Bb * wb].view(Bb, wb),
                             self._env[:Bb * ei].view(Bb, ei))
-        self._tables = None
+            if bk["order_on_device"]:
+                nJ_b, nM_b = db.nJ_max, db.nM_max
+                bk["raw"] = {"xyz": raw["xyz"][:Bb * nJ_b * 3].view(Bb, nJ_b, 3),
+                             "loads": raw["loads"][:Bb * nJ_b * 3].view(Bb, nJ_b, 3),
+                             "cbits": raw["cbits"][:Bb * nJ_b].view(Bb, nJ_b),
+                             "conn": raw["conn"][:Bb * nM_b * 2].view(Bb, nM_b, 2), "nJ": db.nJ, "nM": db.nM}
+                # trs_joint_order writes the renumbered bucket straight into the solver's input tensors
+                bk["ordered"] = {"perm": db.joint_out, "reach": bk["reach"], "xyz": db.xyz, "conn": db.conn,
+                                 "cbits": db.cbits, "loads": db.loads}
+        self._tables = self._copy_tables()
 
     def _copy_tables(self):
-        """ctypes argument arrays of the gather / scatter launches of every bucket (device pointers are fixed
-        once the ordered tensors exist)."""
+        """ctypes argument arrays of the gather / scatter launches of every bucket (all device pointers are
+        fixed at set-up)."""
         import ctypes
         P, Z = ctypes.c_void_p, ctypes.c_size_t
         row_bytes = lambda t: int(t[0].numel() * t.element_size()) if t.dim() > 1 else int(t.element_size())
@@ -942,9 +960,13 @@ class RaggedSolver:
             db = bk["dev"]
             pairs = []
             for f in self.GATHER:
-                renum = bk["renumbered"] and f in ("xyz", "conn", "cbits", "loads")
-                pairs.append(((self.ordered if renum else self.inputs)[f], getattr(db, f)))
-            if bk["renumbered"]:
+                if bk["order_on_device"] and f in self.JOINT_ORDERED:
+                    pairs.append((self.inputs[f], bk["raw"][f]))          # caller's numbering -> input of the order
+                elif bk["renumbered"] and f in self.JOINT_ORDERED:
+                    pairs.append((self.ordered[f], getattr(db, f)))        # host plan: renumbered at set-up
+                else:
+                    pairs.append((self.inputs[f], getattr(db, f)))
+            if bk["renumbered"] and not bk["order_on_device"]:
                 pairs.append((self.ordered["perm"], db.joint_out))
             outs = [(db.u, self.u), (db.f_ext, self.f_ext), (db.N, self.N), (db.info, self.info)]
 
@@ -959,8 +981,8 @@ class RaggedSolver:
 
     def step(self, record=None):
         """One pass of the whole path over the batch, asynchronous on the current stream.  `record` (a list):
-        instrumented step - (stage name, start event, end event) of the order and of every bucket's gather,
-        solve and scatter are appended."""
+        instrumented step - (stage name, start event, end event) of every bucket's gather, order, solve and
+        scatter are appended."""
         torch = self.torch
         if self.B == 0:
             return
@@ -977,32 +999,26 @@ class RaggedSolver:
 
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            if self.plan is not None and self.plan[0] == "device":
-                self.ordered = timed("order", lambda: joint_order_device(
-                    torch, self.inputs, effort=self.plan[1], out=self.ordered))
-            if self._tables is None:
-                self._tables = self._copy_tables()
             for bk, (gather, scatter) in zip(self.buckets, self._tables):
                 timed("gather", lambda: _capi.check(self.lib.trs_copy_rows(
                     *gather, bk["count"], bk["rows"].data_ptr(), 0, stream), "trs_copy_rows (gather)"))
+                if bk["order_on_device"]:
+                    timed("order", lambda: joint_order_device(torch, bk["raw"], effort=self.plan[1], out=bk["ordered"]))
                 timed("solve", bk["dev"].solve)
                 timed("scatter", lambda: _capi.check(self.lib.trs_copy_rows(
                     *scatter, bk["count"], bk["rows"].data_ptr(), 1, stream), "trs_copy_rows (scatter)"))
 
     def adopt_launch_hints(self):
-        """After a step: read back the envelope reach the device order reported (B ints, one synchronisation)
-        and tell every bucket whose envelopes all stay within the wave-per-matrix kernels' range to skip the
+        """After a step: read back the largest envelope reach the device order reported per bucket (one scalar
+        each) and tell every bucket whose envelopes all stay within the wave-per-matrix kernels' range to skip the
         launches that would find no matrix (`DeviceBatch.all_narrow`).  The order is a function of the resident
         inputs, so the hint holds for every later step; it is safe in any case (a hinted batch is routed narrow
         on the device regardless).  Returns the number of buckets hinted."""
-        if self.ordered is None or "reach" not in self.ordered:
-            return 0
-        reach = self.ordered["reach"].cpu().numpy()
         hinted = 0
         for bk in self.buckets:
             db = bk["dev"]
-            if bk["renumbered"] and not db.small and db.use_envelope:
-                db.all_narrow = bool(reach[bk["idx"]].max() <= NARROW_MAX_BELOW)
+            if bk["order_on_device"] and not db.small and db.use_envelope:
+                db.all_narrow = bool(int(bk["reach"].max().item()) <= NARROW_MAX_BELOW)
                 hinted += int(db.all_narrow)
         return hinted
 
