@@ -32,19 +32,20 @@ PEAK_HBM_GBS = 8000.0
 STAGES = ("dofmap", "assemble", "potrf", "potrs", "recover")
 
 
+#: the sources that determine the factorisation kernel and what it reads (the PMC traffic record is about it)
+FINGERPRINT_FILES = ("potrf.hip", "assemble.hip", "dofmap.hip", "trs_common.h", "trs_chol16.h", "trs_subst.h")
+
+
 def kernel_source_sha():
-    """Fingerprint of the device sources (csrc/*.hip, csrc/*.h + the C-ABI header): a PMC record under
-    profiles/ is only quoted in the bench line while it was taken on exactly these sources (.git does
-    not travel to the GPU box, so a commit id cannot be checked there)."""
-    import glob
+    """Fingerprint of the device sources behind the profiled kernel (`FINGERPRINT_FILES` under csrc/): a PMC
+    record under profiles/ is only quoted in the bench line while it was taken on exactly these sources (.git
+    does not travel to the GPU box, so a commit id cannot be checked there)."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "python_stable_3d_truss_analysis_amd", "csrc")
-    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
-                   [os.path.join(ROOT, "include", "trs_solver.h")])
-    for path in files:
-        h.update(os.path.basename(path).encode())
-        with open(path, "rb") as fh:
+    for name in FINGERPRINT_FILES:
+        h.update(name.encode())
+        with open(os.path.join(csrc, name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 

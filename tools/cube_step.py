@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Steps of the ragged cube-truss workload (BASELINE config 3: batch.RaggedSolver on 65 536 generated trusses) for
+profiling:  rocprofv3 --kernel-trace --stats -- python3 tools/cube_step.py [--cubes 65536] [--steps 3]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from python_stable_3d_truss_analysis_amd import batch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cubes", type=int, default=65536)
+ap.add_argument("--steps", type=int, default=3)
+args = ap.parse_args()
+solver = batch.RaggedSolver(bench.cube_workload(args.cubes, 0), "cuda:0", reorder=True)
+solver.step(); torch.cuda.synchronize()
+solver.adopt_launch_hints()
+for _ in range(args.steps):
+    solver.step()
+torch.cuda.synchronize()
+print("info_nonzero", int((solver.info != 0).sum().item()))
