@@ -244,6 +244,25 @@ int trs_joint_order(int B, int nJ_max, int nM_max, const double *xyz, const int3
                     int32_t *perm, int32_t *choice, int32_t *reach, double *xyz_out, int32_t *conn_out,
                     uint8_t *cbits_out, double *loads_out, int effort, void *stream);
 
+/* Random cube trusses generated on the device, straight into the padded batch arrays (the reference's
+ * GenerateRandomCubeTrusses, generate.py:152-376: polycube growth DFS / BFS / Random, cube vertices as joints in
+ * first-seen order, 6 face diagonals by LinkType + 12 edges per cube, pins on the lowest occupied layer, random
+ * loads on unsupported joints, a member type per member, count-unstable draws regenerated).  Bit for bit the output
+ * of the host generator trs_cubegen of trs_host.h for the same (seed, first_index + b): same per-truss splitmix64
+ * stream, same order of draws, same arithmetic.  One wave per truss, grid state in LDS (csrc/cubegen.hip).
+ *   num_cubes [B] (device)  polycube size per truss;  method 0 DFS / 1 BFS / 2 Random;  link_type 0 / 1 / 2 (both
+ *   diagonals) / 3 random;  flags bit 0 = keep parallel members, bit 1 = no pin supports;
+ *   force_range [3][2] (HOST array, read at call time);  mtypes [n_types][3] = (a, e, density) (device)
+ *   xyz == NULL: sizes-only pass - nJ[b], nM[b], n_free[b] (= 3 x unsupported joints; may be NULL) are produced
+ *   with nJ_max / nM_max as bounds only; callers size the batch arrays by its maxima and call again to fill.
+ *   status [2] (device, zeroed by the caller): [0] += regenerated attempts, [1] = 1 if a truss did not fit.
+ * Grids up to 254 cells per axis and 32767 vertices whose tables fit a CU's LDS; hipErrorInvalidValue otherwise. */
+int trs_cubegen_dev(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num_cubes, int method, int link_type,
+                    int flags, double len_lo, double len_hi, const double *force_range, int nforce_lo, int nforce_hi,
+                    const double *mtypes, int n_types, int nJ_max, int nM_max, double *xyz, int32_t *conn, double *E,
+                    double *A, double *rho, uint8_t *cbits, double *loads, int32_t *nJ, int32_t *nM, int32_t *n_free,
+                    int32_t *status, int64_t first_index, void *stream);
+
 /* Row gather / scatter between the padded arrays of a ragged batch and those of one of its size buckets
  * (no reference counterpart: the reference solves one truss per call; its ragged workload is the
  * GenerateRandomCubeTrusses loop, generate.py:342-374).  A bucket's arrays are the rows of its trusses trimmed

@@ -87,6 +87,37 @@ class PackedBatch:
                              else getattr(self, f) for f in self.__dataclass_fields__))
 
 
+@dataclass
+class BatchSizes:
+    """What the host needs to know about a batch whose arrays live on the DEVICE (`generate.generate_cube_batch_device`):
+    the per-truss counts (they decide the size buckets and the slab shapes) and the padded widths.  Accepted
+    wherever a `PackedBatch` is only asked for its sizes (`RaggedSolver(..., tensors=)`, `solve_batch(...,
+    device_inputs=)`, `size_buckets`); `to_packed(tensors)` downloads the arrays."""
+    nJ: np.ndarray
+    nM: np.ndarray
+    n_free: np.ndarray
+    nJ_max: int
+    nM_max: int
+
+    @property
+    def B(self):
+        return int(self.nJ.shape[0])
+
+    @property
+    def n_max(self):
+        return int(self.n_free.max()) if self.B else 0
+
+    @property
+    def dim(self):
+        return np.full([self.B], 3, dtype=np.int32)
+
+    def to_packed(self, tensors):
+        """The same batch as host arrays (`PackedBatch`), downloaded from its device tensors."""
+        host = {f: tensors[f].cpu().numpy() for f in ("xyz", "conn", "E", "A", "rho", "cbits", "loads")}
+        return PackedBatch(host["xyz"], host["conn"], host["E"], host["A"], host["rho"], host["cbits"], host["loads"],
+                           self.nJ.copy(), self.nM.copy(), self.dim, self.n_free.copy())
+
+
 def count_free(cbits, nJ):
     """n_free[b] from the constraint bits (host copy of what trs_dofmap computes)."""
     bits = np.asarray(cbits, dtype=np.uint8)
@@ -872,20 +903,23 @@ class RaggedSolver:
     GATHER = ("xyz", "conn", "E", "A", "cbits", "loads", "nJ", "nM")
     JOINT_ORDERED = ("xyz", "conn", "cbits", "loads")
 
-    def __init__(self, packed: PackedBatch, device=None, reorder=True, max_slab_bytes=48 << 30, granularity=64,
-                 options=None):
-        torch, dev = _require_gpu(device)
+    def __init__(self, packed, device=None, reorder=True, max_slab_bytes=48 << 30, granularity=64,
+                 options=None, tensors=None):
+        """`packed`: a `PackedBatch` (uploaded here) or, with `tensors` = the batch's device tensors by field name
+        (e.g. from `generate.generate_cube_batch_device`), just its `BatchSizes`."""
+        torch, dev = _require_gpu(device if tensors is None else tensors["xyz"].device)
         self.torch, self.device, self.packed, self.lib = torch, dev, packed, _capi.load()
         B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
         self.B = B
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        self.inputs = {f: up(getattr(packed, f)) for f in self.GATHER}
+        self.inputs = {f: (tensors[f].contiguous() if tensors is not None else up(getattr(packed, f))) for f in self.GATHER}
         plan = order_plan(reorder, nJ_max, nM_max) if B else None
         self.plan = plan
         self.ordered = None        # host plan: renumbered xyz / conn / cbits / loads + perm of the FULL batch
         if plan is not None and plan[0] != "device":
-            perm = joint_order(packed, plan[1])
-            renum = permute_joints(packed, perm)
+            host = packed if isinstance(packed, PackedBatch) else packed.to_packed(tensors)
+            perm = joint_order(host, plan[1])
+            renum = permute_joints(host, perm)
             self.ordered = {k: up(getattr(renum, k)) for k in self.JOINT_ORDERED}
             self.ordered["perm"] = up(perm)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # padding beyond a bucket's width stays 0
@@ -1128,7 +1162,7 @@ class ResultPool:
 
 
 def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False, sections=None,
-                on_device=False, pool=None, options=None):
+                on_device=False, pool=None, options=None, device_inputs=None):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
 
     The packed inputs go up once; a ragged batch is bucketed by padded system size
@@ -1151,20 +1185,22 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     Host side of a large batch: the joint order is found on a worker thread while the inputs go up; a
     `PackedBatch.pinned()` uploads by DMA; `pool=ResultPool()` downloads into reused page-locked buffers
     (the returned arrays are then views of the pool, valid until its next use).  `options`: per-call switches
-    of the pipeline (`DEFAULT_OPTIONS`), for A/B runs and tests."""
-    packed = trusses_or_packed if isinstance(trusses_or_packed, PackedBatch) \
+    of the pipeline (`DEFAULT_OPTIONS`), for A/B runs and tests.  `device_inputs`: the batch's arrays already
+    live on the device (dict by field name, e.g. `generate.generate_cube_batch_device`) - nothing is uploaded and
+    the first argument only carries the sizes (`BatchSizes` or a `PackedBatch`)."""
+    packed = trusses_or_packed if isinstance(trusses_or_packed, (PackedBatch, BatchSizes)) \
         else pack_trusses(list(trusses_or_packed))
-    torch, dev = _require_gpu(device)
+    torch, dev = _require_gpu(device if device_inputs is None else device_inputs["xyz"].device)
     B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
     variants = [None] if sections is None else list(sections)
-    if B and _capi.load().trs_solve_small_fits(nJ_max, nM_max, packed.n_max):
+    if B and device_inputs is None and _capi.load().trs_solve_small_fits(nJ_max, nM_max, packed.n_max):
         # every truss is small: the fused kernel, no bucketing, no reordering (nothing to gain from it)
         out = _solve_small_host(packed, torch, dev, variants, on_device)
         return out[0] if sections is None else out
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
     plan = order_plan(reorder, nJ_max, nM_max) if B else None
     ordering = None
-    if plan is not None and plan[0] == "host" and B >= 1024:
+    if plan is not None and plan[0] == "host" and B >= 1024 and isinstance(packed, PackedBatch) and device_inputs is None:
         # native code (the GIL is released): the order is found while the inputs go up
         from concurrent.futures import ThreadPoolExecutor
         worker = ThreadPoolExecutor(max_workers=1)
@@ -1172,7 +1208,14 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     # the densities play no part in the solve (weights and graph features only): they go up for on-device
     # consumers; otherwise the field is not transferred at all (a fifth of the upload of a cube-truss batch)
     needs_rho = on_device
-    full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS if f != "rho" or needs_rho}
+    if device_inputs is not None:
+        full = {f: device_inputs[f].contiguous() for f in DeviceBatch.INPUT_FIELDS if f in device_inputs}
+        if plan is not None and plan[0] == "host" and not isinstance(packed, PackedBatch):
+            packed_host = packed.to_packed(device_inputs)   # a host-side order needs the arrays on the host
+            ordering = None
+            plan = ("given", joint_order(packed_host, plan[1]))
+    else:
+        full = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS if f != "rho" or needs_rho}
     original = dict(full)   # the caller's joint order (the reordering below makes new tensors)
     perm32 = None
     if plan is not None and plan[0] == "device":

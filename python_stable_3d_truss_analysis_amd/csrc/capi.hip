@@ -18,6 +18,9 @@ int trs_recover_launch(int, int, int, const double*, const int*, const double*, 
                        double*, double*, const int*, int, hipStream_t);
 int trs_joint_order_launch(int, int, int, const double*, const int*, const unsigned char*, const double*, const int*,
                            const int*, int*, int*, int*, double*, int*, unsigned char*, double*, int, hipStream_t);
+int trs_cubegen_dev_launch(int, unsigned long long, int, int, int, const int*, int, int, int, double, double, const double*,
+                           int, int, const double*, int, int, int, double*, int*, double*, double*, double*, unsigned char*,
+                           double*, int*, int*, int*, int*, long long, hipStream_t);
 int trs_copy_rows_launch(int, const void* const*, const size_t*, void* const*, const size_t*, const size_t*, int,
                          const long long*, int, hipStream_t);
 int trs_solve_small_fits(int, int, int);
@@ -111,6 +114,20 @@ int trs_fitness(int B, int nJ_max, int nM_max, const double* xyz, const int32_t*
     if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
     return trs_fitness_launch(B, nJ_max, nM_max, xyz, conn, A, rho, nJ, nM, u, N, allow_stress,
                               allow_displace, weight, stress_vio, disp_vio, (hipStream_t)stream);
+}
+
+int trs_cubegen_dev(int B, uint64_t seed, int gx, int gy, int gz, const int32_t* num_cubes, int method, int link_type,
+                    int flags, double len_lo, double len_hi, const double* force_range, int nforce_lo, int nforce_hi,
+                    const double* mtypes, int n_types, int nJ_max, int nM_max, double* xyz, int32_t* conn, double* E,
+                    double* A, double* rho, uint8_t* cbits, double* loads, int32_t* nJ, int32_t* nM, int32_t* n_free,
+                    int32_t* status, int64_t first_index, void* stream) {
+    if (B < 0 || nJ_max <= 0 || nM_max <= 0 || method < 0 || method > 2 || link_type < 0 || link_type > 3)
+        return (int)hipErrorInvalidValue;
+    if (xyz != nullptr && (!conn || !E || !A || !rho || !cbits || !loads)) return (int)hipErrorInvalidValue;
+    return trs_cubegen_dev_launch(B, (unsigned long long)seed, gx, gy, gz, num_cubes, method, link_type, flags, len_lo,
+                                  len_hi, force_range, nforce_lo, nforce_hi, mtypes, n_types, nJ_max, nM_max, xyz, conn,
+                                  E, A, rho, cbits, loads, nJ, nM, n_free, status, (long long)first_index,
+                                  (hipStream_t)stream);
 }
 
 int trs_copy_rows(int nfields, const void* const* src, const size_t* src_pitch, void* const* dst,

@@ -165,6 +165,65 @@ def generate_cube_batch(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 150),
     return (packed, retries.value) if return_retries else packed
 
 
+def generate_cube_batch_device(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 150),
+                               forceRange=((-30000, 30000), (-30000, 30000), (-30000, 30000)),
+                               nForceRange=None, method=GenerateMethod.Random, linkType=LinkType.Random,
+                               memberTypes=((1., 1e7, 0.1),), isAllowParallel=False, seed=0,
+                               isAddPinSupport=True, first_index=0, device=None, return_retries=False):
+    """`generate_cube_batch` ON THE GPU (`trs_cubegen_dev`, `csrc/cubegen.hip`): the same trusses, bit for bit, as
+    the host generator gives for the same arguments (same per-truss streams keyed by (seed, first_index + b)),
+    written straight into device tensors - nothing of the batch ever exists on the host.
+
+    Returns `(sizes, tensors)`: `sizes` = `batch.BatchSizes` (nJ, nM, n_free per truss on the host: they decide
+    buckets and slab shapes), `tensors` = dict of device tensors by `DeviceBatch.INPUT_FIELDS` name, padded to
+    the batch's own maxima.  Two passes like the host generator (sizes only, then the arrays); one
+    synchronisation in between for the maxima."""
+    import torch
+    from . import _capi
+    from .batch import BatchSizes, _require_gpu
+    torch, dev = _require_gpu(device)
+    lib = _capi.load()
+    num_cubes = np.ascontiguousarray(num_cubes, dtype=np.int32).ravel()
+    B = len(num_cubes)
+    gx, gy, gz = (int(v) for v in gridRange)
+    nJ_b, nM_b = ctypes.c_int(), ctypes.c_int()
+    _load().trs_cubegen_bounds(gx, gy, gz, int(num_cubes.max(initial=1)), int(isAllowParallel),
+                               ctypes.byref(nJ_b), ctypes.byref(nM_b))
+    frange = np.ascontiguousarray(forceRange, dtype=np.float64).reshape(3, 2)
+    lo, hi = (-1, -1) if nForceRange is None else tuple(-1 if v is None else int(v) for v in nForceRange)
+    d_cubes = torch.from_numpy(num_cubes).to(dev)
+    d_types = torch.from_numpy(_type_table(memberTypes)).to(dev)
+    i32 = lambda n: torch.empty([n], dtype=torch.int32, device=dev)
+    nJ, nM, n_free, status = i32(B), i32(B), i32(B), torch.zeros([2], dtype=torch.int32, device=dev)
+    flags = int(bool(isAllowParallel)) | (0 if isAddPinSupport else 2)
+
+    def run(nJ_max, nM_max, t):
+        ptr = lambda k: t[k].data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            _capi.check(lib.trs_cubegen_dev(
+                B, int(seed) & (2 ** 64 - 1), gx, gy, gz, d_cubes.data_ptr(), int(method), int(linkType), flags,
+                float(lengthRange[0]), float(lengthRange[1]), frange.ctypes.data_as(ctypes.c_void_p), lo, hi,
+                d_types.data_ptr(), int(d_types.shape[0]), nJ_max, nM_max, ptr("xyz"), ptr("conn"), ptr("E"), ptr("A"),
+                ptr("rho"), ptr("cbits"), ptr("loads"), nJ.data_ptr(), nM.data_ptr(), n_free.data_ptr(),
+                status.data_ptr(), int(first_index), torch.cuda.current_stream(dev).cuda_stream), "trs_cubegen_dev")
+
+    run(nJ_b.value, nM_b.value, None)                      # pass 1: sizes only -> exact padding
+    h_nJ, h_nM, h_free, h_status = nJ.cpu().numpy(), nM.cpu().numpy(), n_free.cpu().numpy(), status.cpu().numpy()
+    if B and h_status[1]:
+        raise RuntimeError("trs_cubegen_dev: a truss does not fit the grid's bounds")
+    retries = int(h_status[0])
+    jm, mm = max(1, int(h_nJ.max(initial=1))), max(1, int(h_nM.max(initial=1)))
+    f64 = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+    tensors = {"xyz": f64(B, jm, 3), "loads": f64(B, jm, 3), "cbits": torch.empty([B, jm], dtype=torch.uint8, device=dev),
+               "conn": torch.empty([B, mm, 2], dtype=torch.int32, device=dev), "E": f64(B, mm), "A": f64(B, mm),
+               "rho": f64(B, mm), "nJ": nJ, "nM": nM}
+    status.zero_()
+    if B:
+        run(jm, mm, tensors)                               # pass 2: the batch itself (same streams)
+    sizes = BatchSizes(h_nJ, h_nM, h_free, jm, mm)
+    return (sizes, tensors, retries) if return_retries else (sizes, tensors)
+
+
 _SUPPORT_3D = {0: "NO", 7: "PIN", 1: "ROLLER_X", 2: "ROLLER_Y", 4: "ROLLER_Z"}
 _SUPPORT_2D = {0: "NO", 3: "PIN", 1: "ROLLER_X", 2: "ROLLER_Y"}
 

@@ -8,7 +8,7 @@ mkdir -p ../variants
 for spec in "$@"; do
   tag=${spec%%:*}; flags=${spec#*:}
   objs=""
-  for f in dofmap assemble potrf potrs recover small graphfeat order rows capi; do
+  for f in dofmap assemble potrf potrs recover small graphfeat order rows cubegen capi; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-value $flags -c $f.hip -o /tmp/var_${tag}_$f.o &
     objs="$objs /tmp/var_${tag}_$f.o"
   done
