@@ -217,15 +217,15 @@ def envelope_counts_batch(n_free, nJ, nM, ft, last, cend, narrow):
             "order_bytes": 2 * (49 * np.asarray(nJ, dtype=np.int64) + 8 * np.asarray(nM, dtype=np.int64)) + 4 * np.asarray(nJ)}
 
 
-def cube_workload(B, rank, seed=7):
+def cube_workload(B, rank, seed=7, device=None):
     """BASELINE config 3: B random cube trusses as `GenerateRandomCubeTrusses(gridRange=(6,6,6), numCube ~ U{8..190},
-    LinkType.Random, GenerateMethod.Random)` (native generator, csrc/cubegen.c; distribution pinned against the
-    reference in tests/test_generate.py).  Rank r draws the trusses with global indices r B .. (r + 1) B - 1."""
-    import numpy as np
+    LinkType.Random, GenerateMethod.Random)`, generated ON THE DEVICE (csrc/cubegen.hip: bit for bit the native
+    host generator csrc/cubegen.c, whose distribution is pinned against the reference in tests/test_generate.py).
+    Rank r draws the trusses with global indices r B .. (r + 1) B - 1.  Returns (sizes, device tensors)."""
     from python_stable_3d_truss_analysis_amd import generate as gen
     from python_stable_3d_truss_analysis_amd.data import dataset_sizes
     sizes = dataset_sizes(seed, rank * B, B, (8, 190))
-    return gen.generate_cube_batch(sizes, gridRange=(6, 6, 6), seed=seed, first_index=rank * B)
+    return gen.generate_cube_batch_device(sizes, gridRange=(6, 6, 6), seed=seed, first_index=rank * B, device=device)
 
 
 def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world):
@@ -234,10 +234,13 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world)
     assembly / factorisation / substitution / recovery + results back in the caller's order and numbering
     (`batch.RaggedSolver`).  Timed like the headline: barrier, K steps, barrier, max over ranks."""
     import numpy as np
+    cube_workload(256, rank, device=device)   # warm
+    torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    packed = cube_workload(args.cube_batch, rank)
+    packed, tensors = cube_workload(args.cube_batch, rank, device=device)
+    torch.cuda.synchronize(device)
     t_gen = time.perf_counter() - t0
-    solver = batch.RaggedSolver(packed, device, reorder=True)
+    solver = batch.RaggedSolver(packed, reorder=True, tensors=tensors)
     for _ in range(max(1, args.cube_warmup)):
         solver.step()
     torch.cuda.synchronize(device)
@@ -312,15 +315,16 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world)
                                                "the bucket gather / scatter copies are overhead, not counted",
                                  "bytes_per_step": bytes_alg, "by_stage": per_stage},
                          "stored_tiles_per_truss": tiles / max(1, packed.B)},
-            "host_generate_s": t_gen,
-            "note": "inputs resident in generator order; one launch pipeline per size bucket on a shared workspace"}
+            "device_generate_s": t_gen,
+            "note": "generated on the device, resident in generator order; one launch pipeline per size bucket on a "
+                    "shared workspace"}
 
 
 def dataset_leg(args, device, torch, barrier, reduce_max, rank, world):
     """BASELINE config 5: this rank's share of a cube-truss dataset streamed through `data.dataset_chunks` -
-    native generation on the host (prefetched), joint order + TWO solves per sample (actual sections and the
-    fixed prior, reference data.py:107-114) + the HeteroData feature kernel on the device, float32 tensors left
-    resident per chunk.  `--dataset-samples` per GPU; rate = samples of all ranks / max rank time."""
+    generation, joint order, TWO solves per sample (actual sections and the fixed prior, reference
+    data.py:107-114) and the HeteroData feature kernel, all on the device; float32 tensors left resident per
+    chunk.  `--dataset-samples` per GPU; rate = samples of all ranks / max rank time."""
     from python_stable_3d_truss_analysis_amd import MemberType, TaskType
     from python_stable_3d_truss_analysis_amd import data as gdata
     chunk = min(16384, args.dataset_samples)
@@ -341,8 +345,8 @@ def dataset_leg(args, device, torch, barrier, reduce_max, rank, world):
         return None
     return {"value": total / elapsed, "unit": "samples/s", "samples_per_gpu": args.dataset_samples, "chunk": chunk,
             "seconds": elapsed, "solves_per_sample": 2, "info_nonzero_rank0": bad, "rank0_samples": seen,
-            "note": "data.dataset_chunks: generation (host, prefetched) + joint order, two solves and graph features "
-                    "(device) per sample, tensors left on the device; mixed cube trusses of 8..190 cubes"}
+            "note": "data.dataset_chunks: generation, joint order, two solves and graph features per sample, all on "
+                    "the device (no host work per sample); tensors left on the device; mixed cube trusses of 8..190 cubes"}
 
 
 def launch_ranks(n):

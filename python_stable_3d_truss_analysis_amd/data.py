@@ -194,14 +194,15 @@ def feature_tensors_host(packed: PackedBatch, actual: BatchResult, prior: BatchR
             "weight": weight, "conn": torch.from_numpy(keep[1].astype(np.int64))}
 
 
-def feature_tensors_device(packed: PackedBatch, fixedMemberType, taskType, forceScale=1., displaceScale=1.,
-                           positionScale=1., device=None, reorder=False):
+def feature_tensors_device(packed, fixedMemberType, taskType, forceScale=1., displaceScale=1.,
+                           positionScale=1., device=None, reorder=False, device_inputs=None):
     """The dataset sample pipeline entirely on the GPU (BASELINE config 5): both solves
     (`solve_batch(..., sections=[None, fixed], on_device=True)`: one upload, one reordering) and the
     feature kernel `trs_graph_features_dev` (`csrc/graphfeat.hip`) on the resident results - nothing but
     the float32 feature tensors ever needs to leave the device.  Returns the same dict as
     `feature_tensors_host` with torch tensors ON THE DEVICE (weight included), plus `info` [2,B]
-    (status of the two solves).  Bit-identical to the host path."""
+    (status of the two solves).  Bit-identical to the host path.  `device_inputs`: the batch already lives
+    on the device (`generate.generate_cube_batch_device`); `packed` then only carries its sizes."""
     import torch
     from . import _capi
     from .batch import solve_batch
@@ -210,7 +211,7 @@ def feature_tensors_device(packed: PackedBatch, fixedMemberType, taskType, force
     regression = taskType == TaskType.REGRESSION
     sections = [None] + ([(fixedMemberType.a, fixedMemberType.e, fixedMemberType.density)]
                          if fixedMemberType is not None else [])
-    out = solve_batch(packed, device, reorder=reorder, sections=sections, on_device=True)
+    out = solve_batch(packed, device, reorder=reorder, sections=sections, on_device=True, device_inputs=device_inputs)
     actual, prior = out[0], (out[1] if fixedMemberType is not None else None)
     inp = actual.inputs
     dev = actual.displace.device
@@ -397,25 +398,42 @@ def dataset_sizes(seed, first, count, numCubeRange):
 
 def dataset_chunks(n_samples, rank=0, world=1, chunk=16384, seed=0, numCubeRange=(8, 190), gridRange=(6, 6, 6),
                    fixedMemberType=None, taskType=TaskType.OPTIMIZATION, forceScale=1., displaceScale=1.,
-                   positionScale=1., device=None, reorder=True, prefetch=True, **generator_args):
+                   positionScale=1., device=None, reorder=True, prefetch=True, generate="device", **generator_args):
     """BASELINE config 5 as a generator: this rank's share of a dataset of `n_samples` random cube trusses,
-    chunk by chunk - native generation (`generate_cube_batch`), both solves and the feature kernel on
-    `device` (`feature_tensors_device`).  Yields `(first_index, packed, tensors)`; nothing larger than one
-    chunk is ever held on the host.  The dataset is DEFINED by (seed, global sample index) - polycube sizes
-    (`dataset_sizes`) and the generator's per-truss streams alike -: any split into ranks and chunks produces
-    the same samples (rank r owns the chunks r, r + world, ...).  One process per
-    GPU, no communication: run it under `torchrun` with rank / world from the environment, or in a loop.
-    The native host work of the next chunk (generation; the joint order only where it cannot run on the GPU)
-    overlaps the GPU work of the current one."""
+    chunk by chunk - generation, joint order, both solves and the feature kernel, everything on `device`
+    (`generate_cube_batch_device`, `feature_tensors_device`): NO host work per sample, so eight ranks on one
+    host do not compete for its CPUs.  Yields `(first_index, packed, tensors)`; `tensors` are the float32
+    feature tensors on the device plus `inputs` (the chunk's resident input tensors); `packed` is a
+    `batch.BatchSizes` (per-truss counts; `packed.to_packed(tensors["inputs"])` downloads the arrays) - or a full
+    `PackedBatch` with `generate="host"`, which builds the chunks with the native host generator (bit for bit the
+    same trusses), prefetching chunk k + 1 on a worker thread while the GPU works on chunk k.
+    The dataset is DEFINED by (seed, global sample index) - polycube sizes (`dataset_sizes`) and the generators'
+    per-truss streams alike -: any split into ranks and chunks produces the same samples (rank r owns the chunks
+    r, r + world, ...).  One process per GPU, no communication: run it under `torchrun` with rank / world from
+    the environment, or in a loop."""
     from concurrent.futures import ThreadPoolExecutor
     from .batch import joint_order, order_plan
-    from .generate import generate_cube_batch
+    from .generate import generate_cube_batch, generate_cube_batch_device
+    if generate not in ("device", "host"):
+        raise ValueError("generate must be 'device' or 'host'")
     n_chunks = (int(n_samples) + chunk - 1) // chunk
     mine = list(range(rank, n_chunks, world))
+    span = lambda k: (k * chunk, min(chunk, int(n_samples) - k * chunk))
+
+    if generate == "device":
+        for k in mine:
+            first, count = span(k)
+            sizes = dataset_sizes(seed, first, count, numCubeRange)
+            meta, inputs = generate_cube_batch_device(sizes, gridRange=gridRange, seed=seed, first_index=first,
+                                                      device=device, **generator_args)
+            tensors = feature_tensors_device(meta, fixedMemberType, taskType, forceScale, displaceScale,
+                                             positionScale, device, reorder, device_inputs=inputs)
+            tensors["inputs"] = inputs
+            yield first, meta, tensors
+        return
 
     def host_side(k):   # native code (the GIL is released): generation and the joint order of chunk k
-        first = k * chunk
-        count = min(chunk, int(n_samples) - first)
+        first, count = span(k)
         sizes = dataset_sizes(seed, first, count, numCubeRange)
         packed = generate_cube_batch(sizes, gridRange=gridRange, seed=seed, first_index=first, **generator_args)
         # the joint order: on the GPU with the solves (`trs_joint_order`) whenever the chunk's shape fits that

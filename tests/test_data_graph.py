@@ -216,12 +216,13 @@ def test_dataset_chunks_sharding_is_invariant():
     import torch
     kw = dict(seed=5, numCubeRange=(3, 12), gridRange=(4, 4, 4), fixedMemberType=FIXED,
               taskType=TaskType.REGRESSION, memberTypes=[[1., 1e7, 0.1], [2., 2e7, 0.2]], **SCALES)
-    single = {first: (p, t) for first, p, t in data.dataset_chunks(700, chunk=256, **kw)}
+    single = {first: (p, t) for first, p, t in data.dataset_chunks(700, chunk=256, generate="host", **kw)}
     assert sorted(single) == [0, 256, 512] and single[512][0].B == 700 - 512
     seen = {}
-    for rank in range(2):
-        for first, p, t in data.dataset_chunks(700, rank=rank, world=2, chunk=256, **kw):
-            seen[first] = (p, t)
+    for rank in range(2):   # ... the ranks generate ON THE DEVICE: the same trusses, the same features, bit for bit
+        for first, meta, t in data.dataset_chunks(700, rank=rank, world=2, chunk=256, **kw):
+            assert not hasattr(meta, "xyz")                       # sizes only: the chunk never visited the host
+            seen[first] = (meta.to_packed(t["inputs"]), t)
     assert sorted(seen) == sorted(single)
     for first in single:
         p0, t0 = single[first]
@@ -231,7 +232,7 @@ def test_dataset_chunks_sharding_is_invariant():
         for key in ("joint_x", "member_x", "joint_y", "member_y"):
             assert torch.equal(t0[key], t1[key])
     # other chunk size: same samples, in every chunk (the sizes are keyed by the global index, not the chunk)
-    for first, p, t in data.dataset_chunks(700, chunk=128, **kw):
+    for first, p, t in data.dataset_chunks(700, chunk=128, generate="host", **kw):
         base, off = single[first // 256 * 256][0], first % 256
         np.testing.assert_array_equal(p.nM, base.nM[off: off + p.B])
         nJ = int(p.nJ.max())

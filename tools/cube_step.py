@@ -12,7 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cubes", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=3)
 args = ap.parse_args()
-solver = batch.RaggedSolver(bench.cube_workload(args.cubes, 0), "cuda:0", reorder=True)
+sizes, tensors = bench.cube_workload(args.cubes, 0, device="cuda:0")
+solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors)
 solver.step(); torch.cuda.synchronize()
 solver.adopt_launch_hints()
 for _ in range(args.steps):
