@@ -12,13 +12,13 @@ from .utils import HipExtensionError, TrussNotStableError
 
 __all__ = ["Truss", "Member", "MemberType", "SupportType", "MetapathType", "TaskType",
            "LinkType", "GenerateMethod", "HipExtensionError", "TrussNotStableError",
-           "solve_batch", "pack_trusses", "PackedBatch", "BatchResult",
+           "solve_batch", "pack_trusses", "PackedBatch", "BatchResult", "RaggedSolver", "DeviceBatch",
            "ShardedSolver", "solve_batch_sharded", "solve_batch_distributed"]
 
 
 def __getattr__(name):
     # torch-dependent names are resolved lazily so that the model imports without torch
-    if name in ("solve_batch", "pack_trusses", "PackedBatch", "BatchResult"):
+    if name in ("solve_batch", "pack_trusses", "PackedBatch", "BatchResult", "RaggedSolver", "DeviceBatch"):
         from . import batch
         return getattr(batch, name)
     if name in ("ShardedSolver", "solve_batch_sharded", "solve_batch_distributed"):

@@ -295,6 +295,141 @@ def GenerateRandomCubeTrusses(gridRange=(5, 5, 5), numCubeRange=(5, 5), numEachR
     return trusses
 
 
+# ---- the reference's object-level generator API (generate.py:150-311) ----------------------------------
+# `CubeGrid` / `CubeTruss` for callers who build polycubes cube by cube in Python.  Same constructor arguments,
+# methods, return values and `random` call order as the reference, so a seeded script carries over unchanged
+# (tests/test_generate.py compares against structures captured from the reference).  The batch paths above
+# (`generate_cube_batch`, `generate_cube_batch_device`) do not go through these classes.
+
+_CUBE_FACE_DIAGONALS = (((0, 5), (1, 4)), ((1, 7), (3, 5)), ((3, 6), (2, 7)), ((2, 4), (0, 6)), ((4, 7), (5, 6)),
+                        ((0, 3), (1, 2)))
+_CUBE_EDGES = ((4, 5), (5, 7), (6, 7), (4, 6), (0, 1), (0, 2), (1, 3), (2, 3), (0, 4), (1, 5), (2, 6), (3, 7))
+
+
+class CubeTruss:
+    """One grid cell as eight joint ids: vertex v sits at `coordinate + ((v & 1), (v >> 1) & 1, (v >> 2) & 1)`;
+    vertices shared with earlier cubes keep their ids (`usedDict`: vertex -> joint id)."""
+
+    def __init__(self, coordinate, usedDict=None):
+        self._coordinate = tuple(coordinate)
+        self.jointIDs = [None] * 8
+        self.GenerateNew({} if usedDict is None else usedDict)
+
+    def __repr__(self):
+        return str(self.jointIDs)
+
+    def __getitem__(self, i):
+        return self.jointIDs[i]
+
+    def __setitem__(self, i, value):
+        self.jointIDs[i] = value
+
+    def GetCubeVertices(self):
+        return [tuple(c + ((v >> axis) & 1) for axis, c in enumerate(self._coordinate))
+                for v in range(1 << len(self._coordinate))]
+
+    def GenerateNew(self, usedDict=None):
+        usedDict = {} if usedDict is None else usedDict
+        nextID = max(usedDict.values()) + 1 if usedDict else 0
+        for v, vertex in enumerate(self.GetCubeVertices()):
+            if vertex not in usedDict:
+                usedDict[vertex] = nextID
+                nextID += 1
+            self[v] = usedDict[vertex]
+
+    def LinkMember(self, linkType, hasLinked):
+        """The cube's members as joint-id pairs: per face one diagonal, the other or both (`linkType`; a fresh
+        `random.sample` per face when `LinkType.Random`), then the twelve edges; with a set `hasLinked` an ordered
+        pair already in it is skipped and new ones are recorded there."""
+        import random
+        links = []
+
+        def add(pair):
+            link = [self[pair[0]], self[pair[1]]]
+            if hasLinked is None:
+                links.append(link)
+            elif tuple(link) not in hasLinked:
+                hasLinked.add(tuple(link))
+                links.append(link)
+
+        for first, second in _CUBE_FACE_DIAGONALS:
+            choice = random.sample(range(3), k=1)[0] if linkType == LinkType.Random else linkType
+            for pair in ((first,), (second,), (first, second))[choice]:
+                add(pair)
+        for pair in _CUBE_EDGES:
+            add(pair)
+        return links
+
+
+class CubeGrid:
+    """A box of `xMax * yMax * zMax` cells in which polycubes are grown."""
+
+    _DIRECTIONS = ((-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1))
+
+    def __init__(self, xMax, yMax, zMax):
+        self._shape = (xMax, yMax, zMax)
+        self._usedDict = {}
+        self.grid = [[[False] * zMax for _ in range(yMax)] for _ in range(xMax)]
+
+    def __getitem__(self, coordinate):
+        return self.grid[coordinate[0]][coordinate[1]][coordinate[2]]
+
+    def __setitem__(self, coordinate, isUsed):
+        self.grid[coordinate[0]][coordinate[1]][coordinate[2]] = isUsed
+
+    def IsOutOfRange(self, coordinate):
+        return any(c < 0 or c >= top for c, top in zip(coordinate, self._shape))
+
+    def GetRandomFeasible(self):
+        import random
+        xMax, yMax, zMax = self._shape
+        return random.choice([(x, y, z) for z in range(zMax) for y in range(yMax) for x in range(xMax)
+                              if not self[(x, y, z)]])
+
+    def GetNextFeasibles(self, coordinate, isSuffle=True):
+        import random
+        around = [tuple(c + d for c, d in zip(coordinate, step)) for step in self._DIRECTIONS]
+        free = [c for c in around if not self.IsOutOfRange(c) and not self[c]]
+        if isSuffle:
+            random.shuffle(free)
+        return free
+
+    def RandomGenerateCubes(self, numCube=None, method=GenerateMethod.DFS):
+        import random
+        xMax, yMax, zMax = self._shape
+        if numCube is None:
+            numCube = random.randint(1, xMax * yMax * zMax)
+        self._usedDict.clear()
+        cubes, pending = [], [self.GetRandomFeasible()]
+        while len(cubes) < numCube and pending:
+            if method == GenerateMethod.DFS:
+                cell = pending.pop()
+            elif method == GenerateMethod.BFS:
+                cell = pending.pop(0)
+            else:
+                cell = pending.pop() if random.random() <= 0.5 else pending.pop(0)
+            self[cell] = True
+            pending.extend(c for c in self.GetNextFeasibles(cell) if c not in pending)
+            cubes.append(CubeTruss(cell, self._usedDict))
+        return cubes
+
+    def ProcessPinSupport(self, isAddPinSupport, length):
+        lowest = min((z for _, _, z in self._usedDict), default=0)
+        length = [float(v) for v in length]
+        joints = [None] * len(self._usedDict)
+        for (x, y, z), jointID in self._usedDict.items():
+            joints[jointID] = [[float(x * length[0]), float(y * length[1]), float((z - lowest) * length[2])],
+                               "PIN" if (isAddPinSupport and z == lowest) else "NO"]
+        return joints
+
+    def CubesToTruss(self, cubes, length, isAddPinSupport=True, isAllowParallel=True, linkType=LinkType.Random,
+                     memberType=(1., 1e7, 0.1)):
+        memberType = list(memberType)
+        hasLinked = None if isAllowParallel else set()
+        members = [[link, memberType] for cube in cubes for link in cube.LinkMember(linkType, hasLinked)]
+        return {"joint": self.ProcessPinSupport(isAddPinSupport, length), "force": {}, "member": members}
+
+
 # ---- data augmentation (reference generate.py:13-148) ------------------------------------------------
 # Callables on a truss JSON dict (or a `Truss`, which is re-loaded from its augmented serialisation);
 # same names, arguments and `random` call order as the reference so that seeded pipelines carry over.

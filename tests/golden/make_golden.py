@@ -23,6 +23,7 @@ Written files:
   hetero_bar25.npz       HeteroData tensors of bar-25 for the four (task, metapath) combinations
   augment.json           the reference's data augmenters (generate.py:13-148) applied to bar-25 with
                          seeded `random`: expected joint lists per augmenter
+  cubegrid.json          CubeGrid / CubeTruss (generate.py:150-311) under seeded `random`: cube joint ids, truss dicts
   cube_stats.npz         integer statistics of 200 reference samples per (GenerateMethod, LinkType, polycube
                          size): the distribution the native generator (csrc/cubegen.c) must reproduce
 """
@@ -326,11 +327,42 @@ def capture_cube_stats(rty, rg):
     np.savez_compressed(os.path.join(HERE, "cube_stats.npz"), **out)
 
 
+def capture_cube_grid(rty, rg):
+    """The reference's object-level generator (CubeGrid / CubeTruss, generate.py:150-311) under seeded `random`:
+    the cubes' joint ids and the truss dict of CubesToTruss, per growth method and link type."""
+    out = []
+    for method in (rty.GenerateMethod.DFS, rty.GenerateMethod.BFS, rty.GenerateMethod.Random):
+        for link in (rty.LinkType.LeftBottom_RightTop, rty.LinkType.RightBottom_LeftTop, rty.LinkType.Cross,
+                     rty.LinkType.Random):
+            for parallel in (False, True):
+                seed = 900 + 100 * method + 10 * link + int(parallel)
+                random.seed(seed)
+                grid = rg.CubeGrid(3, 4, 2)
+                cubes = grid.RandomGenerateCubes(6, method)
+                truss = grid.CubesToTruss(cubes, [10.0, 20.0, 30.0], True, parallel, link)
+                nxt = grid.GetNextFeasibles((1, 1, 0))
+                out.append({"seed": seed, "method": method, "link": link, "parallel": parallel,
+                            "cubes": [list(c.jointIDs) for c in cubes], "joint": truss["joint"],
+                            "member": truss["member"], "next": [list(c) for c in nxt],
+                            "vertices": [list(v) for v in cubes[0].GetCubeVertices()],
+                            "out_of_range": [grid.IsOutOfRange(c) for c in ((0, 0, 0), (3, 0, 0), (2, 3, 1), (0, -1, 0))]})
+    random.seed(77)
+    grid = rg.CubeGrid(2, 2, 2)
+    cubes = grid.RandomGenerateCubes(None, rty.GenerateMethod.Random)      # numCube drawn by the grid itself
+    out.append({"seed": 77, "auto": True, "cubes": [list(c.jointIDs) for c in cubes],
+                "joint": grid.ProcessPinSupport(False, [1, 1, 1])})
+    with open(os.path.join(HERE, "cubegrid.json"), "w") as fh:
+        json.dump(out, fh)
+    print("cubegrid.json:", len(out), "cases")
+
+
 def main():
     rt, rty, rg, rga = import_reference()
-    which = sys.argv[1:] or ["data", "cube", "edge", "ga", "hetero", "augment", "stats"]
+    which = sys.argv[1:] or ["data", "cube", "edge", "ga", "hetero", "augment", "stats", "cubegrid"]
     if "stats" in which:
         capture_cube_stats(rty, rg)
+    if "cubegrid" in which:
+        capture_cube_grid(rty, rg)
     if "augment" in which:
         capture_augmenters(rg)
     if "data" in which:

@@ -302,3 +302,37 @@ def test_augmenters_reproduce_the_reference_with_seeded_random():
                                    np.array([p for p, _ in want["joint"]]), rtol=1e-13, atol=1e-12, err_msg=name)
         assert (got["member"] == base["member"]) == want["member_unchanged"]
         assert (got["force"] == base["force"]) == want["force_unchanged"]
+
+
+def test_cube_grid_and_cube_truss_follow_the_reference_under_seeded_random():
+    """`CubeGrid` / `CubeTruss` (reference generate.py:150-311) against structures captured from the reference
+    with the same `random.seed` (`tests/golden/cubegrid.json`): cube joint ids, neighbour shuffles, joints,
+    members - for every growth method x link type, with and without parallel members."""
+    import random
+    with open(os.path.join(H.GOLDEN, "cubegrid.json")) as fh:
+        cases = json.load(fh)
+    assert len(cases) == 25
+    for case in cases:
+        random.seed(case["seed"])
+        if case.get("auto"):
+            grid = gen.CubeGrid(2, 2, 2)
+            cubes = grid.RandomGenerateCubes(None, gen.GenerateMethod.Random)
+            assert [list(c.jointIDs) for c in cubes] == case["cubes"]
+            assert grid.ProcessPinSupport(False, [1, 1, 1]) == case["joint"]
+            continue
+        grid = gen.CubeGrid(3, 4, 2)
+        cubes = grid.RandomGenerateCubes(6, case["method"])
+        truss = grid.CubesToTruss(cubes, [10.0, 20.0, 30.0], True, case["parallel"], case["link"])
+        assert [list(c.jointIDs) for c in cubes] == case["cubes"], case["seed"]
+        assert [c[i] for c in cubes for i in range(8)] == [v for ids in case["cubes"] for v in ids]
+        assert truss["joint"] == case["joint"] and truss["force"] == {}
+        assert truss["member"] == case["member"], case["seed"]
+        assert [list(c) for c in grid.GetNextFeasibles((1, 1, 0))] == case["next"]
+        assert [list(v) for v in cubes[0].GetCubeVertices()] == case["vertices"]
+        assert [grid.IsOutOfRange(c) for c in ((0, 0, 0), (3, 0, 0), (2, 3, 1), (0, -1, 0))] == case["out_of_range"]
+        assert repr(cubes[0]) == str(case["cubes"][0])
+    # a hand-built cube: fresh ids in vertex order, shared vertices reused
+    used = {}
+    a, b = gen.CubeTruss((0, 0, 0), used), gen.CubeTruss((1, 0, 0), used)
+    assert a.jointIDs == list(range(8)) and b.jointIDs == [1, 8, 3, 9, 5, 10, 7, 11]
+    assert len(a.LinkMember(gen.LinkType.Cross, None)) == 24 and len(a.LinkMember(gen.LinkType.LeftBottom_RightTop, set())) == 18
