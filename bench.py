@@ -379,7 +379,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational PCIe-inclusive pass")
     ap.add_argument("--cube-batch", type=int, default=65536,
                     help="trusses per GPU of the mixed cube-truss leg, BASELINE config 3 (0 = skip)")
-    ap.add_argument("--dataset-samples", type=int, default=32768,
+    ap.add_argument("--dataset-samples", type=int, default=131072,
                     help="samples per GPU of the dataset leg, BASELINE config 5 (0 = skip)")
     ap.add_argument("--cube-steps", type=int, default=5)
     ap.add_argument("--cube-warmup", type=int, default=1)

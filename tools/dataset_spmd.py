@@ -21,6 +21,7 @@ ap.add_argument("--samples", type=int, default=131072)
 ap.add_argument("--chunk", type=int, default=16384)
 ap.add_argument("--no-prefetch", action="store_true")
 ap.add_argument("--order", default="profile", choices=("profile", "fast", "rcm"))
+ap.add_argument("--generate", default="device", choices=("device", "host"), help="where the chunks are generated")
 args = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()}"
@@ -29,7 +30,8 @@ count, bad, bytes_down = 0, 0, 0
 for first, packed, tensors in data.dataset_chunks(args.samples, rank, world, args.chunk, seed=1, device=device,
                                                   fixedMemberType=MemberType(1., 1e7, 0.1),
                                                   taskType=TaskType.REGRESSION, forceScale=1e3, displaceScale=0.1,
-                                                  positionScale=100., reorder=args.order, prefetch=not args.no_prefetch):
+                                                  positionScale=100., reorder=args.order, prefetch=not args.no_prefetch,
+                                                  generate=args.generate):
     host = {k: v.cpu() for k, v in tensors.items() if hasattr(v, "cpu")}   # what a data loader would store
     bad += int(host["info"].sum())
     bytes_down += sum(v.numel() * v.element_size() for v in host.values())
