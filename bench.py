@@ -9,11 +9,17 @@ inputs resident in HBM before the timed region.  One step = one pass of the whol
 the batch: dofmap -> assemble -> potrf -> potrs -> recover (five stages through the C ABI).
 Weak scaling: every rank solves its own batch; no collective on the data path.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (trs_potrf_kernel, FP64 MFMA bound): algorithmic FLOP / measured
-                average launch duration (events recorded on the launch stream inside the timed steps)
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      dominant kernel (the factorisation with the fused substitution): algorithmic bytes or executed
+                tile FLOP / measured average launch duration (events recorded on the launch stream inside the
+                timed steps), the roof picked by arithmetic intensity; `frac_dense_8d` = SURVEY 8d's dense figure
   cpu_baseline  the numpy oracle (faithful restatement of the reference's per-truss path) timed on
-                the host cores of this box, bounded sample, 1 thread
+                the host cores of this box, bounded sample, 1 thread (rank 0, N = 1 only)
+  cube_batch    BASELINE config 3 at EVERY N: `--cube-batch` random cube trusses per GPU generated on the device,
+                joint order INSIDE the timed step (batch.RaggedSolver), solves/s + roofline fractions
+  dataset       BASELINE config 5 at every N: samples/s of data.dataset_chunks (generation, order, two solves and
+                graph features on the device)
+  pcie_inclusive, given_joint_order, dense_mode_potrf   informational legs at N = 1
 """
 import argparse
 import json
@@ -684,8 +690,9 @@ def main():
             "config": {"workload": f"{args.case} x {args.batch} independent copies per GPU "
                                    f"(nJ {nJ}, nM {nM}, n_free {n})",
                        "batch_per_gpu": args.batch, "parallelism": f"batch-sharded x{world}, no collective",
-                       "joint_order": (order or "given") + (" (host, once per topology, before the timed region; "
-                                                            "results in the given numbering)" if order else "")},
+                       "joint_order": (order or "given") + (" (found once per topology, before the timed region - by "
+                                                            "trs_joint_order on the device for 'profile' -; results in "
+                                                            "the given numbering)" if order else "")},
             "roofline": roofline,
             "stages_ms": stage_ms,
             "stages_ms_note": "event pairs around every stage, measured over an equal number of instrumented steps "
