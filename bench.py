@@ -548,7 +548,7 @@ def main():
     # next batch, solve and download of the previous one overlapped on three streams (batch.StreamedSolver)
     pcie = None
     if world == 1 and not args.no_pcie:
-        pipe = batch.StreamedSolver(packed, device, slots=2, use_envelope=not args.dense, same_topology=True)
+        pipe = batch.StreamedSolver(packed, device, slots=3, use_envelope=not args.dense, same_topology=True)
         src = pipe.host_in[0]
         for _ in range(3):          # warm-up: first use of the page-locked buffers, allocator, clocks
             pipe.submit(src)
@@ -568,8 +568,8 @@ def main():
                 "h2d_plus_d2h_GBps": (in_bytes + out_bytes) / dt / 1e9,
                 "info_nonzero": int((last.info != 0).sum()),
                 "note": "steady state of batch.StreamedSolver: upload of all inputs, solve and download of u, "
-                        "f_ext, N, info through page-locked host buffers on three streams, two resident "
-                        "batches; never the headline value"}
+                        "f_ext, N, info through page-locked host buffers on three streams (one DMA per direction "
+                        "and batch), three resident batches; never the headline value"}
         del pipe
 
     # the ragged workload of north_star (BASELINE config 3), on EVERY rank, with its own barrier-bracketed region

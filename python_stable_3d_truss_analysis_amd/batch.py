@@ -643,9 +643,42 @@ class StreamedSolver:
         if not same_topology:   # the batches that follow need not share the template's envelopes: no launch hints
             for d in self.dev:
                 d.all_narrow = False
-        self.host_in = [{f: v for f, v in d.pinned_inputs(template).items() if f in self.fields} for d in self.dev]
-        self.host_out = [{k: torch.empty(getattr(self.dev[0], k).shape, dtype=getattr(self.dev[0], k).dtype).pin_memory()
-                          for k in ("u", "f_ext", "N", "info")} for _ in range(slots + 1)]
+
+        # Every slot's uploaded fields live in ONE device buffer and ONE page-locked host buffer of the same
+        # layout (likewise the four result fields), so that a batch crosses PCIe as one DMA per direction
+        # instead of eight + four copies; the DeviceBatch tensors and the host dicts are views of them.
+        def flat(like, pinned):
+            offs, total = {}, 0
+            for k, v in like.items():
+                offs[k] = total
+                total += (v.numel() * v.element_size() + 255) // 256 * 256
+            buf = torch.empty([total], dtype=torch.uint8, pin_memory=True) if pinned else \
+                torch.empty([total], dtype=torch.uint8, device=dev)
+            views = {k: buf[offs[k]: offs[k] + v.numel() * v.element_size()].view(v.dtype).view(v.shape)
+                     for k, v in like.items()}
+            return buf, views
+
+        self.host_in, self._host_in_flat, self._dev_in_flat = [], [], []
+        self.host_out, self._host_out_flat, self._dev_out_flat = [], [], []
+        for d in self.dev:
+            ins = {f: getattr(d, f) for f in self.fields}
+            dbuf, dviews = flat(ins, pinned=False)
+            hbuf, hviews = flat(ins, pinned=True)
+            for f in self.fields:
+                dviews[f].copy_(ins[f])
+                hviews[f].copy_(ins[f])
+                setattr(d, f, dviews[f])
+            outs = {k: getattr(d, k) for k in ("u", "f_ext", "N", "info")}
+            obuf, oviews = flat(outs, pinned=False)
+            for k in outs:
+                setattr(d, k, oviews[k])
+            self._dev_in_flat.append(dbuf); self._host_in_flat.append(hbuf); self.host_in.append(hviews)
+            self._dev_out_flat.append(obuf)
+        torch.cuda.synchronize(dev)
+        like_out = {k: getattr(self.dev[0], k) for k in ("u", "f_ext", "N", "info")}
+        for _ in range(slots + 1):
+            hbuf, hviews = flat(like_out, pinned=True)
+            self._host_out_flat.append(hbuf); self.host_out.append(hviews)
         self.s_up, self.s_run, self.s_down = (torch.cuda.Stream(dev) for _ in range(3))
         self.ev_up = [torch.cuda.Event() for _ in range(slots)]       # upload into device slot finished
         self.ev_run = [torch.cuda.Event() for _ in range(slots)]      # solve on device slot finished
@@ -671,10 +704,14 @@ class StreamedSolver:
         self.count += 1
         done = self._take(self.pending.pop(0)) if len(self.pending) == n else None
         dev, src = self.dev[slot], host_inputs if host_inputs is not None else self.host_in[slot]
+        own = [i for i, h in enumerate(self.host_in) if h is src]   # one of this pipe's own staging buffers?
         with t.cuda.stream(self.s_up):
             self.s_up.wait_event(self.ev_run[slot])     # the slot's previous solve no longer reads its inputs
-            for f in self.fields:
-                getattr(dev, f).copy_(src[f], non_blocking=True)
+            if own:   # one DMA for all fields
+                self._dev_in_flat[slot].copy_(self._host_in_flat[own[0]], non_blocking=True)
+            else:
+                for f in self.fields:
+                    getattr(dev, f).copy_(src[f], non_blocking=True)
             self.ev_up[slot].record(self.s_up)
         with t.cuda.stream(self.s_run):
             self.s_run.wait_event(self.ev_up[slot])
@@ -683,7 +720,7 @@ class StreamedSolver:
             self.ev_run[slot].record(self.s_run)
         with t.cuda.stream(self.s_down):
             self.s_down.wait_event(self.ev_run[slot])
-            dev.download(self.host_out[hbuf])
+            self._host_out_flat[hbuf].copy_(self._dev_out_flat[slot], non_blocking=True)   # one DMA for the four results
             self.ev_down[slot].record(self.s_down)
         self.pending.append((slot, hbuf))
         return done
