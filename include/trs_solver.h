@@ -270,11 +270,16 @@ int trs_cubegen_dev(int B, uint64_t seed, int gx, int gy, int gz, const int32_t 
  * field k < nfields (at most 12, one launch) and every i < count, `width[k]` bytes:
  *   scatter == 0:  dst[k] + i * dst_pitch[k]        <-  src[k] + rows[i] * src_pitch[k]     (gather)
  *   scatter != 0:  dst[k] + rows[i] * dst_pitch[k]  <-  src[k] + i * src_pitch[k]           (scatter)
- * src / dst / pitches / widths are HOST arrays of device pointers and byte counts (read at call time);
- * rows is a device array of int64 row indices (distinct for a scatter). */
+ * fill_to (or NULL): behind the copied prefix the destination row is ZEROED up to fill_to[k] bytes (a scatter into
+ * rows wider than the bucket's).  src / dst / pitches / widths / fill_to are HOST arrays of device pointers and
+ * byte counts (read at call time); rows is a device array of int64 row indices (distinct for a scatter).
+ * Either side may be page-locked HOST memory (mapped into the device's address space): the gather then pulls a
+ * bucket's rows over PCIe straight out of the caller's host batch, the scatter pushes results into the caller's
+ * host arrays; max_blocks > 0 keeps such a launch to that many work-groups (it needs bytes in flight, not CUs);
+ * 0 = default. */
 int trs_copy_rows(int nfields, const void *const *src, const size_t *src_pitch, void *const *dst,
-                  const size_t *dst_pitch, const size_t *width, int count, const int64_t *rows, int scatter,
-                  void *stream);
+                  const size_t *dst_pitch, const size_t *width, const size_t *fill_to, int count,
+                  const int64_t *rows, int scatter, int max_blocks, void *stream);
 
 /* The whole Truss.Solve() pipeline (truss.py:329-364) on one stream: trs_solve_small when the batch
  * shape qualifies (the slab, uf, work and env arguments are then not touched), otherwise

@@ -37,7 +37,7 @@ SIGNATURES = {
     "trs_joint_order": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "trs_cubegen_dev": (_I, [_I, ctypes.c_uint64, _I, _I, _I, _P, _I, _I, _I, _D, _D, _P, _I, _I, _P, _I, _I, _I,
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int64, _P]),
-    "trs_copy_rows": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "trs_copy_rows": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
     "trs_solve": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
                        _P, _P, _P, _P, _P, _P, _P, _I, _P]),
 }

@@ -921,6 +921,30 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30, granularity=64):
     return groups
 
 
+class SolverWorkspace:
+    """Grow-only device buffers for the bucket pipelines of `RaggedSolver`s that run one after the other on one
+    stream (slab, reduced vectors, assembly tables, envelope metadata, gathered un-ordered inputs): several
+    solvers - the pieces of `solve_batch_streamed` - share one instead of allocating their own."""
+
+    KINDS = {"S": "float64", "uf": "float64", "work": "uint8", "env": "int32", "raw_xyz": "float64",
+             "raw_loads": "float64", "raw_cbits": "uint8", "raw_conn": "int32"}
+
+    def __init__(self, torch, device):
+        self.torch, self.device, self.buf = torch, device, {}
+
+    def get(self, need):
+        """Flat tensors of at least `need[kind]` elements each (zero-filled for the envelope metadata)."""
+        t = self.torch
+        for kind, count in need.items():
+            have = self.buf.get(kind)
+            if have is None or have.numel() < count:
+                make = t.zeros if kind == "env" else t.empty
+                self.buf[kind] = make([max(1, int(count))], dtype=getattr(t, self.KINDS[kind]), device=self.device)
+                if kind == "S" and os.environ.get("TRS_DEBUG_POISON"):
+                    self.buf[kind].fill_(float("nan"))
+        return self.buf
+
+
 class RaggedSolver:
     """A RAGGED batch (trusses of very different sizes: the reference's `GenerateRandomCubeTrusses` loop,
     `generate.py:342-374`, BASELINE config 3) resident on one device in the caller's order and numbering, set
@@ -941,15 +965,29 @@ class RaggedSolver:
     JOINT_ORDERED = ("xyz", "conn", "cbits", "loads")
 
     def __init__(self, packed, device=None, reorder=True, max_slab_bytes=48 << 30, granularity=64,
-                 options=None, tensors=None):
+                 options=None, tensors=None, workspace=None, host_io=None):
         """`packed`: a `PackedBatch` (uploaded here) or, with `tensors` = the batch's device tensors by field name
-        (e.g. from `generate.generate_cube_batch_device`), just its `BatchSizes`."""
+        (e.g. from `generate.generate_cube_batch_device`), just its `BatchSizes`.  `workspace`: a
+        `SolverWorkspace` shared with other solvers that run on the same stream one after the other.
+
+        `host_io=(inputs, outputs)`: the batch STAYS in page-locked host memory - `inputs` / `outputs` are dicts of
+        pinned CPU tensors (the padded arrays of a `PackedBatch.pinned()`; `u`, `f_ext`, `N`, `info` of a
+        `ResultPool`).  Page-locked memory is mapped into the device's address space, so every bucket's gather
+        PULLS its rows straight out of the host batch and its scatter PUSHES the results into the host arrays
+        (full rows, zero padding included); `step()` then runs the buckets as a three-stream pipeline - pull of
+        bucket k + 1, device work of bucket k, push of bucket k - 1 at the same time (`solve_batch_streamed`)."""
         torch, dev = _require_gpu(device if tensors is None else tensors["xyz"].device)
         self.torch, self.device, self.packed, self.lib = torch, dev, packed, _capi.load()
         B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
         self.B = B
+        self.host_io = host_io is not None
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        self.inputs = {f: (tensors[f].contiguous() if tensors is not None else up(getattr(packed, f))) for f in self.GATHER}
+        if self.host_io:
+            self.inputs = {f: host_io[0][f] for f in self.GATHER}
+            if not all(t.is_pinned() and t.is_contiguous() for t in self.inputs.values()):
+                raise ValueError("host_io inputs must be contiguous page-locked tensors (PackedBatch.pinned())")
+        else:
+            self.inputs = {f: (tensors[f].contiguous() if tensors is not None else up(getattr(packed, f))) for f in self.GATHER}
         plan = order_plan(reorder, nJ_max, nM_max) if B else None
         self.plan = plan
         self.ordered = None        # host plan: renumbered xyz / conn / cbits / loads + perm of the FULL batch
@@ -960,11 +998,21 @@ class RaggedSolver:
             self.ordered = {k: up(getattr(renum, k)) for k in self.JOINT_ORDERED}
             self.ordered["perm"] = up(perm)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # padding beyond a bucket's width stays 0
-        self.u, self.f_ext = z([B, nJ_max, 3], torch.float64), z([B, nJ_max, 3], torch.float64)
-        self.N, self.info = z([B, nM_max], torch.float64), z([B], torch.int32)
+        if self.host_io:
+            out = host_io[1]
+            self.u, self.f_ext, self.N, self.info = out["u"], out["f_ext"], out["N"], out["info"]
+            want = {"u": (B, nJ_max, 3), "f_ext": (B, nJ_max, 3), "N": (B, nM_max), "info": (B,)}
+            if not all(out[k].is_pinned() and out[k].is_contiguous() and tuple(out[k].shape) == want[k] for k in want):
+                raise ValueError("host_io outputs must be contiguous page-locked tensors of the padded result shapes")
+        else:
+            self.u, self.f_ext = z([B, nJ_max, 3], torch.float64), z([B, nJ_max, 3], torch.float64)
+            self.N, self.info = z([B, nM_max], torch.float64), z([B], torch.int32)
         groups = size_buckets(packed, max_slab_bytes, granularity) if B else []
         n_pad_of = lambda idx: (int(packed.n_free[idx].max()) + 63) // 64 * 64
-        groups.sort(key=lambda idx: -len(idx) * n_pad_of(idx) * (n_pad_of(idx) + 16))
+        slab_of = lambda idx: len(idx) * n_pad_of(idx) * (n_pad_of(idx) + 16)
+        # largest slab first (the shared workspace is sized once) - in the host-fed pipeline SMALLEST first: the
+        # device starts after a short pull, and what is exposed at the end is a small bucket's push
+        groups.sort(key=(lambda idx: slab_of(idx)) if self.host_io else (lambda idx: -slab_of(idx)))
         self.buckets = []
         need = {"S": 0, "uf": 0, "work": 0, "env": 0, "raw_j": 0, "raw_m": 0}
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
@@ -987,20 +1035,19 @@ class RaggedSolver:
                 need["work"] = max(need["work"], Bb * self.lib.trs_assemble_work_bytes(nJ_b, nM_b, n_b))
                 need["env"] = max(need["env"], Bb * self.lib.trs_env_ints(n_b))
             on_device = renumbered and plan[0] == "device"
-            if on_device:   # the bucket's rows in the caller's numbering: input of its trs_joint_order
+            if on_device and not self.host_io:   # the bucket's rows in the caller's numbering: input of its trs_joint_order
                 need["raw_j"], need["raw_m"] = max(need["raw_j"], Bb * nJ_b), max(need["raw_m"], Bb * nM_b)
             self.buckets.append({"rows": up(np.ascontiguousarray(idx, dtype=np.int64)), "dev": db, "count": Bb,
                                  "renumbered": renumbered, "order_on_device": on_device, "idx": idx,
                                  "reach": e([Bb], torch.int32) if on_device else None})
         # one workspace for all buckets (they run one after the other on the stream)
-        self._S = torch.empty([need["S"]], dtype=torch.float64, device=dev)
-        if os.environ.get("TRS_DEBUG_POISON"):
-            self._S.fill_(float("nan"))
-        self._uf = torch.empty([need["uf"]], dtype=torch.float64, device=dev)
-        self._work = torch.empty([need["work"]], dtype=torch.uint8, device=dev)
-        self._env = torch.zeros([need["env"]], dtype=torch.int32, device=dev)
-        raw = {"xyz": e([need["raw_j"] * 3], torch.float64), "loads": e([need["raw_j"] * 3], torch.float64),
-               "cbits": e([need["raw_j"]], torch.uint8), "conn": e([need["raw_m"] * 2], torch.int32)}
+        ws = workspace if workspace is not None else SolverWorkspace(torch, dev)
+        bufs = ws.get({"S": need["S"], "uf": need["uf"], "work": need["work"], "env": need["env"],
+                       "raw_xyz": need["raw_j"] * 3, "raw_loads": need["raw_j"] * 3, "raw_cbits": need["raw_j"],
+                       "raw_conn": need["raw_m"] * 2})
+        self.workspace = ws
+        self._S, self._uf, self._work, self._env = bufs["S"], bufs["uf"], bufs["work"], bufs["env"]
+        raw = {"xyz": bufs["raw_xyz"], "loads": bufs["raw_loads"], "cbits": bufs["raw_cbits"], "conn": bufs["raw_conn"]}
         for bk in self.buckets:
             db, Bb = bk["dev"], bk["count"]
             if not db.small:
@@ -1009,16 +1056,25 @@ class RaggedSolver:
                 db._slab = (self._S[:Bb * db.rows * db.ld].view(Bb, db.rows, db.ld),
                             self._uf[:Bb * db.rows].view(Bb, db.rows), self._work[:Bb * wb].view(Bb, wb),
                             self._env[:Bb * ei].view(Bb, ei))
-            if bk["order_on_device"]:
+            if bk["order_on_device"] and self.host_io:
+                # (the pull of bucket k + 1 runs while bucket k is being ordered: every bucket its own buffers)
+                nJ_b, nM_b = db.nJ_max, db.nM_max
+                bk["raw"] = {"xyz": e([Bb, nJ_b, 3], torch.float64), "loads": e([Bb, nJ_b, 3], torch.float64),
+                             "cbits": e([Bb, nJ_b], torch.uint8), "conn": e([Bb, nM_b, 2], torch.int32),
+                             "nJ": db.nJ, "nM": db.nM}
+            elif bk["order_on_device"]:
                 nJ_b, nM_b = db.nJ_max, db.nM_max
                 bk["raw"] = {"xyz": raw["xyz"][:Bb * nJ_b * 3].view(Bb, nJ_b, 3),
                              "loads": raw["loads"][:Bb * nJ_b * 3].view(Bb, nJ_b, 3),
                              "cbits": raw["cbits"][:Bb * nJ_b].view(Bb, nJ_b),
                              "conn": raw["conn"][:Bb * nM_b * 2].view(Bb, nM_b, 2), "nJ": db.nJ, "nM": db.nM}
+            if bk["order_on_device"]:
                 # trs_joint_order writes the renumbered bucket straight into the solver's input tensors
                 bk["ordered"] = {"perm": db.joint_out, "reach": bk["reach"], "xyz": db.xyz, "conn": db.conn,
                                  "cbits": db.cbits, "loads": db.loads}
         self._tables = self._copy_tables()
+        if self.host_io:
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev))
 
     def _copy_tables(self):
         """ctypes argument arrays of the gather / scatter launches of every bucket (all device pointers are
@@ -1046,7 +1102,9 @@ class RaggedSolver:
                 src, dst = (P * n)(*[a.data_ptr() for a, _ in pairs]), (P * n)(*[b.data_ptr() for _, b in pairs])
                 sp, dp = (Z * n)(*[row_bytes(a) for a, _ in pairs]), (Z * n)(*[row_bytes(b) for _, b in pairs])
                 width = (Z * n)(*[row_bytes(b if trimmed_is_dst else a) for a, b in pairs])
-                return n, src, sp, dst, dp, width
+                # results pushed into HOST rows: the whole row is written, zeros behind the bucket's width
+                fill = (Z * n)(*[row_bytes(b) for _, b in pairs]) if (self.host_io and not trimmed_is_dst) else None
+                return n, src, sp, dst, dp, width, fill
             tables.append((pack(pairs, True), pack(outs, False)))
         return tables
 
@@ -1068,16 +1126,58 @@ class RaggedSolver:
             record.append((name, e0, e1))
             return out
 
+        # work-groups of a copy kernel whose other side is host memory (it needs bytes in flight, not CUs)
+        PCIE_BLOCKS = int(os.environ.get("TRS_PCIE_BLOCKS", "32"))
         with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            for bk, (gather, scatter) in zip(self.buckets, self._tables):
-                timed("gather", lambda: _capi.check(self.lib.trs_copy_rows(
-                    *gather, bk["count"], bk["rows"].data_ptr(), 0, stream), "trs_copy_rows (gather)"))
-                if bk["order_on_device"]:
-                    timed("order", lambda: joint_order_device(torch, bk["raw"], effort=self.plan[1], out=bk["ordered"]))
-                timed("solve", bk["dev"].solve)
-                timed("scatter", lambda: _capi.check(self.lib.trs_copy_rows(
-                    *scatter, bk["count"], bk["rows"].data_ptr(), 1, stream), "trs_copy_rows (scatter)"))
+            if not self.host_io:
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                for bk, (gather, scatter) in zip(self.buckets, self._tables):
+                    timed("gather", lambda: _capi.check(self.lib.trs_copy_rows(
+                        *gather, bk["count"], bk["rows"].data_ptr(), 0, 0, stream), "trs_copy_rows (gather)"))
+                    if bk["order_on_device"]:
+                        timed("order", lambda: joint_order_device(torch, bk["raw"], effort=self.plan[1], out=bk["ordered"]))
+                    timed("solve", bk["dev"].solve)
+                    timed("scatter", lambda: _capi.check(self.lib.trs_copy_rows(
+                        *scatter, bk["count"], bk["rows"].data_ptr(), 1, 0, stream), "trs_copy_rows (scatter)"))
+                return
+            # host-fed pipeline: pull of bucket k + 1 | order + solve of bucket k | push of bucket k - 1
+            s_up, s_run, s_down = self._streams
+            caller = torch.cuda.current_stream(self.device)
+            timing = record is not None
+            begin = torch.cuda.Event(enable_timing=timing)
+            begin.record(caller)
+            for st in self._streams:
+                st.wait_event(begin)
+            mark = lambda name, stream: record.append((name, begin, self._marked(stream))) if timing else None
+            for k, (bk, (gather, scatter)) in enumerate(zip(self.buckets, self._tables)):
+                with torch.cuda.stream(s_up):
+                    _capi.check(self.lib.trs_copy_rows(*gather, bk["count"], bk["rows"].data_ptr(), 0, PCIE_BLOCKS,
+                                                       s_up.cuda_stream), "trs_copy_rows (pull)")
+                    pulled = torch.cuda.Event()
+                    pulled.record(s_up)
+                    mark(f"bucket {k} pulled", s_up)
+                with torch.cuda.stream(s_run):
+                    s_run.wait_event(pulled)
+                    mark(f"bucket {k} run begins", s_run)
+                    if bk["order_on_device"]:
+                        joint_order_device(torch, bk["raw"], effort=self.plan[1], out=bk["ordered"])
+                    bk["dev"].solve()
+                    solved = torch.cuda.Event()
+                    solved.record(s_run)
+                    mark(f"bucket {k} solved", s_run)
+                with torch.cuda.stream(s_down):
+                    s_down.wait_event(solved)
+                    _capi.check(self.lib.trs_copy_rows(*scatter, bk["count"], bk["rows"].data_ptr(), 1, PCIE_BLOCKS,
+                                                       s_down.cuda_stream), "trs_copy_rows (push)")
+                    mark(f"bucket {k} pushed", s_down)
+            done = torch.cuda.Event()
+            done.record(s_down)
+            caller.wait_event(done)   # work queued on the caller's stream after step() sees the results
+
+    def _marked(self, stream):
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
 
     def adopt_launch_hints(self):
         """After a step: read back the largest envelope reach the device order reported per bucket (one scalar
@@ -1094,8 +1194,11 @@ class RaggedSolver:
         return hinted
 
     def result(self):
-        """Synchronise and download the dense results (caller's order and numbering)."""
+        """Synchronise and download the dense results (caller's order and numbering); in the host-fed mode they
+        are in the caller's page-locked arrays already."""
         self.torch.cuda.synchronize(self.device)
+        if self.host_io:
+            return BatchResult(self.u.numpy(), self.f_ext.numpy(), self.N.numpy(), self.info.numpy())
         return BatchResult(self.u.cpu().numpy(), self.f_ext.cpu().numpy(), self.N.cpu().numpy(),
                            self.info.cpu().numpy())
 
@@ -1198,6 +1301,42 @@ class ResultPool:
         return buf
 
 
+def solve_batch_streamed(packed: PackedBatch, device=None, reorder=True, pool=None, max_slab_bytes=48 << 30):
+    """Host arrays in -> host results out for a LARGE ragged batch held in page-locked memory
+    (`PackedBatch.pinned()`), as a pipeline over PCIe with NO staging copy: the batch stays where it is, every
+    size bucket's gather pulls its rows straight out of the host arrays (page-locked memory is mapped into the
+    device's address space; only the bucket-trimmed prefix of every row crosses the link - for cube trusses
+    about 60 % of the padded bytes), the device orders and solves the bucket, and its scatter pushes the results
+    into the (page-locked) result arrays - pull of bucket k + 1, device work of bucket k and push of bucket k - 1
+    at the same time on three streams (`RaggedSolver(host_io=...)`).  Same results, bit for bit, as
+    `solve_batch(packed, reorder=...)`.  `solve_batch(..., pool=...)` routes big pinned batches here by itself."""
+    torch, dev = _require_gpu(device)
+    B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
+    pool = pool if pool is not None else ResultPool()
+    host_out = {"u": pool.take(torch, (0, "u"), [B, nJ_max, 3], torch.float64),
+                "f_ext": pool.take(torch, (0, "f_ext"), [B, nJ_max, 3], torch.float64),
+                "N": pool.take(torch, (0, "N"), [B, nM_max], torch.float64),
+                "info": pool.take(torch, (0, "info"), [B], torch.int32)}
+    host_in = {f: torch.from_numpy(getattr(packed, f)) for f in RaggedSolver.GATHER}
+    solver = RaggedSolver(packed, dev, reorder=reorder, max_slab_bytes=max_slab_bytes, host_io=(host_in, host_out))
+    solver.step()
+    return solver.result()
+
+
+def _is_pinned(packed):
+    """Every solver input of a `PackedBatch` is a contiguous array in page-locked memory."""
+    import torch
+    try:
+        return all(getattr(packed, f).flags["C_CONTIGUOUS"] and torch.from_numpy(getattr(packed, f)).is_pinned()
+                   for f in RaggedSolver.GATHER)
+    except (RuntimeError, TypeError, ValueError):
+        return False
+
+
+#: `solve_batch(..., pool=...)` hands batches of at least this many trusses to `solve_batch_streamed`
+STREAMED_FROM = 16384
+
+
 def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder=False, sections=None,
                 on_device=False, pool=None, options=None, device_inputs=None):
     """Solve many trusses in device pipelines.  Accepts `list[Truss]` or a `PackedBatch`.
@@ -1230,6 +1369,10 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     torch, dev = _require_gpu(device if device_inputs is None else device_inputs["xyz"].device)
     B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
     variants = [None] if sections is None else list(sections)
+    if (pool is not None and B >= STREAMED_FROM and sections is None and not on_device and device_inputs is None
+            and isinstance(packed, PackedBatch) and options is None and _is_pinned(packed)
+            and not _capi.load().trs_solve_small_fits(nJ_max, nM_max, packed.n_max)):
+        return solve_batch_streamed(packed, dev, reorder=reorder, pool=pool, max_slab_bytes=min(max_slab_bytes, 48 << 30))
     if B and device_inputs is None and _capi.load().trs_solve_small_fits(nJ_max, nM_max, packed.n_max):
         # every truss is small: the fused kernel, no bucketing, no reordering (nothing to gain from it)
         out = _solve_small_host(packed, torch, dev, variants, on_device)

@@ -15,34 +15,57 @@ struct RowFields {
     const unsigned char* src[MAX_FIELDS];
     unsigned char* dst[MAX_FIELDS];
     unsigned long long src_pitch[MAX_FIELDS], dst_pitch[MAX_FIELDS], width[MAX_FIELDS];  // bytes
+    unsigned long long fill_to[MAX_FIELDS];  // zeros are written behind the copied prefix up to this many bytes
     int unit[MAX_FIELDS];                                                                 // 16, 8, 4 or 1
+    int nfields;
 };
+
+template <typename V>
+__device__ __forceinline__ void zero_units(unsigned char* d, unsigned long long from, unsigned long long to, int lane) {
+    V* dv = reinterpret_cast<V*>(d);
+    V z;
+    __builtin_memset(&z, 0, sizeof(V));
+    for (unsigned long long i = from / sizeof(V) + lane; i < to / sizeof(V); i += 64) dv[i] = z;
+}
 
 template <typename V>
 __device__ __forceinline__ void copy_units(const unsigned char* s, unsigned char* d, unsigned long long bytes, int lane) {
     const V* sv = reinterpret_cast<const V*>(s);
     V* dv = reinterpret_cast<V*>(d);
     const unsigned long long n = bytes / sizeof(V);
-    for (unsigned long long i = lane; i < n; i += 64) dv[i] = sv[i];
+    unsigned long long i = lane;
+    for (; i + 7 * 64 < n; i += 8 * 64) {  // eight loads in flight per lane before the first store: a copy whose
+        V v[8];                            // far side is host memory lives on bytes in flight, not on waves
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sv[i + 64 * k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dv[i + 64 * k] = v[k];
+    }
+    for (; i < n; i += 64) dv[i] = sv[i];
 }
 
 // scatter == 0: dst[i] = src[rows[i]];  scatter != 0: dst[rows[i]] = src[i].   One wave per row, strided.
+// gridDim.y == nfields: blockIdx.y = field (device-to-device: as many waves as the chip takes);
+// gridDim.y == 1: every work-group walks all fields (host-side copies: FEW waves in total, see the launcher).
 __global__ __launch_bounds__(256) void trs_copy_rows_kernel(const RowFields f, const long long* __restrict__ rows,
                                                             const int count, const int scatter) {
-    const int field = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwave = gridDim.x * 4;
-    const unsigned long long sp = f.src_pitch[field], dp = f.dst_pitch[field], w = f.width[field];
-    for (int i = wave; i < count; i += nwave) {
-        const long long r = rows[i];
-        const unsigned char* s = f.src[field] + (scatter ? (unsigned long long)i : (unsigned long long)r) * sp;
-        unsigned char* d = f.dst[field] + (scatter ? (unsigned long long)r : (unsigned long long)i) * dp;
-        switch (f.unit[field]) {
-            case 16: copy_units<uint4>(s, d, w, lane); break;
-            case 8: copy_units<uint2>(s, d, w, lane); break;
-            case 4: copy_units<unsigned>(s, d, w, lane); break;
-            default: copy_units<unsigned char>(s, d, w, lane); break;
+    const int f0 = gridDim.y == 1 ? 0 : blockIdx.y, f1 = gridDim.y == 1 ? f.nfields : f0 + 1;
+    for (int field = f0; field < f1; ++field) {
+        const unsigned long long sp = f.src_pitch[field], dp = f.dst_pitch[field], w = f.width[field];
+        const unsigned long long ft = f.fill_to[field];
+        for (int i = wave; i < count; i += nwave) {
+            const long long r = rows[i];
+            const unsigned char* s = f.src[field] + (scatter ? (unsigned long long)i : (unsigned long long)r) * sp;
+            unsigned char* d = f.dst[field] + (scatter ? (unsigned long long)r : (unsigned long long)i) * dp;
+            switch (f.unit[field]) {
+                case 16: copy_units<uint4>(s, d, w, lane); if (ft > w) zero_units<uint4>(d, w, ft, lane); break;
+                case 8: copy_units<uint2>(s, d, w, lane); if (ft > w) zero_units<uint2>(d, w, ft, lane); break;
+                case 4: copy_units<unsigned>(s, d, w, lane); if (ft > w) zero_units<unsigned>(d, w, ft, lane); break;
+                default: copy_units<unsigned char>(s, d, w, lane); if (ft > w) zero_units<unsigned char>(d, w, ft, lane); break;
+            }
         }
     }
 }
@@ -50,8 +73,8 @@ __global__ __launch_bounds__(256) void trs_copy_rows_kernel(const RowFields f, c
 }  // namespace
 
 extern "C" int trs_copy_rows_launch(int nfields, const void* const* src, const size_t* src_pitch, void* const* dst,
-                                    const size_t* dst_pitch, const size_t* width, int count, const long long* rows,
-                                    int scatter, hipStream_t stream) {
+                                    const size_t* dst_pitch, const size_t* width, const size_t* fill_to, int count,
+                                    const long long* rows, int scatter, int max_blocks, hipStream_t stream) {
     if (count <= 0 || nfields <= 0) return 0;
     if (nfields > MAX_FIELDS) return (int)hipErrorInvalidValue;
     RowFields f;
@@ -63,14 +86,22 @@ extern "C" int trs_copy_rows_launch(int nfields, const void* const* src, const s
         f.src_pitch[k] = src_pitch[k];
         f.dst_pitch[k] = dst_pitch[k];
         f.width[k] = width[k];
+        f.fill_to[k] = fill_to != nullptr ? fill_to[k] : 0;
+        if (f.fill_to[k] > dst_pitch[k]) return (int)hipErrorInvalidValue;
         const unsigned long long all = (unsigned long long)(uintptr_t)src[k] | (unsigned long long)(uintptr_t)dst[k] |
-                                       src_pitch[k] | dst_pitch[k] | width[k];
+                                       src_pitch[k] | dst_pitch[k] | width[k] | f.fill_to[k];
         f.unit[k] = all % 16 == 0 ? 16 : (all % 8 == 0 ? 8 : (all % 4 == 0 ? 4 : 1));
         most = width[k] > most ? width[k] : most;
     }
-    // enough waves to fill the chip: one wave per row up to 8192 waves per field
+    f.nfields = nfields;
+    // enough waves to fill the chip: one wave per row up to 8192 waves per field - or FEW work-groups IN TOTAL when
+    // the caller says so (max_blocks > 0: one side is page-locked host memory; a PCIe stream needs ~100 KB in
+    // flight, not the whole chip - and every wave it holds on a SIMD takes registers from the factorisation
+    // running beside it, which fills its SIMDs to the last VGPR)
     int blocks = (count + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(trs_copy_rows_kernel, dim3(blocks, nfields), dim3(256), 0, stream, f, rows, count, scatter);
+    const int cap = max_blocks > 0 ? max_blocks : 2048;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(trs_copy_rows_kernel, dim3(blocks, max_blocks > 0 ? 1 : nfields), dim3(256), 0, stream, f, rows,
+                       count, scatter);
     return (int)hipGetLastError();
 }

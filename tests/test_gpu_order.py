@@ -212,13 +212,48 @@ def test_copy_rows_gathers_and_scatters_prefixes(gpu):
     src, dst = (P * 2)(full.data_ptr(), small.data_ptr()), (P * 2)(a.data_ptr(), b.data_ptr())
     sp, dp, w = (Z * 2)(37 * 24, 13), (Z * 2)(30 * 24, 11), (Z * 2)(30 * 24, 11)
     stream = torch.cuda.current_stream().cuda_stream
-    assert lib.trs_copy_rows(2, src, sp, dst, dp, w, 20, rows.data_ptr(), 0, stream) == 0
+    assert lib.trs_copy_rows(2, src, sp, dst, dp, w, None, 20, rows.data_ptr(), 0, 0, stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(a, full[rows][:, :30]) and torch.equal(b, small[rows][:, :11])
     back_a, back_b = torch.zeros_like(full), torch.zeros_like(small)
     src2, dst2 = (P * 2)(a.data_ptr(), b.data_ptr()), (P * 2)(back_a.data_ptr(), back_b.data_ptr())
-    assert lib.trs_copy_rows(2, src2, dp, dst2, sp, w, 20, rows.data_ptr(), 1, stream) == 0
+    assert lib.trs_copy_rows(2, src2, dp, dst2, sp, w, None, 20, rows.data_ptr(), 1, 0, stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(back_a[rows][:, :30], full[rows][:, :30]) and not back_a[:, 30:].any()
     assert torch.equal(back_b[rows][:, :11], small[rows][:, :11])
-    assert lib.trs_copy_rows(2, src, sp, dst, dp, (Z * 2)(10 ** 6, 11), 20, rows.data_ptr(), 0, stream) != 0  # width > pitch
+    assert lib.trs_copy_rows(2, src, sp, dst, dp, (Z * 2)(10 ** 6, 11), None, 20, rows.data_ptr(), 0, 0, stream) != 0  # width > pitch
+
+
+def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
+    """`solve_batch_streamed` / `RaggedSolver(host_io=...)`: the batch stays in page-locked host memory, every
+    bucket is pulled over PCIe by the gather kernel, solved, and pushed into the page-locked result arrays (full
+    rows, zero padding) on three streams - bit for bit the results of the one-piece `solve_batch`, also when the
+    result pool held other data before, and `solve_batch(pool=...)` routes big pinned batches there by itself."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    rng = np.random.default_rng(8)
+    packed = gen.generate_cube_batch(rng.integers(1, 191, size=1500), gridRange=(6, 6, 6), seed=13)
+    want = gpu.solve_batch(packed, reorder=True)
+    pinned, pool = packed.pinned(), gpu.ResultPool()
+    assert gpu._is_pinned(pinned) and not gpu._is_pinned(packed)
+    for reorder in (True, False):
+        ref = want if reorder else gpu.solve_batch(packed)
+        for attempt in range(2):
+            for k in ("u", "f_ext", "N"):                 # stale content of an earlier call must not survive
+                if (0, k) in pool._bufs:
+                    pool._bufs[(0, k)].fill_(float("nan"))
+            got = gpu.solve_batch_streamed(pinned, reorder=reorder, pool=pool)
+            for k in ("displace", "external", "internal", "info"):
+                np.testing.assert_array_equal(getattr(got, k), getattr(ref, k), err_msg=f"{k} reorder={reorder}")
+    keep = gpu.STREAMED_FROM
+    gpu.STREAMED_FROM = 1000
+    try:
+        routed = gpu.solve_batch(pinned, reorder=True, pool=pool)
+        np.testing.assert_array_equal(routed.displace, want.displace)
+        plain = gpu.solve_batch(packed, reorder=True, pool=pool)      # pageable inputs: the one-piece path
+        np.testing.assert_array_equal(plain.internal, want.internal)
+    finally:
+        gpu.STREAMED_FROM = keep
+    with pytest.raises(ValueError):
+        import torch
+        gpu.RaggedSolver(packed, host_io=({f: torch.from_numpy(getattr(packed, f)) for f in gpu.RaggedSolver.GATHER},
+                                          {}))

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Host arrays in -> host results out on 65 536 mixed cube trusses: `solve_batch` in one piece (upload, device
+work, download one after the other) against `solve_batch_streamed` (the batch stays in page-locked host memory,
+buckets are pulled / solved / pushed as a three-stream pipeline)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from python_stable_3d_truss_analysis_amd import batch, generate as gen
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+rng = np.random.default_rng(0)
+packed = gen.generate_cube_batch(rng.integers(8, 191, size=B), gridRange=(6, 6, 6), seed=7)
+pinned, pool = packed.pinned(), batch.ResultPool()
+keep = batch.STREAMED_FROM
+batch.STREAMED_FROM = 1 << 60
+for _ in range(3):
+    t0 = time.perf_counter(); ref = batch.solve_batch(pinned, reorder=True, pool=pool); dt = time.perf_counter() - t0
+print(f"one piece: {dt:.3f} s = {B / dt / 1e6:.2f} M solves/s")
+ref = batch.BatchResult(ref.displace.copy(), ref.external.copy(), ref.internal.copy(), ref.info.copy())
+batch.STREAMED_FROM = keep
+for _ in range(4):
+    t0 = time.perf_counter(); res = batch.solve_batch(pinned, reorder=True, pool=pool); dt = time.perf_counter() - t0
+same = all(np.array_equal(getattr(res, k), getattr(ref, k)) for k in ("displace", "external", "internal", "info"))
+print(f"streamed (buckets pulled / solved / pushed): {dt:.3f} s = {B / dt / 1e6:.2f} M solves/s, bitwise equal: {same}")
+# where the streamed call's time goes: set-up (bucket tensors, workspace, index lists) vs the pipeline itself
+host_in = {f: torch.from_numpy(getattr(pinned, f)) for f in batch.RaggedSolver.GATHER}
+host_out = {"u": pool.take(torch, (0, "u"), [B, pinned.nJ_max, 3], torch.float64),
+            "f_ext": pool.take(torch, (0, "f_ext"), [B, pinned.nJ_max, 3], torch.float64),
+            "N": pool.take(torch, (0, "N"), [B, pinned.nM_max], torch.float64),
+            "info": pool.take(torch, (0, "info"), [B], torch.int32)}
+for _ in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    solver = batch.RaggedSolver(pinned, "cuda:0", reorder=True, max_slab_bytes=48 << 30, host_io=(host_in, host_out))
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    solver.step(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    solver.step(); torch.cuda.synchronize(); t3 = time.perf_counter()
+    print(f"set-up {1e3 * (t1 - t0):.1f} ms, first step {1e3 * (t2 - t1):.1f} ms, second step {1e3 * (t3 - t2):.1f} ms "
+          f"({B / (t3 - t2) / 1e6:.2f} M solves/s as a resident host-fed solver)")
+rec = []
+solver.step(record=rec); torch.cuda.synchronize()
+for name, e0, e1 in rec:
+    print(f"{e0.elapsed_time(e1):8.2f} ms  {name}  (B {solver.buckets[int(name.split()[1])]['count']}, n_pad {solver.buckets[int(name.split()[1])]['dev'].rows})")
