@@ -440,6 +440,13 @@ class TrussDataAugmenter:
     def _apply(self, data):
         return data
 
+    @staticmethod
+    def IsTrussClass(trussData):
+        """(is it a `Truss` object, the JSON dict to work on) - `generate.py:14-20`."""
+        if isinstance(trussData, Truss):
+            return True, trussData.Serialize()
+        return False, trussData
+
     def __call__(self, trussData):
         if isinstance(trussData, Truss):
             # The reference re-loads the augmented serialisation INTO the same object

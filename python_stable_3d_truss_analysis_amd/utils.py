@@ -128,3 +128,19 @@ def GetAngles(position0, position1):
     if IsZero(plan):
         return plan / full, d[2] / full, 0.0, 0.0
     return plan / full, d[2] / full, d[1] / plan, d[0] / plan
+
+
+def GetPowerset(s):
+    """Every subset of the sequence `s`, in binary counting order (subset i holds s[j] for the set bits j of i):
+    the order in which the reference enumerates a cube's vertices (`utils.py:95-98`, `generate.py:168-174`)."""
+    for i in range(1 << len(s)):
+        yield [item for j, item in enumerate(s) if (i >> j) & 1]
+
+
+def InfinteLoop():
+    """0, 1, 2, ... without end (`utils.py:117-121`; the name is the reference's)."""
+    i = 0
+    while True:
+        yield i
+        i += 1
+

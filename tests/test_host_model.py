@@ -329,3 +329,17 @@ def test_profile_order_is_valid_never_worse_than_rcm_and_cheaper_on_cube_trusses
     np.testing.assert_array_equal(batch.joint_order(p, perm), perm)
     with pytest.raises(ValueError):
         batch.joint_order(p, perm[:3])
+
+
+def test_small_utilities_of_the_reference():
+    from python_stable_3d_truss_analysis_amd import utils
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    assert list(utils.GetPowerset([0, 1, 2])) == [[], [0], [1], [0, 1], [2], [0, 2], [1, 2], [0, 1, 2]]
+    loop = utils.InfinteLoop()
+    assert [next(loop) for _ in range(4)] == [0, 1, 2, 3]
+    data = H.load_json("bar-25_input_0")
+    truss = Truss(3).LoadFromJSON(data=data)
+    is_truss, as_dict = gen.TrussDataAugmenter.IsTrussClass(truss)
+    assert is_truss and as_dict["member"] == truss.Serialize()["member"]
+    assert gen.TrussDataAugmenter.IsTrussClass(data) == (False, data)
+
