@@ -19,7 +19,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 joint order INSIDE the timed step (batch.RaggedSolver), solves/s + roofline fractions
   dataset       BASELINE config 5 at every N: samples/s of data.dataset_chunks (generation, order, two solves and
                 graph features on the device)
-  pcie_inclusive, given_joint_order, dense_mode_potrf   informational legs at N = 1
+  pcie_inclusive, given_joint_order, dense_mode_potrf, ga_generation (BASELINE config 4)   informational legs at N = 1
 """
 import argparse
 import json
@@ -353,6 +353,33 @@ def dataset_leg(args, device, torch, barrier, reduce_max, rank, world):
             "seconds": elapsed, "solves_per_sample": 2, "info_nonzero_rank0": bad, "rank0_samples": seen,
             "note": "data.dataset_chunks: generation, joint order, two solves and graph features per sample, all on "
                     "the device (no host work per sample); tensors left on the device; mixed cube trusses of 8..190 cubes"}
+
+
+def ga_leg(device, torch):
+    """BASELINE config 4 (informational, rank 0 at N = 1): one GA generation on bar-120 with nPop = 1024 - every
+    fitness evaluation of the generation in ONE batched solve (the fused small-system kernel with the constraint
+    reductions, reference ga.py:139-160), wall time per generation evaluation."""
+    import random
+    from python_stable_3d_truss_analysis_amd import MemberType, Truss
+    from python_stable_3d_truss_analysis_amd.ga import GA
+    truss = Truss(3).LoadFromJSON(data=load_case("bar-120_input_0"))
+    state = random.getstate()
+    random.seed(0)
+    types = [MemberType(i, random.uniform(1e7, 3e7), random.uniform(0.1, 1.0)) for i in range(1, 21)]   # example.py:186
+    ga = GA(truss, types, nIteration=3, nPop=1024, nElite=256)
+    pop = ga.Initialize()
+    random.setstate(state)
+    ga.GetFitnessBatch(pop)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        fit = ga.GetFitnessBatch(pop)
+    dt = (time.perf_counter() - t0) / reps
+    return {"nPop": 1024, "truss": "bar-120 (120 members, 111 free DOFs), 20 member types", "ms_per_generation_eval": dt * 1e3,
+            "fitness_evals_per_s": 1024 / dt, "feasible_in_population": int(sum(1 for f in fit if f[1] and f[2])),
+            "note": "wall time of GA.GetFitnessBatch (gene matrix -> sections on the device -> trs_solve_small with "
+                    "the fitness reductions -> one download); informational"}
 
 
 def launch_ranks(n):
@@ -718,6 +745,11 @@ def main():
             line["cube_batch"] = cube
         if dataset is not None:
             line["dataset"] = dataset
+        if world == 1 and not args.no_pcie:   # (the informational legs' switch)
+            try:
+                line["ga_generation"] = ga_leg(device, torch)
+            except Exception as exc:
+                line["ga_generation"] = {"error": repr(exc)}
         if given is not None:
             line["given_joint_order"] = given
         if dense_ms is not None:
