@@ -257,3 +257,40 @@ def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
         import torch
         gpu.RaggedSolver(packed, host_io=({f: torch.from_numpy(getattr(packed, f)) for f in gpu.RaggedSolver.GATHER},
                                           {}))
+
+
+def _random_trusses(rng, count):
+    """Irregular small trusses: random joints (some coincident coordinates), random members incl. parallel ones
+    and members between supports, every support type incl. rollers, isolated joints, several components, 2D
+    and 3D - most of them mechanisms (irrelevant for the ORDER, which only reads topology and coordinates)."""
+    datas = []
+    for k in range(count):
+        dim = 2 if k % 5 == 0 else 3
+        nJ = int(rng.integers(2, 40))
+        pts = np.round(rng.uniform(0, 10, size=[nJ, dim]), 1 if k % 3 else 0)          # coarse grid: ties in the bins
+        kinds = ["NO", "PIN", "ROLLER_X", "ROLLER_Y"] + (["ROLLER_Z"] if dim == 3 else [])
+        sup = rng.choice(kinds, size=nJ, p=[0.6, 0.2] + [0.2 / (len(kinds) - 2)] * (len(kinds) - 2))
+        nM = int(rng.integers(1, 4 * nJ))
+        ends = rng.integers(0, nJ, size=[nM, 2])
+        ends[ends[:, 0] == ends[:, 1], 1] = (ends[ends[:, 0] == ends[:, 1], 1] + 1) % nJ
+        if k % 4 == 0 and nM > 2:
+            ends[1] = ends[0]                                                       # a parallel member
+            ends[2] = ends[0][::-1]
+        datas.append({"joint": [[pts[j].tolist(), str(sup[j])] for j in range(nJ)],
+                      "force": [[int(j), rng.uniform(-5, 5, size=dim).tolist()] for j in rng.choice(nJ, size=min(3, nJ), replace=False)],
+                      "member": [[ends[m].tolist(), [1.0, 1e7, 0.1]] for m in range(nM)]})
+    return datas
+
+
+def test_device_order_on_irregular_trusses_with_every_support_kind(gpu):
+    rng = np.random.default_rng(42)
+    packed = gpu.pack_json(_random_trusses(rng, 400))
+    for effort in (2, 1, 0):
+        got = _device_order(gpu, packed, effort)
+        perm, choice = gpu.profile_permutation(packed, return_choice=True, effort=effort)
+        np.testing.assert_array_equal(got["choice"], choice)
+        np.testing.assert_array_equal(got["perm"], perm)
+        np.testing.assert_array_equal(got["reach"], gpu.envelope_reach(packed, perm))
+        want = gpu.permute_joints(packed, perm)
+        for field in ("xyz", "conn", "cbits", "loads"):
+            np.testing.assert_array_equal(got[field], getattr(want, field), err_msg=field)
