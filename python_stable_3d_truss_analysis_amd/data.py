@@ -424,8 +424,10 @@ def dataset_chunks(n_samples, rank=0, world=1, chunk=16384, seed=0, numCubeRange
         for k in mine:
             first, count = span(k)
             sizes = dataset_sizes(seed, first, count, numCubeRange)
+            # (padded widths in steps of 8 joints / 64 members: the chunks of a stream then share a few tensor
+            # shapes, which the caching allocator re-uses, instead of growing its pools chunk after chunk)
             meta, inputs = generate_cube_batch_device(sizes, gridRange=gridRange, seed=seed, first_index=first,
-                                                      device=device, **generator_args)
+                                                      device=device, pad_to=(8, 64), **generator_args)
             tensors = feature_tensors_device(meta, fixedMemberType, taskType, forceScale, displaceScale,
                                              positionScale, device, reorder, device_inputs=inputs)
             tensors["inputs"] = inputs

@@ -169,7 +169,8 @@ def generate_cube_batch_device(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 
                                forceRange=((-30000, 30000), (-30000, 30000), (-30000, 30000)),
                                nForceRange=None, method=GenerateMethod.Random, linkType=LinkType.Random,
                                memberTypes=((1., 1e7, 0.1),), isAllowParallel=False, seed=0,
-                               isAddPinSupport=True, first_index=0, device=None, return_retries=False):
+                               isAddPinSupport=True, first_index=0, device=None, return_retries=False,
+                               pad_to=(1, 1)):
     """`generate_cube_batch` ON THE GPU (`trs_cubegen_dev`, `csrc/cubegen.hip`): the same trusses, bit for bit, as
     the host generator gives for the same arguments (same per-truss streams keyed by (seed, first_index + b)),
     written straight into device tensors - nothing of the batch ever exists on the host.
@@ -177,7 +178,9 @@ def generate_cube_batch_device(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 
     Returns `(sizes, tensors)`: `sizes` = `batch.BatchSizes` (nJ, nM, n_free per truss on the host: they decide
     buckets and slab shapes), `tensors` = dict of device tensors by `DeviceBatch.INPUT_FIELDS` name, padded to
     the batch's own maxima.  Two passes like the host generator (sizes only, then the arrays); one
-    synchronisation in between for the maxima."""
+    synchronisation in between for the maxima.  `pad_to=(j, m)`: the padded widths are rounded up to multiples of
+    j joints / m members (a stream of chunks then repeats a few tensor shapes instead of one per chunk, which
+    the caching allocator can reuse; the extra padding is inert)."""
     import torch
     from . import _capi
     from .batch import BatchSizes, _require_gpu
@@ -212,7 +215,8 @@ def generate_cube_batch_device(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 
     if B and h_status[1]:
         raise RuntimeError("trs_cubegen_dev: a truss does not fit the grid's bounds")
     retries = int(h_status[0])
-    jm, mm = max(1, int(h_nJ.max(initial=1))), max(1, int(h_nM.max(initial=1)))
+    up_to = lambda v, q: (max(1, int(v)) + int(q) - 1) // int(q) * int(q)
+    jm, mm = up_to(h_nJ.max(initial=1), pad_to[0]), up_to(h_nM.max(initial=1), pad_to[1])
     f64 = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
     tensors = {"xyz": f64(B, jm, 3), "loads": f64(B, jm, 3), "cbits": torch.empty([B, jm], dtype=torch.uint8, device=dev),
                "conn": torch.empty([B, mm, 2], dtype=torch.int32, device=dev), "E": f64(B, mm), "A": f64(B, mm),

@@ -227,10 +227,15 @@ def test_dataset_chunks_sharding_is_invariant():
     for first in single:
         p0, t0 = single[first]
         p1, t1 = seen[first]
-        np.testing.assert_array_equal(p0.xyz, p1.xyz)
-        assert not t0["info"].any()
-        for key in ("joint_x", "member_x", "joint_y", "member_y"):
-            assert torch.equal(t0[key], t1[key])
+        nJ, nM = p0.xyz.shape[1], p0.conn.shape[1]               # the device chunks pad to rounded widths
+        assert p1.xyz.shape[1] >= nJ and p1.xyz.shape[1] % 8 == 0 and p1.conn.shape[1] % 64 == 0
+        np.testing.assert_array_equal(p0.xyz, p1.xyz[:, :nJ])
+        np.testing.assert_array_equal(p0.nJ, p1.nJ)
+        np.testing.assert_array_equal(p0.nM, p1.nM)
+        assert not t0["info"].any() and not t1["info"].any()
+        for key, width in (("joint_x", nJ), ("member_x", nM), ("joint_y", nJ), ("member_y", nM)):
+            assert torch.equal(t0[key], t1[key][:, :width])
+            assert not t1[key][:, width:].any()                  # ... and the extra padding rows are zeros
     # other chunk size: same samples, in every chunk (the sizes are keyed by the global index, not the chunk)
     for first, p, t in data.dataset_chunks(700, chunk=128, generate="host", **kw):
         base, off = single[first // 256 * 256][0], first % 256
