@@ -268,6 +268,31 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world)
     info_bad = int((solver.info != 0).sum().item())
     if rank != 0:
         return None
+    host_fed = None
+    if world == 1 and not args.no_pcie:
+        # informational: the same batch from page-locked HOST arrays to page-locked host results, one call
+        # (set-up, bucket pulls, device order + solves, pushes: `batch.solve_batch_streamed`)
+        try:
+            pinned, pool = packed.to_packed(tensors).pinned(), batch.ResultPool()
+            for _ in range(2):
+                batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                got = batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
+            dt = (time.perf_counter() - t0) / reps
+            nJ64, nM64 = packed.nJ.astype(np.int64), packed.nM.astype(np.int64)
+            host_fed = {"solves_per_s": packed.B / dt, "ms_per_call": dt * 1e3,
+                        "h2d_live_bytes": int((nJ64 * 49 + nM64 * 24).sum()),
+                        "d2h_live_bytes": int((nJ64 * 48 + nM64 * 8).sum()) + 4 * packed.B,
+                        "info_nonzero": int((got.info != 0).sum()),
+                        "note": "host arrays in -> host results out per CALL of batch.solve_batch_streamed (set-up "
+                                "included): buckets pulled over PCIe by the gather kernel (live bytes only), ordered "
+                                "and solved on the device, results pushed into page-locked arrays; copy kernels on "
+                                "compute units of their own; never the leg's value"}
+            del pinned, pool, got
+        except Exception as exc:   # (an informational leg must not take the line down)
+            host_fed = {"error": repr(exc)}
     # executed matrix-core work and algorithmic bytes of this rank's batch, from the envelope metadata of every
     # bucket (the buckets share one workspace: re-assemble bucket by bucket to read it)
     flops = bytes_alg = tiles = 0.0
@@ -321,7 +346,7 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world)
                                                "the bucket gather / scatter copies are overhead, not counted",
                                  "bytes_per_step": bytes_alg, "by_stage": per_stage},
                          "stored_tiles_per_truss": tiles / max(1, packed.B)},
-            "device_generate_s": t_gen,
+            "device_generate_s": t_gen, "host_fed": host_fed,
             "note": "generated on the device, resident in generator order; one launch pipeline per size bucket on a "
                     "shared workspace"}
 

@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TRS_ABI_VERSION 7
+#define TRS_ABI_VERSION 8
 
 /* trs_assemble flags */
 #define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests); implies the slab form */
@@ -271,15 +271,35 @@ int trs_cubegen_dev(int B, uint64_t seed, int gx, int gy, int gz, const int32_t 
  *   scatter == 0:  dst[k] + i * dst_pitch[k]        <-  src[k] + rows[i] * src_pitch[k]     (gather)
  *   scatter != 0:  dst[k] + rows[i] * dst_pitch[k]  <-  src[k] + i * src_pitch[k]           (scatter)
  * fill_to (or NULL): behind the copied prefix the destination row is ZEROED up to fill_to[k] bytes (a scatter into
- * rows wider than the bucket's).  src / dst / pitches / widths / fill_to are HOST arrays of device pointers and
- * byte counts (read at call time); rows is a device array of int64 row indices (distinct for a scatter).
+ * rows wider than the bucket's).
+ * counts / elem (or NULL, and counts[k] may be NULL): counts[k] is a DEVICE array of int32, one per bucket row i - only
+ * min(width[k], counts[k][i] * elem[k]) bytes of that row are live and copied (the nJ or nM of the truss times the
+ * bytes per joint / member); the rest of the row up to fill_to[k] is zeroed, not copied - over PCIe only live
+ * bytes cross.
+ * live (or NULL; scatter only; live[k] may be NULL): live[k] is a DEVICE array of int32, one per row of the FAR
+ * array dst[k], that states an invariant of that array: "row r is zero behind byte live[k][r]".  The scatter
+ * then zeroes only [copied bytes, live[k][r]) - what the previous writer of that row left - and records the new
+ * extent (fill_to[k] is ignored for such a field): results pushed again and again into the same page-locked
+ * arrays pay for their zero padding once, when the array is created (batch.ResultPool).
+ * src / dst / pitches / widths / fill_to / counts / elem / live are HOST arrays of device pointers and byte
+ * counts (read at call time); rows is a device array of int64 row indices (distinct for a scatter).
  * Either side may be page-locked HOST memory (mapped into the device's address space): the gather then pulls a
  * bucket's rows over PCIe straight out of the caller's host batch, the scatter pushes results into the caller's
  * host arrays; max_blocks > 0 keeps such a launch to that many work-groups (it needs bytes in flight, not CUs);
  * 0 = default. */
 int trs_copy_rows(int nfields, const void *const *src, const size_t *src_pitch, void *const *dst,
-                  const size_t *dst_pitch, const size_t *width, const size_t *fill_to, int count,
+                  const size_t *dst_pitch, const size_t *width, const size_t *fill_to,
+                  const int32_t *const *counts, const size_t *elem, int32_t *const *live, int count,
                   const int64_t *rows, int scatter, int max_blocks, void *stream);
+
+/* A stream whose kernels run only on the compute units set in `cu_mask` (bit i % 32 of word i / 32 = logical CU i
+ * of the current device; on MI355X consecutive bits go round the eight XCDs, so bits 0-7 are ONE CU of each XCD).
+ * The host-fed pipeline gives its pull and push kernels (trs_copy_rows on page-locked host memory) a few CUs of
+ * their own and the solver kernels the rest: a copy wave then never waits for registers the factorisation holds,
+ * nor takes them from it.  The stream is created non-blocking; destroy it with trs_stream_destroy after the work
+ * queued on it has finished.  No counterpart in the reference (plumbing of ABI 8). */
+int trs_stream_create_masked(const uint32_t *cu_mask, int n_words, void **stream);
+int trs_stream_destroy(void *stream);
 
 /* The whole Truss.Solve() pipeline (truss.py:329-364) on one stream: trs_solve_small when the batch
  * shape qualifies (the slab, uf, work and env arguments are then not touched), otherwise

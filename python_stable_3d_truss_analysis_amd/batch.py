@@ -945,6 +945,82 @@ class SolverWorkspace:
         return self.buf
 
 
+class _MaskedStreams:
+    """The three streams of the host-fed pipeline with their compute units set apart (`trs_stream_create_masked`):
+    pull and push get CUs of their own - consecutive mask bits go round the XCDs, so eight are one CU of every
+    XCD - and the solver kernels the rest.  Destroyed with the object."""
+
+    def __init__(self, torch, dev, lib, pull_cus, push_cus):
+        import ctypes
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        if not (pull_cus > 0 and push_cus > 0 and pull_cus + push_cus < n_cu):
+            raise ValueError(f"cannot set {pull_cus} + {push_cus} copy CUs apart on a device with {n_cu}")
+        words = (n_cu + 31) // 32
+        sets = (range(0, pull_cus), range(pull_cus + push_cus, n_cu), range(pull_cus, pull_cus + push_cus))   # pull, run, push
+        self.lib, self.handles, self.streams = lib, [], []
+        with torch.cuda.device(dev):
+            for cus in sets:
+                mask = (ctypes.c_uint32 * words)()
+                for c in cus:
+                    mask[c // 32] |= 1 << (c % 32)
+                handle = ctypes.c_void_p()
+                _capi.check(lib.trs_stream_create_masked(mask, words, ctypes.byref(handle)), "trs_stream_create_masked")
+                self.handles.append(handle)
+                self.streams.append(torch.cuda.ExternalStream(handle.value, device=dev))
+        self.torch, self.dev = torch, dev
+
+    def __iter__(self):
+        return iter(self.streams)
+
+    def __del__(self):
+        try:
+            self.torch.cuda.synchronize(self.dev)
+            for handle in self.handles:
+                self.lib.trs_stream_destroy(handle)
+        except Exception:   # interpreter shutdown
+            pass
+
+
+def _flow_shop_order(groups, packed, n_pad_of, rule="johnson"):
+    """Order of the buckets in the host-fed pipeline.  Every bucket is pulled over PCIe, then solved; the link and
+    the chip each take the buckets one after the other - a two-machine flow shop, for which Johnson's rule gives the
+    shortest makespan: first the buckets that take longer to solve than to pull, by increasing pull time (the chip
+    starts early and never runs dry), then the others by decreasing solve time (what is left exposed at the end
+    is the smallest solve).  The two times are estimates - live input bytes at the rate a pull reaches beside the
+    solves, and count x n_pad^2 at the rate the factorisation of cube trusses runs at - and only their ratio
+    matters.  Small buckets are link-bound, large ones chip-bound; smallest-first (`rule="small"`) leaves the chip
+    waiting in the first third of the step and the link idle in the last."""
+    if rule == "small":
+        return sorted(groups, key=lambda idx: len(idx) * n_pad_of(idx) ** 2)
+    if rule == "large":
+        return sorted(groups, key=lambda idx: -len(idx) * n_pad_of(idx) ** 2)
+    nJ, nM = packed.nJ.astype(np.int64), packed.nM.astype(np.int64)
+    pull = lambda idx: float((nJ[idx] * 49 + nM[idx] * 24).sum()) / 45e9
+    solve = lambda idx: len(idx) * float(n_pad_of(idx)) ** 2 * 2.0e-12
+    chip_bound = sorted((g for g in groups if pull(g) < solve(g)), key=pull)
+    link_bound = sorted((g for g in groups if pull(g) >= solve(g)), key=lambda g: -solve(g))
+    return chip_bound + link_bound
+
+
+def _pipeline_streams(torch, dev, lib):
+    """(pull, run, push) streams of `RaggedSolver`'s host-fed pipeline.  `TRS_PCIE_CUS="pull,push"` compute units
+    are set apart for the copy kernels (default 16 + 8 = two per XCD for the pull, one for the push: the row copies reach the
+    link's rate on those, `tools/masked_pipeline_check.py`); 0 = three ordinary streams (the copies then compete
+    with the factorisation for registers on every CU)."""
+    spec = os.environ.get("TRS_PCIE_CUS", "16,8")
+    key = (str(dev), spec)
+    if key not in _PIPELINE_STREAMS:   # (a queue with a CU mask takes ~20 ms to create: once per process and device)
+        pull_cus, push_cus = int(spec.split(",")[0]), int(spec.split(",")[-1])
+        if pull_cus <= 0:
+            _PIPELINE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        else:
+            _PIPELINE_STREAMS[key] = _MaskedStreams(torch, dev, lib, pull_cus, push_cus)
+    return _PIPELINE_STREAMS[key]
+
+
+_PIPELINE_STREAMS = {}
+
+
 class RaggedSolver:
     """A RAGGED batch (trusses of very different sizes: the reference's `GenerateRandomCubeTrusses` loop,
     `generate.py:342-374`, BASELINE config 3) resident on one device in the caller's order and numbering, set
@@ -983,10 +1059,14 @@ class RaggedSolver:
         self.host_io = host_io is not None
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         if self.host_io:
-            self.inputs = {f: host_io[0][f] for f in self.GATHER}
+            # (the sizes nJ / nM come from `packed` and go up once, with the bucket index lists: they tell the copy
+            # kernels how much of a row is live, so that nothing but live bytes crosses the link)
+            self.gather_fields = tuple(f for f in self.GATHER if f not in ("nJ", "nM"))
+            self.inputs = {f: host_io[0][f] for f in self.gather_fields}
             if not all(t.is_pinned() and t.is_contiguous() for t in self.inputs.values()):
                 raise ValueError("host_io inputs must be contiguous page-locked tensors (PackedBatch.pinned())")
         else:
+            self.gather_fields = self.GATHER
             self.inputs = {f: (tensors[f].contiguous() if tensors is not None else up(getattr(packed, f))) for f in self.GATHER}
         plan = order_plan(reorder, nJ_max, nM_max) if B else None
         self.plan = plan
@@ -1004,6 +1084,11 @@ class RaggedSolver:
             want = {"u": (B, nJ_max, 3), "f_ext": (B, nJ_max, 3), "N": (B, nM_max), "info": (B,)}
             if not all(out[k].is_pinned() and out[k].is_contiguous() and tuple(out[k].shape) == want[k] for k in want):
                 raise ValueError("host_io outputs must be contiguous page-locked tensors of the padded result shapes")
+            # `live` (optional): per result array a device int32 [B] "row r is zero behind byte live[r]"
+            # (`ResultPool.take_tracked`); without it every push zero-fills its rows to their full width
+            self.live = dict(out.get("live") or {})
+            if any(t.device != dev or t.dtype != torch.int32 or tuple(t.shape) != (B,) for t in self.live.values()):
+                raise ValueError("host_io live extents must be int32 [B] tensors on the solver's device")
         else:
             self.u, self.f_ext = z([B, nJ_max, 3], torch.float64), z([B, nJ_max, 3], torch.float64)
             self.N, self.info = z([B, nM_max], torch.float64), z([B], torch.int32)
@@ -1012,7 +1097,9 @@ class RaggedSolver:
         slab_of = lambda idx: len(idx) * n_pad_of(idx) * (n_pad_of(idx) + 16)
         # largest slab first (the shared workspace is sized once) - in the host-fed pipeline SMALLEST first: the
         # device starts after a short pull, and what is exposed at the end is a small bucket's push
-        groups.sort(key=(lambda idx: slab_of(idx)) if self.host_io else (lambda idx: -slab_of(idx)))
+        groups.sort(key=lambda idx: -slab_of(idx))
+        if self.host_io:
+            groups = _flow_shop_order(groups, packed, n_pad_of, os.environ.get("TRS_HOSTFED_ORDER", "johnson"))
         self.buckets = []
         need = {"S": 0, "uf": 0, "work": 0, "env": 0, "raw_j": 0, "raw_m": 0}
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
@@ -1023,6 +1110,8 @@ class RaggedSolver:
                    "cbits": e([Bb, nJ_b], torch.uint8), "conn": e([Bb, nM_b, 2], torch.int32),
                    "E": e([Bb, nM_b], torch.float64), "A": e([Bb, nM_b], torch.float64),
                    "nJ": e([Bb], torch.int32), "nM": e([Bb], torch.int32)}
+            if self.host_io:
+                sub["nJ"], sub["nM"] = up(packed.nJ[idx].astype(np.int32)), up(packed.nM[idx].astype(np.int32))
             sub["rho"] = sub["A"]   # placeholder of the right shape: no kernel of the solve reads the densities
             small = bool(self.lib.trs_solve_small_fits(nJ_b, nM_b, n_b))
             renumbered = plan is not None and not small   # the fused small-system kernel gains nothing from an order
@@ -1074,7 +1163,7 @@ class RaggedSolver:
                                  "cbits": db.cbits, "loads": db.loads}
         self._tables = self._copy_tables()
         if self.host_io:
-            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            self._streams = _pipeline_streams(torch, dev, self.lib)
 
     def _copy_tables(self):
         """ctypes argument arrays of the gather / scatter launches of every bucket (all device pointers are
@@ -1086,25 +1175,36 @@ class RaggedSolver:
         for bk in self.buckets:
             db = bk["dev"]
             pairs = []
-            for f in self.GATHER:
+            for f in self.gather_fields:
                 if bk["order_on_device"] and f in self.JOINT_ORDERED:
-                    pairs.append((self.inputs[f], bk["raw"][f]))          # caller's numbering -> input of the order
+                    pairs.append((f, self.inputs[f], bk["raw"][f]))       # caller's numbering -> input of the order
                 elif bk["renumbered"] and f in self.JOINT_ORDERED:
-                    pairs.append((self.ordered[f], getattr(db, f)))        # host plan: renumbered at set-up
+                    pairs.append((f, self.ordered[f], getattr(db, f)))     # host plan: renumbered at set-up
                 else:
-                    pairs.append((self.inputs[f], getattr(db, f)))
+                    pairs.append((f, self.inputs[f], getattr(db, f)))
             if bk["renumbered"] and not bk["order_on_device"]:
-                pairs.append((self.ordered["perm"], db.joint_out))
-            outs = [(db.u, self.u), (db.f_ext, self.f_ext), (db.N, self.N), (db.info, self.info)]
+                pairs.append(("perm", self.ordered["perm"], db.joint_out))
+            outs = [("u", db.u, self.u), ("f_ext", db.f_ext, self.f_ext), ("N", db.N, self.N), ("info", db.info, self.info)]
+            # host-fed: only the live part of a row crosses the link - (count array, bytes per element) by field
+            per_joint = {"xyz": 24, "loads": 24, "cbits": 1, "u": 24, "f_ext": 24}
+            per_member = {"conn": 8, "E": 8, "A": 8, "N": 8}
 
             def pack(pairs, trimmed_is_dst):
                 n = len(pairs)
-                src, dst = (P * n)(*[a.data_ptr() for a, _ in pairs]), (P * n)(*[b.data_ptr() for _, b in pairs])
-                sp, dp = (Z * n)(*[row_bytes(a) for a, _ in pairs]), (Z * n)(*[row_bytes(b) for _, b in pairs])
-                width = (Z * n)(*[row_bytes(b if trimmed_is_dst else a) for a, b in pairs])
-                # results pushed into HOST rows: the whole row is written, zeros behind the bucket's width
-                fill = (Z * n)(*[row_bytes(b) for _, b in pairs]) if (self.host_io and not trimmed_is_dst) else None
-                return n, src, sp, dst, dp, width, fill
+                src, dst = (P * n)(*[a.data_ptr() for _, a, _ in pairs]), (P * n)(*[b.data_ptr() for _, _, b in pairs])
+                sp, dp = (Z * n)(*[row_bytes(a) for _, a, _ in pairs]), (Z * n)(*[row_bytes(b) for _, _, b in pairs])
+                width = (Z * n)(*[row_bytes(b if trimmed_is_dst else a) for _, a, b in pairs])
+                if not self.host_io:
+                    return n, src, sp, dst, dp, width, None, None, None, None
+                counts = (P * n)(*[db.nJ.data_ptr() if f in per_joint else (db.nM.data_ptr() if f in per_member else None)
+                                   for f, _, _ in pairs])
+                elem = (Z * n)(*[per_joint.get(f, per_member.get(f, 0)) for f, _, _ in pairs])
+                # pulled rows are zeroed behind their live part on the device; pushed rows up to the full row of the
+                # host array, or - where the array's live extents are tracked - only over what the last writer left
+                fill = (Z * n)(*[row_bytes(b) for _, _, b in pairs])
+                live = None if trimmed_is_dst else (P * n)(*[self.live[f].data_ptr() if f in self.live else None
+                                                             for f, _, _ in pairs])
+                return n, src, sp, dst, dp, width, fill, counts, elem, live
             tables.append((pack(pairs, True), pack(outs, False)))
         return tables
 
@@ -1127,7 +1227,13 @@ class RaggedSolver:
             return out
 
         # work-groups of a copy kernel whose other side is host memory (it needs bytes in flight, not CUs)
-        PCIE_BLOCKS = int(os.environ.get("TRS_PCIE_BLOCKS", "32"))
+        # (the pushes are kept to a handful of work-groups: stores to host memory are fire-and-forget, and beyond
+        # ~35 GB/s they back up in the queues the solver's own stores stand in - its step beside a saturating
+        # push takes 89 instead of 60 ms, beside one of four work-groups 64, `tools/masked_pipeline_check.py`; six
+        # is where the pushes still keep up with the solves of the cube batch)
+        masked = self.host_io and isinstance(self._streams, _MaskedStreams)
+        PCIE_BLOCKS = int(os.environ.get("TRS_PCIE_BLOCKS", "64" if masked else "32"))
+        PUSH_BLOCKS = int(os.environ.get("TRS_PCIE_PUSH_BLOCKS", "6" if masked else str(PCIE_BLOCKS)))
         with torch.cuda.device(self.device):
             if not self.host_io:
                 stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -1141,16 +1247,17 @@ class RaggedSolver:
                         *scatter, bk["count"], bk["rows"].data_ptr(), 1, 0, stream), "trs_copy_rows (scatter)"))
                 return
             # host-fed pipeline: pull of bucket k + 1 | order + solve of bucket k | push of bucket k - 1
-            s_up, s_run, s_down = self._streams
+            s_up, s_run, s_down = tuple(self._streams)
             caller = torch.cuda.current_stream(self.device)
             timing = record is not None
             begin = torch.cuda.Event(enable_timing=timing)
             begin.record(caller)
-            for st in self._streams:
+            for st in (s_up, s_run, s_down):
                 st.wait_event(begin)
             mark = lambda name, stream: record.append((name, begin, self._marked(stream))) if timing else None
             for k, (bk, (gather, scatter)) in enumerate(zip(self.buckets, self._tables)):
                 with torch.cuda.stream(s_up):
+                    mark(f"bucket {k} pull begins", s_up)
                     _capi.check(self.lib.trs_copy_rows(*gather, bk["count"], bk["rows"].data_ptr(), 0, PCIE_BLOCKS,
                                                        s_up.cuda_stream), "trs_copy_rows (pull)")
                     pulled = torch.cuda.Event()
@@ -1167,7 +1274,8 @@ class RaggedSolver:
                     mark(f"bucket {k} solved", s_run)
                 with torch.cuda.stream(s_down):
                     s_down.wait_event(solved)
-                    _capi.check(self.lib.trs_copy_rows(*scatter, bk["count"], bk["rows"].data_ptr(), 1, PCIE_BLOCKS,
+                    mark(f"bucket {k} push begins", s_down)
+                    _capi.check(self.lib.trs_copy_rows(*scatter, bk["count"], bk["rows"].data_ptr(), 1, PUSH_BLOCKS,
                                                        s_down.cuda_stream), "trs_copy_rows (push)")
                     mark(f"bucket {k} pushed", s_down)
             done = torch.cuda.Event()
@@ -1292,13 +1400,49 @@ class ResultPool:
 
     def __init__(self):
         self._bufs = {}
+        self._live = {}
 
     def take(self, torch, key, shape, dtype):
+        self._live.pop(key, None)   # whoever takes the plain buffer may write anything anywhere in it
         buf = self._bufs.get(key)
         if buf is None or tuple(buf.shape) != tuple(shape) or buf.dtype != dtype:
             buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
             self._bufs[key] = buf
         return buf
+
+    def take_tracked(self, torch, key, shape, dtype, device):
+        """The buffer together with its LIVE EXTENTS: a device int32 tensor, one entry per row, that states "row r
+        is zero behind byte live[r]".  `trs_copy_rows` keeps the statement true while it pushes results into the
+        rows (it zeroes only what the previous writer of a row left and records the new extent), so the zero
+        padding of the padded result arrays is paid for once - the buffer is created zeroed - instead of crossing
+        the link with every call.  Anyone else who writes into the buffer must take it with `take` (or call
+        `invalidate`): the next tracked use then starts from "nothing known" and zero-fills whole rows once."""
+        shape = tuple(shape)
+        row_bytes = int(np.prod(shape[1:], dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+        buf, live = self._bufs.get(key), self._live.get(key)
+        if buf is None or tuple(buf.shape) != shape or buf.dtype != dtype:
+            buf = torch.zeros(shape, dtype=dtype, pin_memory=True)
+            self._bufs[key] = buf
+            live = torch.zeros([shape[0]], dtype=torch.int32, device=device)
+        elif live is None or live.device != torch.device(device) or live.shape[0] != shape[0]:
+            live = torch.full([shape[0]], row_bytes, dtype=torch.int32, device=device)
+        self._live[key] = live
+        return buf, live
+
+    def invalidate(self):
+        """Forget the live extents (after writing into pool buffers by hand)."""
+        self._live.clear()
+
+
+def host_result_arrays(torch, pool, B, nJ_max, nM_max, device):
+    """The page-locked result arrays of a host-fed `RaggedSolver` (`host_io=(inputs, THIS)`) out of a
+    `ResultPool`, with their live extents."""
+    out, live = {}, {}
+    for name, shape in (("u", [B, nJ_max, 3]), ("f_ext", [B, nJ_max, 3]), ("N", [B, nM_max])):
+        out[name], live[name] = pool.take_tracked(torch, (0, name), shape, torch.float64, device)
+    out["info"] = pool.take(torch, (0, "info"), [B], torch.int32)
+    out["live"] = live
+    return out
 
 
 def solve_batch_streamed(packed: PackedBatch, device=None, reorder=True, pool=None, max_slab_bytes=48 << 30):
@@ -1313,10 +1457,7 @@ def solve_batch_streamed(packed: PackedBatch, device=None, reorder=True, pool=No
     torch, dev = _require_gpu(device)
     B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
     pool = pool if pool is not None else ResultPool()
-    host_out = {"u": pool.take(torch, (0, "u"), [B, nJ_max, 3], torch.float64),
-                "f_ext": pool.take(torch, (0, "f_ext"), [B, nJ_max, 3], torch.float64),
-                "N": pool.take(torch, (0, "N"), [B, nM_max], torch.float64),
-                "info": pool.take(torch, (0, "info"), [B], torch.int32)}
+    host_out = host_result_arrays(torch, pool, B, nJ_max, nM_max, dev)
     host_in = {f: torch.from_numpy(getattr(packed, f)) for f in RaggedSolver.GATHER}
     solver = RaggedSolver(packed, dev, reorder=reorder, max_slab_bytes=max_slab_bytes, host_io=(host_in, host_out))
     solver.step()

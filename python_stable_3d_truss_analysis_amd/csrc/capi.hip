@@ -22,7 +22,8 @@ int trs_cubegen_dev_launch(int, unsigned long long, int, int, int, const int*, i
                            int, int, const double*, int, int, int, double*, int*, double*, double*, double*, unsigned char*,
                            double*, int*, int*, int*, int*, long long, hipStream_t);
 int trs_copy_rows_launch(int, const void* const*, const size_t*, void* const*, const size_t*, const size_t*,
-                         const size_t*, int, const long long*, int, int, hipStream_t);
+                         const size_t*, const int* const*, const size_t*, int* const*, int, const long long*, int, int,
+                         hipStream_t);
 int trs_solve_small_fits(int, int, int);
 int trs_solve_small_launch(int, int, int, int, const double*, const int*, const double*, const double*,
                            const uint8_t*, const double*, const int*, const int*, double*, double*, double*,
@@ -131,13 +132,31 @@ int trs_cubegen_dev(int B, uint64_t seed, int gx, int gy, int gz, const int32_t*
 }
 
 int trs_copy_rows(int nfields, const void* const* src, const size_t* src_pitch, void* const* dst,
-                  const size_t* dst_pitch, const size_t* width, const size_t* fill_to, int count,
-                  const int64_t* rows, int scatter, int max_blocks, void* stream) {
+                  const size_t* dst_pitch, const size_t* width, const size_t* fill_to, const int32_t* const* counts,
+                  const size_t* elem, int32_t* const* live, int count, const int64_t* rows, int scatter,
+                  int max_blocks, void* stream) {
     if (nfields < 0 || count < 0 || max_blocks < 0) return (int)hipErrorInvalidValue;
     if (nfields > 0 && count > 0 && (!src || !src_pitch || !dst || !dst_pitch || !width || !rows))
         return (int)hipErrorInvalidValue;
-    return trs_copy_rows_launch(nfields, src, src_pitch, dst, dst_pitch, width, fill_to, count,
+    return trs_copy_rows_launch(nfields, src, src_pitch, dst, dst_pitch, width, fill_to, counts, elem, live, count,
                                 reinterpret_cast<const long long*>(rows), scatter, max_blocks, (hipStream_t)stream);
+}
+
+int trs_stream_create_masked(const uint32_t* cu_mask, int n_words, void** stream) {
+    if (!cu_mask || n_words <= 0 || !stream) return (int)hipErrorInvalidValue;
+    bool any = false;
+    for (int w = 0; w < n_words; ++w) any = any || cu_mask[w] != 0u;
+    if (!any) return (int)hipErrorInvalidValue;   // a stream with no compute unit would never run anything
+    hipStream_t s = nullptr;
+    hipError_t rc = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask);
+    if (rc != hipSuccess) return (int)rc;
+    *stream = (void*)s;
+    return 0;
+}
+
+int trs_stream_destroy(void* stream) {
+    if (!stream) return (int)hipErrorInvalidValue;
+    return (int)hipStreamDestroy((hipStream_t)stream);
 }
 
 int trs_joint_order(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const uint8_t* cbits,

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_host_side_helpers_of_the_abi():
     lib = _capi.load()
-    assert lib.trs_abi_version() == _capi.ABI_VERSION == 7
+    assert lib.trs_abi_version() == _capi.ABI_VERSION == 8
     assert lib.trs_assemble_work_bytes(244, 942, 696) % 256 == 0
     assert lib.trs_slab_rows(696) == 704 and lib.trs_slab_ld(696) == 720
     assert lib.trs_slab_rows(64) == 64 and lib.trs_slab_rows(65) == 128 and lib.trs_slab_rows(0) == 64
@@ -35,6 +35,11 @@ def test_host_side_helpers_of_the_abi():
     assert lib.trs_potrf_batched(1, None, 100, 64, None, None, None, None, None, 64, 0, None) != 0
     assert not hasattr(lib, "trs_set_option")        # ABI 7: no process-wide switches, flags per call
     assert lib.trs_env_ints(696) == 2 * (704 // 16) + 704 // 64 + 8
+    # ABI 8: masked streams refuse an empty mask (no compute unit) before touching the runtime
+    import ctypes
+    handle, empty = ctypes.c_void_p(), (ctypes.c_uint32 * 8)()
+    assert lib.trs_stream_create_masked(empty, 8, ctypes.byref(handle)) != 0 and handle.value is None
+    assert lib.trs_stream_create_masked(None, 0, None) != 0 and lib.trs_stream_destroy(None) != 0
 
 
 def test_host_library_exports_every_symbol_of_its_header():

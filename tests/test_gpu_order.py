@@ -212,16 +212,69 @@ def test_copy_rows_gathers_and_scatters_prefixes(gpu):
     src, dst = (P * 2)(full.data_ptr(), small.data_ptr()), (P * 2)(a.data_ptr(), b.data_ptr())
     sp, dp, w = (Z * 2)(37 * 24, 13), (Z * 2)(30 * 24, 11), (Z * 2)(30 * 24, 11)
     stream = torch.cuda.current_stream().cuda_stream
-    assert lib.trs_copy_rows(2, src, sp, dst, dp, w, None, 20, rows.data_ptr(), 0, 0, stream) == 0
+    assert lib.trs_copy_rows(2, src, sp, dst, dp, w, None, None, None, None, 20, rows.data_ptr(), 0, 0, stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(a, full[rows][:, :30]) and torch.equal(b, small[rows][:, :11])
     back_a, back_b = torch.zeros_like(full), torch.zeros_like(small)
     src2, dst2 = (P * 2)(a.data_ptr(), b.data_ptr()), (P * 2)(back_a.data_ptr(), back_b.data_ptr())
-    assert lib.trs_copy_rows(2, src2, dp, dst2, sp, w, None, 20, rows.data_ptr(), 1, 0, stream) == 0
+    assert lib.trs_copy_rows(2, src2, dp, dst2, sp, w, None, None, None, None, 20, rows.data_ptr(), 1, 0, stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(back_a[rows][:, :30], full[rows][:, :30]) and not back_a[:, 30:].any()
     assert torch.equal(back_b[rows][:, :11], small[rows][:, :11])
-    assert lib.trs_copy_rows(2, src, sp, dst, dp, (Z * 2)(10 ** 6, 11), None, 20, rows.data_ptr(), 0, 0, stream) != 0  # width > pitch
+    assert lib.trs_copy_rows(2, src, sp, dst, dp, (Z * 2)(10 ** 6, 11), None, None, None, None, 20, rows.data_ptr(), 0, 0,
+                             stream) != 0   # width > pitch
+
+
+def test_copy_rows_live_counts_and_tracked_extents(gpu):
+    """ABI 8: with per-row counts only the live elements of a row are copied, the rest of the destination row is
+    zeroed up to `fill_to`; a scatter into an array whose live extents are tracked zeroes exactly what the last
+    writer of a row left (the rest is zero by the array's invariant) and records the new extents."""
+    import ctypes
+    import torch
+    lib = gpu._capi.load()
+    rng = np.random.default_rng(1)
+    P, Z = ctypes.c_void_p, ctypes.c_size_t
+    stream = torch.cuda.current_stream().cuda_stream
+    nrow, wide, narrow = 40, 29, 21                                    # odd widths: byte-granular heads and tails
+    far3 = torch.from_numpy(rng.standard_normal([nrow, wide, 3])).cuda()          # 24-byte elements
+    far1 = torch.from_numpy(rng.integers(1, 255, size=[nrow, wide]).astype(np.uint8)).cuda()
+    rows = torch.from_numpy(rng.permutation(nrow)[:16].astype(np.int64)).cuda()
+    counts = torch.from_numpy(rng.integers(0, narrow + 1, size=16).astype(np.int32)).cuda()
+    counts[0], counts[1] = 0, narrow
+    near3 = torch.full([16, narrow, 3], float("nan"), dtype=torch.float64, device="cuda")
+    near1 = torch.full([16, narrow], 7, dtype=torch.uint8, device="cuda")
+    args = ((P * 2)(far3.data_ptr(), far1.data_ptr()), (Z * 2)(wide * 24, wide),
+            (P * 2)(near3.data_ptr(), near1.data_ptr()), (Z * 2)(narrow * 24, narrow), (Z * 2)(narrow * 24, narrow))
+    cnt, elem = (P * 2)(counts.data_ptr(), counts.data_ptr()), (Z * 2)(24, 1)
+    assert lib.trs_copy_rows(2, *args, (Z * 2)(narrow * 24, narrow), cnt, elem, None, 16, rows.data_ptr(), 0, 4, stream) == 0
+    torch.cuda.synchronize()
+    keep = (torch.arange(narrow, device="cuda")[None, :] < counts[:, None])
+    assert torch.equal(near3, torch.where(keep[:, :, None], far3[rows][:, :narrow], torch.zeros((), dtype=torch.float64, device="cuda")))
+    assert torch.equal(near1, torch.where(keep, far1[rows][:, :narrow], torch.zeros((), dtype=torch.uint8, device="cuda")))
+    # scatter back into tracked arrays: rows start "zero behind `live`" with junk below it
+    back3, back1 = torch.zeros_like(far3), torch.zeros_like(far1)
+    live3 = torch.from_numpy(rng.integers(0, wide + 1, size=nrow).astype(np.int32) * 24).cuda()
+    live1 = torch.from_numpy(rng.integers(0, wide + 1, size=nrow).astype(np.int32)).cuda()
+    col = torch.arange(wide, device="cuda")[None, :]
+    back3[(col * 24 < live3[:, None])] = 5.0
+    back1[(col < live1[:, None])] = 9
+    before3, before1 = back3.clone(), back1.clone()
+    sargs = ((P * 2)(near3.data_ptr(), near1.data_ptr()), (Z * 2)(narrow * 24, narrow),
+             (P * 2)(back3.data_ptr(), back1.data_ptr()), (Z * 2)(wide * 24, wide), (Z * 2)(narrow * 24, narrow))
+    live = (P * 2)(live3.data_ptr(), live1.data_ptr())
+    assert lib.trs_copy_rows(2, *sargs, None, cnt, elem, live, 16, rows.data_ptr(), 1, 4, stream) == 0
+    torch.cuda.synchronize()
+    want3, want1 = before3.clone(), before1.clone()
+    want3[rows] = 0.0
+    want1[rows] = 0
+    want3[rows, :narrow] = near3
+    want1[rows, :narrow] = near1
+    assert torch.equal(back3, want3) and torch.equal(back1, want1)      # untouched rows keep their content
+    assert torch.equal(live3[rows], counts * 24) and torch.equal(live1[rows], counts)
+    untouched = torch.ones(nrow, dtype=torch.bool, device="cuda")
+    untouched[rows] = False
+    assert torch.equal(live3[untouched], (before3[:, :, 0] != 0).sum(1).int()[untouched] * 24)
+    assert lib.trs_copy_rows(2, *args, None, cnt, (Z * 2)(0, 1), None, 16, rows.data_ptr(), 0, 0, stream) != 0   # element size 0
 
 
 def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
@@ -238,12 +291,20 @@ def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
     for reorder in (True, False):
         ref = want if reorder else gpu.solve_batch(packed)
         for attempt in range(2):
-            for k in ("u", "f_ext", "N"):                 # stale content of an earlier call must not survive
-                if (0, k) in pool._bufs:
+            if attempt == 1:                              # content written by hand must not survive either
+                for k in ("u", "f_ext", "N"):
                     pool._bufs[(0, k)].fill_(float("nan"))
+                pool.invalidate()
             got = gpu.solve_batch_streamed(pinned, reorder=reorder, pool=pool)
             for k in ("displace", "external", "internal", "info"):
                 np.testing.assert_array_equal(getattr(got, k), getattr(ref, k), err_msg=f"{k} reorder={reorder}")
+    # the same pool serves ANOTHER batch of the same padded shape: rows that shrink are zeroed behind their new
+    # extent (tracked live extents), rows that grow are simply written
+    other = packed.take(np.random.default_rng(9).permutation(packed.B))      # same padded shape, other rows
+    got = gpu.solve_batch_streamed(other.pinned(), reorder=True, pool=pool)
+    ref = gpu.solve_batch(other, reorder=True)
+    for k in ("displace", "external", "internal", "info"):
+        np.testing.assert_array_equal(getattr(got, k), getattr(ref, k), err_msg=f"second batch, {k}")
     keep = gpu.STREAMED_FROM
     gpu.STREAMED_FROM = 1000
     try:

@@ -23,10 +23,7 @@ same = all(np.array_equal(getattr(res, k), getattr(ref, k)) for k in ("displace"
 print(f"streamed (buckets pulled / solved / pushed): {dt:.3f} s = {B / dt / 1e6:.2f} M solves/s, bitwise equal: {same}")
 # where the streamed call's time goes: set-up (bucket tensors, workspace, index lists) vs the pipeline itself
 host_in = {f: torch.from_numpy(getattr(pinned, f)) for f in batch.RaggedSolver.GATHER}
-host_out = {"u": pool.take(torch, (0, "u"), [B, pinned.nJ_max, 3], torch.float64),
-            "f_ext": pool.take(torch, (0, "f_ext"), [B, pinned.nJ_max, 3], torch.float64),
-            "N": pool.take(torch, (0, "N"), [B, pinned.nM_max], torch.float64),
-            "info": pool.take(torch, (0, "info"), [B], torch.int32)}
+host_out = batch.host_result_arrays(torch, pool, B, pinned.nJ_max, pinned.nM_max, torch.device("cuda:0"))
 for _ in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     solver = batch.RaggedSolver(pinned, "cuda:0", reorder=True, max_slab_bytes=48 << 30, host_io=(host_in, host_out))
