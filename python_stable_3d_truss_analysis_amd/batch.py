@@ -991,15 +991,15 @@ def _flow_shop_order(groups, packed, n_pad_of, rule="johnson"):
     matters.  Small buckets are link-bound, large ones chip-bound; smallest-first (`rule="small"`) leaves the chip
     waiting in the first third of the step and the link idle in the last."""
     if rule == "small":
-        return sorted(groups, key=lambda idx: len(idx) * n_pad_of(idx) ** 2)
+        return sorted(groups, key=lambda idx: len(idx) * n_pad_of(idx) ** 2), 0
     if rule == "large":
-        return sorted(groups, key=lambda idx: -len(idx) * n_pad_of(idx) ** 2)
+        return sorted(groups, key=lambda idx: -len(idx) * n_pad_of(idx) ** 2), len(groups)
     nJ, nM = packed.nJ.astype(np.int64), packed.nM.astype(np.int64)
     pull = lambda idx: float((nJ[idx] * 49 + nM[idx] * 24).sum()) / 45e9
     solve = lambda idx: len(idx) * float(n_pad_of(idx)) ** 2 * 2.0e-12
     chip_bound = sorted((g for g in groups if pull(g) < solve(g)), key=pull)
     link_bound = sorted((g for g in groups if pull(g) >= solve(g)), key=lambda g: -solve(g))
-    return chip_bound + link_bound
+    return chip_bound + link_bound, len(chip_bound)
 
 
 def _pipeline_streams(torch, dev, lib):
@@ -1099,7 +1099,8 @@ class RaggedSolver:
         # device starts after a short pull, and what is exposed at the end is a small bucket's push
         groups.sort(key=lambda idx: -slab_of(idx))
         if self.host_io:
-            groups = _flow_shop_order(groups, packed, n_pad_of, os.environ.get("TRS_HOSTFED_ORDER", "johnson"))
+            groups, self._chip_bound_buckets = _flow_shop_order(groups, packed, n_pad_of,
+                                                                os.environ.get("TRS_HOSTFED_ORDER", "johnson"))
         self.buckets = []
         need = {"S": 0, "uf": 0, "work": 0, "env": 0, "raw_j": 0, "raw_m": 0}
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
@@ -1229,11 +1230,14 @@ class RaggedSolver:
         # work-groups of a copy kernel whose other side is host memory (it needs bytes in flight, not CUs)
         # (the pushes are kept to a handful of work-groups: stores to host memory are fire-and-forget, and beyond
         # ~35 GB/s they back up in the queues the solver's own stores stand in - its step beside a saturating
-        # push takes 89 instead of 60 ms, beside one of four work-groups 64, `tools/masked_pipeline_check.py`; six
-        # is where the pushes still keep up with the solves of the cube batch)
+        # push takes 89 instead of 60 ms, beside one of four work-groups 64, `tools/masked_pipeline_check.py`; three
+        # work-groups while the chip-bound buckets are being solved, eight for the small ones at the end, is where
+        # the pushes still keep up with the solves of the cube batch)
         masked = self.host_io and isinstance(self._streams, _MaskedStreams)
         PCIE_BLOCKS = int(os.environ.get("TRS_PCIE_BLOCKS", "64" if masked else "32"))
-        PUSH_BLOCKS = int(os.environ.get("TRS_PCIE_PUSH_BLOCKS", "6" if masked else str(PCIE_BLOCKS)))
+        push_spec = os.environ.get("TRS_PCIE_PUSH_BLOCKS", "3,8" if masked else str(PCIE_BLOCKS)).split(",")
+        n_chip = getattr(self, "_chip_bound_buckets", 0)   # "a,b": a for the chip-bound buckets, b for the others
+        push_blocks = lambda k: int(push_spec[0] if (k < n_chip or len(push_spec) == 1) else push_spec[1])
         with torch.cuda.device(self.device):
             if not self.host_io:
                 stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -1275,7 +1279,7 @@ class RaggedSolver:
                 with torch.cuda.stream(s_down):
                     s_down.wait_event(solved)
                     mark(f"bucket {k} push begins", s_down)
-                    _capi.check(self.lib.trs_copy_rows(*scatter, bk["count"], bk["rows"].data_ptr(), 1, PUSH_BLOCKS,
+                    _capi.check(self.lib.trs_copy_rows(*scatter, bk["count"], bk["rows"].data_ptr(), 1, push_blocks(k),
                                                        s_down.cuda_stream), "trs_copy_rows (push)")
                     mark(f"bucket {k} pushed", s_down)
             done = torch.cuda.Event()

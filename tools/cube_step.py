@@ -20,3 +20,17 @@ for _ in range(args.steps):
     solver.step()
 torch.cuda.synchronize()
 print("info_nonzero", int((solver.info != 0).sum().item()))
+# per-stage times of one step (events on the stream), summed over the buckets
+import time
+rec = []
+solver.step(record=rec); torch.cuda.synchronize()
+tot = {}
+for name, e0, e1 in rec:
+    tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    solver.step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+print(f"options {solver.buckets[-1]['dev'].options}: step {dt * 1e3:.2f} ms = {args.cubes / dt / 1e6:.3f} M solves/s; "
+      + ", ".join(f"{k} {v:.2f}" for k, v in tot.items()))
