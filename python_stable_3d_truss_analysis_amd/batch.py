@@ -948,7 +948,7 @@ class SolverWorkspace:
 class _MaskedStreams:
     """The three streams of the host-fed pipeline with their compute units set apart (`trs_stream_create_masked`):
     pull and push get CUs of their own - consecutive mask bits go round the XCDs, so eight are one CU of every
-    XCD - and the solver kernels the rest.  Destroyed with the object."""
+    XCD - and the solver kernels the rest."""
 
     def __init__(self, torch, dev, lib, pull_cus, push_cus):
         import ctypes
@@ -972,13 +972,13 @@ class _MaskedStreams:
     def __iter__(self):
         return iter(self.streams)
 
-    def __del__(self):
-        try:
-            self.torch.cuda.synchronize(self.dev)
-            for handle in self.handles:
-                self.lib.trs_stream_destroy(handle)
-        except Exception:   # interpreter shutdown
-            pass
+    def close(self):
+        """Destroy the streams (after the work queued on them has finished).  The pipeline's own set is created
+        once per process and device and lives as long as the process."""
+        self.torch.cuda.synchronize(self.dev)
+        for handle in self.handles:
+            _capi.check(self.lib.trs_stream_destroy(handle), "trs_stream_destroy")
+        self.handles, self.streams = [], []
 
 
 def _flow_shop_order(groups, packed, n_pad_of, rule="johnson"):

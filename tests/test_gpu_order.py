@@ -277,6 +277,33 @@ def test_copy_rows_live_counts_and_tracked_extents(gpu):
     assert lib.trs_copy_rows(2, *args, None, cnt, (Z * 2)(0, 1), None, 16, rows.data_ptr(), 0, 0, stream) != 0   # element size 0
 
 
+def test_masked_streams_run_kernels_and_refuse_bad_masks(gpu):
+    """`trs_stream_create_masked` (ABI 8): kernels queued on a CU-masked stream run (on whichever CUs the mask
+    names) and give the same results; masks that leave a role without CUs are refused."""
+    import ctypes
+    import torch
+    lib = gpu._capi.load()
+    streams = gpu._MaskedStreams(torch, torch.device("cuda:0"), lib, 8, 4)
+    P, Z = ctypes.c_void_p, ctypes.c_size_t
+    src = torch.arange(64 * 100, dtype=torch.float64, device="cuda").reshape(64, 100)
+    rows = torch.arange(63, -1, -1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    outs = []
+    for st in streams:
+        dst = torch.zeros_like(src)
+        assert lib.trs_copy_rows(1, (P * 1)(src.data_ptr()), (Z * 1)(800), (P * 1)(dst.data_ptr()), (Z * 1)(800), (Z * 1)(800),
+                                 None, None, None, None, 64, rows.data_ptr(), 0, 2, st.cuda_stream) == 0
+        outs.append(dst)
+    torch.cuda.synchronize()
+    assert all(torch.equal(dst, src.flip(0)) for dst in outs)
+    streams.close()
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    with pytest.raises(ValueError):
+        gpu._MaskedStreams(torch, torch.device("cuda:0"), lib, n_cu, 8)
+    with pytest.raises(ValueError):
+        gpu._MaskedStreams(torch, torch.device("cuda:0"), lib, 0, 8)
+
+
 def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
     """`solve_batch_streamed` / `RaggedSolver(host_io=...)`: the batch stays in page-locked host memory, every
     bucket is pulled over PCIe by the gather kernel, solved, and pushed into the page-locked result arrays (full
