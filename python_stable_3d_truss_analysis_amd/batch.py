@@ -1011,7 +1011,8 @@ def _pipeline_streams(torch, dev, lib):
     key = (str(dev), spec)
     if key not in _PIPELINE_STREAMS:   # (a queue with a CU mask takes ~20 ms to create: once per process and device)
         pull_cus, push_cus = int(spec.split(",")[0]), int(spec.split(",")[-1])
-        if pull_cus <= 0:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        if pull_cus <= 0 or 2 * (pull_cus + push_cus) > n_cu:   # (a partitioned or small device: no CUs to spare)
             _PIPELINE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         else:
             _PIPELINE_STREAMS[key] = _MaskedStreams(torch, dev, lib, pull_cus, push_cus)
