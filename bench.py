@@ -358,7 +358,7 @@ def dataset_leg(args, device, torch, barrier, reduce_max, rank, world):
     chunk.  `--dataset-samples` per GPU; rate = samples of all ranks / max rank time."""
     from python_stable_3d_truss_analysis_amd import MemberType, TaskType
     from python_stable_3d_truss_analysis_amd import data as gdata
-    chunk = min(16384, args.dataset_samples)
+    chunk = min(32768, args.dataset_samples)   # (chunks of 16 384 leave the buckets with fewer matrices than the chip holds waves: 453 against 523 K samples/s)
     total = args.dataset_samples * world
     kw = dict(seed=11, numCubeRange=(8, 190), gridRange=(6, 6, 6), fixedMemberType=MemberType(1., 1e7, 0.1),
               taskType=TaskType.REGRESSION, device=device, forceScale=1e3, displaceScale=0.1, positionScale=100.)

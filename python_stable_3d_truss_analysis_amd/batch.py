@@ -939,10 +939,29 @@ class SolverWorkspace:
             have = self.buf.get(kind)
             if have is None or have.numel() < count:
                 make = t.zeros if kind == "env" else t.empty
+                if have is not None:
+                    # a buffer that has to grow goes back to the driver first (the caching allocator would keep
+                    # the old block beside the new one for good), and grows with headroom: a stream of batches
+                    # of slightly different shapes settles after a few steps
+                    self.buf[kind] = have = None
+                    t.cuda.empty_cache()
+                    count = int(count) + int(count) // 8
                 self.buf[kind] = make([max(1, int(count))], dtype=getattr(t, self.KINDS[kind]), device=self.device)
                 if kind == "S" and os.environ.get("TRS_DEBUG_POISON"):
                     self.buf[kind].fill_(float("nan"))
         return self.buf
+
+
+_SHARED_WORKSPACES = {}
+
+
+def shared_workspace(torch, device):
+    """The process's `SolverWorkspace` of `device` for bucket pipelines that run one after the other on the
+    current stream (the chunks of `data.dataset_chunks`): one slab for all of them instead of one per call."""
+    key = str(device)
+    if key not in _SHARED_WORKSPACES:
+        _SHARED_WORKSPACES[key] = SolverWorkspace(torch, device)
+    return _SHARED_WORKSPACES[key]
 
 
 class _MaskedStreams:
@@ -1042,7 +1061,7 @@ class RaggedSolver:
     JOINT_ORDERED = ("xyz", "conn", "cbits", "loads")
 
     def __init__(self, packed, device=None, reorder=True, max_slab_bytes=48 << 30, granularity=64,
-                 options=None, tensors=None, workspace=None, host_io=None):
+                 options=None, tensors=None, workspace=None, host_io=None, n_variants=1):
         """`packed`: a `PackedBatch` (uploaded here) or, with `tensors` = the batch's device tensors by field name
         (e.g. from `generate.generate_cube_batch_device`), just its `BatchSizes`.  `workspace`: a
         `SolverWorkspace` shared with other solvers that run on the same stream one after the other.
@@ -1052,7 +1071,11 @@ class RaggedSolver:
         `ResultPool`).  Page-locked memory is mapped into the device's address space, so every bucket's gather
         PULLS its rows straight out of the host batch and its scatter PUSHES the results into the host arrays
         (full rows, zero padding included); `step()` then runs the buckets as a three-stream pipeline - pull of
-        bucket k + 1, device work of bucket k, push of bucket k - 1 at the same time (`solve_batch_streamed`)."""
+        bucket k + 1, device work of bucket k, push of bucket k - 1 at the same time (`solve_batch_streamed`).
+
+        `n_variants` > 1: every step solves the batch that many times with different member sections
+        (`step(sections=[...])`, as `solve_batch(sections=...)`): gather and joint order once per bucket, one result
+        set per variant in `outs` (`u` / `f_ext` / `N` / `info` are the first variant's)."""
         torch, dev = _require_gpu(device if tensors is None else tensors["xyz"].device)
         self.torch, self.device, self.packed, self.lib = torch, dev, packed, _capi.load()
         B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
@@ -1090,9 +1113,15 @@ class RaggedSolver:
             self.live = dict(out.get("live") or {})
             if any(t.device != dev or t.dtype != torch.int32 or tuple(t.shape) != (B,) for t in self.live.values()):
                 raise ValueError("host_io live extents must be int32 [B] tensors on the solver's device")
+            if n_variants != 1:
+                raise ValueError("the host-fed pipeline solves one set of sections per step")
+            self.outs = [{"u": self.u, "f_ext": self.f_ext, "N": self.N, "info": self.info}]
         else:
-            self.u, self.f_ext = z([B, nJ_max, 3], torch.float64), z([B, nJ_max, 3], torch.float64)
-            self.N, self.info = z([B, nM_max], torch.float64), z([B], torch.int32)
+            self.outs = [{"u": z([B, nJ_max, 3], torch.float64), "f_ext": z([B, nJ_max, 3], torch.float64),
+                          "N": z([B, nM_max], torch.float64), "info": z([B], torch.int32)}
+                         for _ in range(max(1, int(n_variants)))]
+            first = self.outs[0]
+            self.u, self.f_ext, self.N, self.info = first["u"], first["f_ext"], first["N"], first["info"]
         groups = size_buckets(packed, max_slab_bytes, granularity) if B else []
         n_pad_of = lambda idx: (int(packed.n_free[idx].max()) + 63) // 64 * 64
         slab_of = lambda idx: len(idx) * n_pad_of(idx) * (n_pad_of(idx) + 16)
@@ -1186,7 +1215,8 @@ class RaggedSolver:
                     pairs.append((f, self.inputs[f], getattr(db, f)))
             if bk["renumbered"] and not bk["order_on_device"]:
                 pairs.append(("perm", self.ordered["perm"], db.joint_out))
-            outs = [("u", db.u, self.u), ("f_ext", db.f_ext, self.f_ext), ("N", db.N, self.N), ("info", db.info, self.info)]
+            outs = [[("u", db.u, o["u"]), ("f_ext", db.f_ext, o["f_ext"]), ("N", db.N, o["N"]), ("info", db.info, o["info"])]
+                    for o in self.outs]
             # host-fed: only the live part of a row crosses the link - (count array, bytes per element) by field
             per_joint = {"xyz": 24, "loads": 24, "cbits": 1, "u": 24, "f_ext": 24}
             per_member = {"conn": 8, "E": 8, "A": 8, "N": 8}
@@ -1207,16 +1237,22 @@ class RaggedSolver:
                 live = None if trimmed_is_dst else (P * n)(*[self.live[f].data_ptr() if f in self.live else None
                                                              for f, _, _ in pairs])
                 return n, src, sp, dst, dp, width, fill, counts, elem, live
-            tables.append((pack(pairs, True), pack(outs, False)))
+            tables.append((pack(pairs, True), [pack(o, False) for o in outs]))
         return tables
 
-    def step(self, record=None):
+    def step(self, record=None, sections=None):
         """One pass of the whole path over the batch, asynchronous on the current stream.  `record` (a list):
         instrumented step - (stage name, start event, end event) of every bucket's gather, order, solve and
-        scatter are appended."""
+        scatter are appended.  `sections`: one entry per variant of the solver (`n_variants`) - None = the
+        members' own sections, (A, E, density) = every member set to that type; results in `outs[slot]`."""
         torch = self.torch
         if self.B == 0:
             return
+        sections = [None] * len(self.outs) if sections is None else list(sections)
+        if len(sections) != len(self.outs):
+            raise ValueError(f"{len(sections)} section variants for a solver built for {len(self.outs)}")
+        # the variants with the members' own sections first: they need what the gather brought
+        slots = sorted(range(len(sections)), key=lambda k: sections[k] is not None)
 
         def timed(name, call):
             if record is None:
@@ -1242,15 +1278,21 @@ class RaggedSolver:
         with torch.cuda.device(self.device):
             if not self.host_io:
                 stream = torch.cuda.current_stream(self.device).cuda_stream
-                for bk, (gather, scatter) in zip(self.buckets, self._tables):
+                for bk, (gather, scatters) in zip(self.buckets, self._tables):
                     timed("gather", lambda: _capi.check(self.lib.trs_copy_rows(
                         *gather, bk["count"], bk["rows"].data_ptr(), 0, 0, stream), "trs_copy_rows (gather)"))
                     if bk["order_on_device"]:
                         timed("order", lambda: joint_order_device(torch, bk["raw"], effort=self.plan[1], out=bk["ordered"]))
-                    timed("solve", bk["dev"].solve)
-                    timed("scatter", lambda: _capi.check(self.lib.trs_copy_rows(
-                        *scatter, bk["count"], bk["rows"].data_ptr(), 1, 0, stream), "trs_copy_rows (scatter)"))
+                    for slot in slots:
+                        if sections[slot] is not None:
+                            bk["dev"].A.fill_(float(sections[slot][0]))
+                            bk["dev"].E.fill_(float(sections[slot][1]))
+                        timed("solve", bk["dev"].solve)
+                        timed("scatter", lambda: _capi.check(self.lib.trs_copy_rows(
+                            *scatters[slot], bk["count"], bk["rows"].data_ptr(), 1, 0, stream), "trs_copy_rows (scatter)"))
                 return
+            if sections[0] is not None:
+                raise ValueError("the host-fed pipeline solves the members' own sections")
             # host-fed pipeline: pull of bucket k + 1 | order + solve of bucket k | push of bucket k - 1
             s_up, s_run, s_down = tuple(self._streams)
             caller = torch.cuda.current_stream(self.device)
@@ -1260,7 +1302,8 @@ class RaggedSolver:
             for st in (s_up, s_run, s_down):
                 st.wait_event(begin)
             mark = lambda name, stream: record.append((name, begin, self._marked(stream))) if timing else None
-            for k, (bk, (gather, scatter)) in enumerate(zip(self.buckets, self._tables)):
+            for k, (bk, (gather, scatters)) in enumerate(zip(self.buckets, self._tables)):
+                scatter = scatters[0]
                 with torch.cuda.stream(s_up):
                     mark(f"bucket {k} pull begins", s_up)
                     _capi.check(self.lib.trs_copy_rows(*gather, bk["count"], bk["rows"].data_ptr(), 0, PCIE_BLOCKS,
@@ -1523,6 +1566,19 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
         # every truss is small: the fused kernel, no bucketing, no reordering (nothing to gain from it)
         out = _solve_small_host(packed, torch, dev, variants, on_device)
         return out[0] if sections is None else out
+    if device_inputs is not None and on_device and B and options is None:
+        groups = size_buckets(packed, min(max_slab_bytes, 48 << 30))
+        if len(groups) > 1:
+            # a ragged batch that is on the device already and stays there: the resident bucket pipeline
+            # (one-launch gathers and scatters, joint order per bucket, one workspace shared by all buckets and by
+            # all calls on this device), one result set per section variant
+            solver = RaggedSolver(packed, dev, reorder=reorder, max_slab_bytes=min(max_slab_bytes, 48 << 30),
+                                  tensors=device_inputs, workspace=shared_workspace(torch, dev),
+                                  n_variants=len(variants))
+            solver.step(sections=variants)
+            inputs = {f: device_inputs[f] for f in DeviceBatch.INPUT_FIELDS if f in device_inputs}
+            results = [DeviceResult(o["u"], o["f_ext"], o["N"], o["info"], inputs) for o in solver.outs]
+            return results[0] if sections is None else results
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
     plan = order_plan(reorder, nJ_max, nM_max) if B else None
     ordering = None

@@ -396,7 +396,7 @@ def dataset_sizes(seed, first, count, numCubeRange):
     return out
 
 
-def dataset_chunks(n_samples, rank=0, world=1, chunk=16384, seed=0, numCubeRange=(8, 190), gridRange=(6, 6, 6),
+def dataset_chunks(n_samples, rank=0, world=1, chunk=32768, seed=0, numCubeRange=(8, 190), gridRange=(6, 6, 6),
                    fixedMemberType=None, taskType=TaskType.OPTIMIZATION, forceScale=1., displaceScale=1.,
                    positionScale=1., device=None, reorder=True, prefetch=True, generate="device", **generator_args):
     """BASELINE config 5 as a generator: this rank's share of a dataset of `n_samples` random cube trusses,

@@ -47,7 +47,7 @@ lib = solver.lib
 s_up, s_run, s_down = tuple(solver._streams)
 def launch(which, blocks, stream):
     for bk, tabs in zip(solver.buckets, solver._tables):
-        _capi.check(lib.trs_copy_rows(*tabs[which], bk["count"], bk["rows"].data_ptr(), which, blocks, stream.cuda_stream), "copy")
+        _capi.check(lib.trs_copy_rows(*(tabs[0] if which == 0 else tabs[1][0]), bk["count"], bk["rows"].data_ptr(), which, blocks, stream.cuda_stream), "copy")
 nJ64, nM64 = packed.nJ.astype(np.int64), packed.nM.astype(np.int64)
 pulled_bytes = int((nJ64 * 49 + nM64 * 24).sum())      # live bytes: xyz, loads, cbits per joint; conn, E, A per member
 pushed_bytes = int((nJ64 * 48 + nM64 * 8).sum()) + 4 * B
