@@ -1,0 +1,198 @@
+"""The usage flows of the reference's own `example.py` (its de-facto test-suite: TestTimeConsuming, TestExample,
+TestLoadFromJSON, TestGA, TestGenerateCubeTruss, TestDataAugmentation, TestTrussHeteroData - `/root/reference/
+example.py:1-296`) written against THIS package: a user who swaps `slientruss3d` for
+`python_stable_3d_truss_analysis_amd` runs exactly these calls.  Every `Solve()` below goes through the HIP
+pipeline; results are checked against the reference's stored output files, captured reference tensors, or the CPU
+oracle (tolerance 1e-9 of the largest entry: what the FP64 path holds; north_star asks 1e-6).  Plotting
+(`TrussPlotter`) is outside the path and is the one call of those flows that is left out."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import truss_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _needs_gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+
+
+def _data(name):
+    return os.path.join(H.GOLDEN, "data", name + ".json")
+
+
+def _same_results(truss, stored, nJ, nM, dim):
+    """Displacements and member forces of a solved truss against a stored output file of the reference."""
+    got_u = [[k, list(v)] for k, v in truss.GetDisplacements().items()]
+    got_n = [[k, v] for k, v in truss.GetInternalForces().items()]
+    assert H.max_scaled_err(orc.densify(got_u, nJ, dim), orc.densify(stored["displace"], nJ, dim)) <= TOL
+    assert H.max_scaled_err(orc.densify(got_n, nM), orc.densify(stored["internal"], nM)) <= TOL
+
+
+def test_time_consuming_flow_repeated_solves_of_a_2d_truss():
+    """example.py:1-25 - load bar-47 (2D), Solve() thirty times: every solve gives the stored results."""
+    from python_stable_3d_truss_analysis_amd.truss import Truss
+    truss = Truss(dim=2)
+    truss.LoadFromJSON(_data("bar-47_input_0"))
+    stored = H.load_json("bar-47_output_0")
+    for _ in range(30):
+        truss.Solve()
+        assert truss.isSolved
+    _same_results(truss, stored, truss.nJoint, truss.nMember, 2)
+
+
+def test_example_flow_build_a_space_truss_by_hand(tmp_path):
+    """example.py:62-121 - five joints, six members, one load, built call by call; Solve, DumpIntoJSON, getters."""
+    from python_stable_3d_truss_analysis_amd.truss import Truss
+    from python_stable_3d_truss_analysis_amd.type import SupportType, MemberType
+    truss = Truss(dim=3)
+    joints = [(0, 0, 0), (360, 0, 0), (360, 180, 0), (0, 200, 0), (120, 100, 180)]
+    supports = [SupportType.PIN, SupportType.ROLLER_Z, SupportType.PIN, SupportType.PIN, SupportType.NO]
+    forces = [(1, (0, -10000, 5000))]
+    members = [(0, 4), (1, 4), (2, 4), (3, 4), (1, 2), (1, 3)]
+    memberType = MemberType(1, 1e7, 1)
+    for joint, support in zip(joints, supports):
+        truss.AddNewJoint(joint, support)
+    for jointID, force in forces:
+        truss.AddExternalForce(jointID, force)
+    for jointID0, jointID1 in members:
+        truss.AddNewMember(jointID0, jointID1, memberType)
+    truss.Solve()
+    out = tmp_path / "test_output.json"
+    truss.DumpIntoJSON(str(out))
+    displace, stress, resistance = truss.GetDisplacements(), truss.GetInternalStresses(), truss.GetResistances()
+    dumped = json.loads(out.read_text())
+    ref = orc.solve({k: dumped[k] for k in ("joint", "force", "member")})
+    u = np.zeros([5, 3])
+    for j, v in displace.items():
+        u[j] = v
+    assert H.max_scaled_err(u, ref["u"]) <= TOL
+    s = np.zeros(6)
+    for m, v in stress.items():
+        s[m] = v
+    assert H.max_scaled_err(s, ref["N"] / 1.0) <= TOL                   # area 1: stress = force
+    assert sorted(resistance) == [0, 1, 2, 3]                            # reactions at the four supports only
+    total = np.sum([np.asarray(v, dtype=float) for v in resistance.values()], axis=0) + np.array([0, -10000, 5000.])
+    assert np.abs(total).max() <= 1e-6 * 10000                           # global equilibrium
+    assert abs(resistance[1][0]) <= 1e-6 and abs(resistance[1][1]) <= 1e-6   # ROLLER_Z holds z only
+
+
+def test_load_from_json_flow_and_dump(tmp_path):
+    """example.py:124-171 - bar-10 (2D) from its JSON file, Solve, DumpIntoJSON = the reference's stored output."""
+    from python_stable_3d_truss_analysis_amd.truss import Truss
+    truss = Truss(dim=2)
+    truss.LoadFromJSON(_data("bar-10_input_0"))
+    truss.Solve()
+    out = tmp_path / "bar-10_output_0.json"
+    truss.DumpIntoJSON(str(out))
+    mine, stored = json.loads(out.read_text()), H.load_json("bar-10_output_0")
+    assert mine["joint"] == stored["joint"] and mine["member"] == stored["member"] and mine["force"] == stored["force"]
+    for key, count, width in (("displace", 6, 2), ("external", 6, 2), ("internal", 10, None)):
+        assert H.max_scaled_err(orc.densify(mine[key], count, width), orc.densify(stored[key], count, width)) <= TOL
+    assert mine["weight"] == pytest.approx(stored["weight"], rel=1e-14)
+    displace, stress, resistance = truss.GetDisplacements(), truss.GetInternalStresses(), truss.GetResistances()
+    assert len(displace) and len(stress) and len(resistance)
+
+
+def test_ga_flow_on_bar_120(tmp_path):
+    """example.py:175-205 - twenty random member types, GA on bar-120 (every fitness evaluation is ONE launch of
+    the fused small-system kernel over the population), the best gene put back, Solve, DumpIntoJSON."""
+    from python_stable_3d_truss_analysis_amd.truss import Truss
+    from python_stable_3d_truss_analysis_amd.type import MemberType
+    from python_stable_3d_truss_analysis_amd.ga import GA
+    random.seed(7)
+    types = [MemberType(inch, random.uniform(1e7, 3e7), random.uniform(0.1, 1.0)) for inch in range(1, 21)]
+    truss = Truss(3)
+    truss.LoadFromJSON(_data("bar-120_input_0"))
+    ga = GA(truss, types, 30000., 10., nIteration=12, nPatience=50)
+    minGene, (fitness, isInternalAllowed, isDisplaceAllowed), finalPop, bestFitnessHistory = ga.Evolve(isPrintMessage=False)
+    assert len(minGene) == 120 and len(bestFitnessHistory) == 12
+    assert all(b <= a + 1e-9 for a, b in zip(bestFitnessHistory, bestFitnessHistory[1:]))     # elitism: never worse
+    truss.SetMemberTypes(ga.TranslateGene(minGene))
+    truss.Solve()
+    out = tmp_path / "bar-120_ga_0.json"
+    truss.DumpIntoJSON(str(out))
+    dumped = json.loads(out.read_text())
+    ref = orc.solve({k: dumped[k] for k in ("joint", "force", "member")})
+    assert H.max_scaled_err(orc.densify(dumped["internal"], 120), ref["N"]) <= TOL
+    # the fitness the GA reported for its best gene: the truss's weight, plus penalties only when a limit is violated
+    if isInternalAllowed and isDisplaceAllowed:
+        assert fitness == pytest.approx(dumped["weight"], rel=1e-9)
+    else:
+        assert fitness >= dumped["weight"] * (1 - 1e-9)
+
+
+def test_generate_cube_truss_flow(tmp_path):
+    """example.py:208-231 - ten 7-cube trusses in a 5x5x5 grid, analysed (one batched GPU call) and saved."""
+    from python_stable_3d_truss_analysis_amd.generate import GenerateRandomCubeTrusses
+    from python_stable_3d_truss_analysis_amd.truss import Truss
+    folder = tmp_path / "generate"
+    folder.mkdir()                                   # (as the reference: the folder has to exist)
+    trussList = GenerateRandomCubeTrusses(gridRange=(5, 5, 5), numCubeRange=(7, 7), numEachRange=(1, 10),
+                                          lengthRange=(100, 200), forceRange=[(-1000, 1000)] * 3,
+                                          isDoStructuralAnalysis=True, isPlotTruss=False, saveFolder=str(folder),
+                                          seed=42, isPrintMessage=False)
+    assert len(trussList) == 10 and all(t.isSolved for t in trussList)
+    files = sorted(os.listdir(folder))
+    assert files == sorted(f"cube-7_case_{i}.json" for i in range(1, 11))
+    for i, truss in enumerate(trussList, start=1):
+        dumped = json.loads((folder / f"cube-7_case_{i}.json").read_text())
+        ref = orc.solve({k: dumped[k] for k in ("joint", "force", "member")})
+        assert H.max_scaled_err(orc.densify(dumped["displace"], truss.nJoint, 3), ref["u"]) <= TOL
+        assert H.max_scaled_err(orc.densify(dumped["internal"], truss.nMember), ref["N"]) <= TOL
+        again = Truss(3).LoadFromJSON(str(folder / f"cube-7_case_{i}.json"), isOutputFile=True)   # loads back solved
+        assert again.isSolved and again.nMember == truss.nMember
+
+
+def test_data_augmentation_flow(tmp_path):
+    """example.py:234-268 - the five augmenters as one list, applied to a generated 4-cube truss, analysed."""
+    from python_stable_3d_truss_analysis_amd.generate import GenerateRandomCubeTrusses
+    from python_stable_3d_truss_analysis_amd.generate import (MoveToCentroid, RandomTranslation, AddJointNoise,
+                                                              RandomResetPin, NoChange, TrussDataAugmenterList)
+    transforms = TrussDataAugmenterList(
+        NoChange(), MoveToCentroid(), RandomTranslation(translateRange=[-30., 30.]),
+        AddJointNoise(noiseMeans=[0., 0., 0.], noiseStds=[10., 10., 10.]),
+        RandomResetPin(minNumPin=5, maxNumPinRatio=0.6))
+    (tmp_path / "augmentations").mkdir()
+    truss = GenerateRandomCubeTrusses(gridRange=(5, 5, 5), numCubeRange=(4, 4), numEachRange=(1, 1),
+                                      lengthRange=(100, 200), forceRange=[(-1000, 1000)] * 3,
+                                      isDoStructuralAnalysis=True, isPlotTruss=False,
+                                      saveFolder=str(tmp_path / "augmentations"), seed=42, augmenter=transforms,
+                                      isPrintMessage=False)[0]
+    assert truss.isSolved and truss.isStable
+    dumped = json.loads((tmp_path / "augmentations" / "cube-4_case_1.json").read_text())
+    ref = orc.solve({k: dumped[k] for k in ("joint", "force", "member")})
+    assert H.max_scaled_err(orc.densify(dumped["displace"], truss.nJoint, 3), ref["u"]) <= TOL
+    nPin = sum(1 for _, support in dumped["joint"] if support == "PIN")
+    assert 5 <= nPin <= max(5, int(0.6 * truss.nJoint))
+
+
+def test_truss_hetero_data_flow():
+    """example.py:271-293 - TrussHeteroDataCreator.FromJSON / FromTruss on bar-25: the tensors the reference's
+    creator builds (captured by importing it, `tests/golden/hetero_bar25.npz`)."""
+    from python_stable_3d_truss_analysis_amd.data import TrussHeteroDataCreator
+    from python_stable_3d_truss_analysis_amd.type import TaskType
+    from python_stable_3d_truss_analysis_amd.truss import Truss
+    from tests.test_data_graph import _compare, SCALES
+    golden = np.load(os.path.join(H.GOLDEN, "hetero_bar25.npz"))
+    JSON_FILE, TRUSS_DIM = _data("bar-25_input_0"), 3
+    creator = TrussHeteroDataCreator(taskType=TaskType.OPTIMIZATION)
+    graph = creator.FromJSON(JSON_FILE, TRUSS_DIM)                       # the example's call, default scales
+    assert tuple(graph["joint"].x.shape) == golden["opt_noimp/joint/x"].shape
+    assert tuple(graph["member"].x.shape) == golden["opt_noimp/member/x"].shape
+    assert "joint" in str(graph) or "joint" in repr(graph)               # the example prints the structure
+    truss = Truss(TRUSS_DIM).LoadFromJSON(JSON_FILE)
+    graph2 = creator.FromTruss(truss, trussSrc=JSON_FILE)
+    assert np.array_equal(graph["member"].x.numpy(), graph2["member"].x.numpy())
+    assert creator.source == JSON_FILE and creator.jointIndexToID == list(range(10))
+    # the same two calls with the scales the reference capture was made with: its tensors
+    _compare(creator.FromJSON(JSON_FILE, TRUSS_DIM, **SCALES), golden, "opt_noimp")
+    _compare(creator.FromTruss(Truss(TRUSS_DIM).LoadFromJSON(JSON_FILE), **SCALES), golden, "opt_noimp")
