@@ -277,6 +277,40 @@ def test_copy_rows_live_counts_and_tracked_extents(gpu):
     assert lib.trs_copy_rows(2, *args, None, cnt, (Z * 2)(0, 1), None, 16, rows.data_ptr(), 0, 0, stream) != 0   # element size 0
 
 
+def test_ragged_solver_section_variants_equal_solve_batch_sections(gpu):
+    """`RaggedSolver(n_variants=2).step(sections=[None, fixed])` - gather and joint order once per bucket, one
+    solve + scatter per variant - gives the bits of `solve_batch(..., sections=[None, fixed])` (the staged path:
+    upload, torch gathers, one `DeviceBatch` per bucket), in either order of the variants, step after step; and
+    `solve_batch(device_inputs=..., on_device=True)` routes a ragged device batch through it."""
+    import torch
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    rng = np.random.default_rng(21)
+    packed = gen.generate_cube_batch(rng.integers(1, 120, size=600), gridRange=(6, 6, 6), seed=4,
+                                     memberTypes=[[1., 1e7, 0.1], [2.5, 2e7, 0.2]])
+    fixed = (1.5, 3e7, 0.3)
+    want = gpu.solve_batch(packed, reorder=True, sections=[None, fixed])
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tensors = {f: up(getattr(packed, f)) for f in gpu.DeviceBatch.INPUT_FIELDS}
+    for order in ([None, fixed], [fixed, None]):
+        solver = gpu.RaggedSolver(packed, reorder=True, tensors=tensors, n_variants=2)
+        for _ in range(2):
+            solver.step(sections=order)
+        torch.cuda.synchronize()
+        for slot, sec in enumerate(order):
+            ref = want[0] if sec is None else want[1]
+            o = solver.outs[slot]
+            np.testing.assert_array_equal(o["u"].cpu().numpy(), ref.displace)
+            np.testing.assert_array_equal(o["f_ext"].cpu().numpy(), ref.external)
+            np.testing.assert_array_equal(o["N"].cpu().numpy(), ref.internal)
+            assert not o["info"].any()
+    with pytest.raises(ValueError):
+        solver.step(sections=[None])                       # built for two variants
+    routed = gpu.solve_batch(packed, reorder=True, sections=[None, fixed], device_inputs=tensors, on_device=True)
+    for got, ref in zip(routed, want):
+        np.testing.assert_array_equal(got.displace.cpu().numpy(), ref.displace)
+        np.testing.assert_array_equal(got.internal.cpu().numpy(), ref.internal)
+
+
 def test_masked_streams_run_kernels_and_refuse_bad_masks(gpu):
     """`trs_stream_create_masked` (ABI 8): kernels queued on a CU-masked stream run (on whichever CUs the mask
     names) and give the same results; masks that leave a role without CUs are refused."""
@@ -315,8 +349,8 @@ def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
     want = gpu.solve_batch(packed, reorder=True)
     pinned, pool = packed.pinned(), gpu.ResultPool()
     assert gpu._is_pinned(pinned) and not gpu._is_pinned(packed)
-    for reorder in (True, False):
-        ref = want if reorder else gpu.solve_batch(packed)
+    for reorder in (True, False, "rcm"):                # device plan, no order, a plan carried out on the host
+        ref = want if reorder is True else gpu.solve_batch(packed, reorder=reorder)
         for attempt in range(2):
             if attempt == 1:                              # content written by hand must not survive either
                 for k in ("u", "f_ext", "N"):
