@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""One-off consistency fuzz: `solve_batch_streamed` (host-fed pipeline) and the resident bucket pipeline with section
+variants against the staged `solve_batch`, bit for bit, over random batch sizes (1 .. 1000), size mixes (small-only,
+mixed, large-only) and order plans."""
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from python_stable_3d_truss_analysis_amd import batch, generate as gen
+rng = np.random.default_rng(0)
+bad = 0
+pool = batch.ResultPool()
+for trial in range(40):
+    B = int(rng.choice([1, 2, 5, 17, 64, 300, 1000]))
+    lo, hi = [(1, 3), (1, 30), (20, 60), (1, 190), (150, 190)][trial % 5]
+    packed = gen.generate_cube_batch(rng.integers(lo, hi + 1, size=B), gridRange=(6, 6, 6), seed=int(rng.integers(1 << 30)))
+    reorder = [True, False, "rcm", "fast"][trial % 4]
+    ref = batch.solve_batch(packed, reorder=reorder)
+    got = batch.solve_batch_streamed(packed.pinned(), reorder=reorder, pool=pool if trial % 3 else None)
+    ok = all(np.array_equal(getattr(got, k), getattr(ref, k)) for k in ("displace", "external", "internal", "info"))
+    # resident solver with variants against sections
+    t = {f: torch.from_numpy(np.ascontiguousarray(getattr(packed, f))).cuda() for f in batch.DeviceBatch.INPUT_FIELDS}
+    sec = [None, (2.0, 2e7, 0.3)]
+    want = batch.solve_batch(packed, reorder=reorder, sections=sec)
+    res = batch.solve_batch(packed, reorder=reorder, sections=sec, device_inputs=t, on_device=True)
+    ok2 = all(np.array_equal(r.displace.cpu().numpy(), w.displace) and np.array_equal(r.internal.cpu().numpy(), w.internal)
+              and np.array_equal(r.external.cpu().numpy(), w.external) for r, w in zip(res, want))
+    if not (ok and ok2):
+        bad += 1
+        print("MISMATCH trial", trial, B, (lo, hi), reorder, ok, ok2)
+print("trials done, mismatches:", bad)
