@@ -53,18 +53,17 @@ def test_example_flow_build_a_space_truss_by_hand(tmp_path):
     """example.py:62-121 - five joints, six members, one load, built call by call; Solve, DumpIntoJSON, getters."""
     from python_stable_3d_truss_analysis_amd.truss import Truss
     from python_stable_3d_truss_analysis_amd.type import SupportType, MemberType
+    # the example's structure: four supports on the ground, an apex, a load on the roller joint
+    layout = [((0, 0, 0), SupportType.PIN), ((360, 0, 0), SupportType.ROLLER_Z), ((360, 180, 0), SupportType.PIN),
+              ((0, 200, 0), SupportType.PIN), ((120, 100, 180), SupportType.NO)]
+    bars = [(0, 4), (1, 4), (2, 4), (3, 4), (1, 2), (1, 3)]
+    section = MemberType(1, 1e7, 1)
     truss = Truss(dim=3)
-    joints = [(0, 0, 0), (360, 0, 0), (360, 180, 0), (0, 200, 0), (120, 100, 180)]
-    supports = [SupportType.PIN, SupportType.ROLLER_Z, SupportType.PIN, SupportType.PIN, SupportType.NO]
-    forces = [(1, (0, -10000, 5000))]
-    members = [(0, 4), (1, 4), (2, 4), (3, 4), (1, 2), (1, 3)]
-    memberType = MemberType(1, 1e7, 1)
-    for joint, support in zip(joints, supports):
-        truss.AddNewJoint(joint, support)
-    for jointID, force in forces:
-        truss.AddExternalForce(jointID, force)
-    for jointID0, jointID1 in members:
-        truss.AddNewMember(jointID0, jointID1, memberType)
+    for position, support in layout:
+        truss.AddNewJoint(position, support)
+    truss.AddExternalForce(1, (0, -10000, 5000))
+    for a, b in bars:
+        truss.AddNewMember(a, b, section)
     truss.Solve()
     out = tmp_path / "test_output.json"
     truss.DumpIntoJSON(str(out))
