@@ -9,8 +9,10 @@ from python_stable_3d_truss_analysis_amd import batch, generate as gen
 rng = np.random.default_rng(0)
 bad = 0
 pool = batch.ResultPool()
-for trial in range(40):
-    B = int(rng.choice([1, 2, 5, 17, 64, 300, 1000]))
+TRIALS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+BIG = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+for trial in range(TRIALS):
+    B = int(rng.choice([1, 2, 5, 17, 64, 300, 1000, BIG]))
     lo, hi = [(1, 3), (1, 30), (20, 60), (1, 190), (150, 190)][trial % 5]
     packed = gen.generate_cube_batch(rng.integers(lo, hi + 1, size=B), gridRange=(6, 6, 6), seed=int(rng.integers(1 << 30)))
     reorder = [True, False, "rcm", "fast"][trial % 4]
