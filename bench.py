@@ -19,7 +19,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 joint order INSIDE the timed step (batch.RaggedSolver), solves/s + roofline fractions
   dataset       BASELINE config 5 at every N: samples/s of data.dataset_chunks (generation, order, two solves and
                 graph features on the device)
-  pcie_inclusive, given_joint_order, dense_mode_potrf, ga_generation (BASELINE config 4)   informational legs at N = 1
+  pcie_inclusive, given_joint_order, dense_mode_potrf, ga_generation (BASELINE config 4),
+  reference_protocol (the reference's own published benchmark: 30 x Truss.Solve() per case)   informational legs at N = 1
 """
 import argparse
 import json
@@ -407,6 +408,30 @@ def ga_leg(device, torch):
                     "the fitness reductions -> one download); informational"}
 
 
+def reference_protocol_leg():
+    """The reference's OWN published benchmark (README.md:86-94, example.py:1-25): load a
+    truss once, call `Truss.Solve()` 30 times, mean wall time per call - through this package's drop-in `Truss`
+    (every call: pack, upload, kernels, download, sparse result dicts), for the seven bundled cases.  Informational,
+    rank 0 at N = 1: one truss per call is not what the device is for, but it is the number the reference quotes."""
+    from python_stable_3d_truss_analysis_amd.truss import Truss
+    published = {"bar-6": 0.00037, "bar-10": 0.00050, "bar-25": 0.00126, "bar-47": 0.00253, "bar-72": 0.00323,
+                 "bar-120": 0.00557, "bar-942": 0.05253}     # seconds, Intel i7-10750H (README.md:88-94)
+    out = {}
+    for case, ref_s in published.items():
+        truss = Truss(dim=2 if case in ("bar-10", "bar-47") else 3).LoadFromJSON(data=load_case(f"{case}_input_0"))
+        truss.Solve()
+        ts = []
+        for _ in range(30):
+            t0 = time.time()
+            truss.Solve()
+            ts.append(time.time() - t0)
+        mean = sum(ts) / len(ts)
+        out[case] = {"mean_ms": mean * 1e3, "reference_published_ms": ref_s * 1e3, "ratio": ref_s / mean}
+    out["note"] = ("mean wall time of 30 Truss.Solve() calls per case through the drop-in API, against the reference's "
+                   "published single-truss times (its README, other hardware: a laptop CPU); informational")
+    return out
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) with
     torch.distributed.run as a CHILD process and pass its output and exit code through.  This process
@@ -775,6 +800,10 @@ def main():
                 line["ga_generation"] = ga_leg(device, torch)
             except Exception as exc:
                 line["ga_generation"] = {"error": repr(exc)}
+            try:
+                line["reference_protocol"] = reference_protocol_leg()
+            except Exception as exc:
+                line["reference_protocol"] = {"error": repr(exc)}
         if given is not None:
             line["given_joint_order"] = given
         if dense_ms is not None:

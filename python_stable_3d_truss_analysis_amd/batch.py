@@ -145,7 +145,11 @@ def pack_arrays(xyz_list, conn_list, mtype_list, support_list, loads_list, dims)
         x = np.asarray(xyz_list[b], dtype=float).reshape(-1, dim)
         xyz[b, :nJ[b], :dim] = x
         loads[b, :nJ[b], :dim] = np.asarray(loads_list[b], dtype=float).reshape(-1, dim)
-        bits = np.array([SupportType.ConstraintBits(s, dim) for s in support_list[b]], dtype=np.uint8)
+        table = SupportType._BITS3 if dim == 3 else SupportType._BITS2
+        try:    # (one dict look-up per joint; an unknown type takes the slow road to the reference's exception)
+            bits = np.array([table[s] for s in support_list[b]], dtype=np.uint8)
+        except (KeyError, TypeError):
+            bits = np.array([SupportType.ConstraintBits(s, dim) for s in support_list[b]], dtype=np.uint8)
         cbits[b, :nJ[b]] = bits | (4 if dim == 2 else 0)  # a 2D truss never moves in z
         if nM[b]:
             conn[b, :nM[b]] = np.asarray(conn_list[b], dtype=np.int32).reshape(-1, 2)
@@ -159,15 +163,9 @@ def pack_trusses(trusses):
     """`list[Truss]` -> `PackedBatch` (DOF order joint*dim + axis, reference `truss.py:312-314`)."""
     xyz, conn, mtype, sup, loads, dims = [], [], [], [], [], []
     for t in trusses:
-        nJ, dim = t.nJoint, t.dim
-        xyz.append(np.array([t.GetJointPosition(j) for j in range(nJ)], dtype=float).reshape(nJ, dim))
-        sup.append([t.GetSupportType(j) for j in range(nJ)])
-        loads.append(t.GetExternalForceVector().reshape(nJ, dim))
-        members = t.GetMembers(isProtect=False)
-        conn.append(np.array([[members[m][0], members[m][1]] for m in range(t.nMember)], dtype=np.int32))
-        mtype.append(np.array([[members[m][2].a, members[m][2].e, members[m][2].density]
-                               for m in range(t.nMember)], dtype=float))
-        dims.append(dim)
+        x, c, sections, supports, f = t.PackedArrays()
+        xyz.append(x); conn.append(c); mtype.append(sections); sup.append(supports); loads.append(f)
+        dims.append(t.dim)
     return pack_arrays(xyz, conn, mtype, sup, loads, dims)
 
 

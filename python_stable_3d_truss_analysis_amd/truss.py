@@ -300,6 +300,17 @@ class Truss:
             f[jointID] = vec
         return f.ravel()
 
+    def PackedArrays(self):
+        """This truss as the arrays the batched solver packs (`batch.pack_trusses`): positions [nJ, dim], member
+        end joints [nM, 2] int32, sections [nM, 3] = (a, e, density), support types (list), loads [nJ, dim] -
+        straight from the model's own lists, no per-joint getter calls."""
+        nJ, dim = len(self._pos), self._dim
+        xyz = np.array(self._pos, dtype=float).reshape(nJ, dim)
+        conn = np.array(self._ends, dtype=np.int32).reshape(len(self._bars), 2)
+        sections = np.array([(t.a, t.e, t.density) for t in (bar._type for bar in self._bars)],
+                            dtype=float).reshape(len(self._bars), 3)
+        return xyz, conn, sections, self._sup, self.GetExternalForceVector().reshape(nJ, dim)
+
     def GetKMatrix(self):
         """The dense global stiffness matrix, `[nJoint * dim, nJoint * dim]` (`truss.py:307-316`): every
         member's four dim x dim blocks `+- k c c^T` added at its joints' DOFs (DOF = joint * dim + axis),
@@ -343,9 +354,11 @@ class Truss:
         n = np.asarray(internal, dtype=float)[:nM]
         keep_u = (np.abs(u) >= ZERO_EPS).any(axis=1)
         keep_f = (np.abs(f) >= ZERO_EPS).any(axis=1)
-        self._displace = {int(j): u[j].copy() for j in np.flatnonzero(keep_u)}
-        self._external = {int(j): f[j].copy() for j in np.flatnonzero(keep_f)}
-        self._internal = {int(m): float(n[m]) for m in np.flatnonzero(np.abs(n) >= ZERO_EPS)}
+        ju, jf, jm = np.flatnonzero(keep_u), np.flatnonzero(keep_f), np.flatnonzero(np.abs(n) >= ZERO_EPS)
+        # (one copy per array, its rows handed out as the dict values: they do not alias the caller's arrays)
+        self._displace = dict(zip(ju.tolist(), u[ju]))
+        self._external = dict(zip(jf.tolist(), f[jf]))
+        self._internal = dict(zip(jm.tolist(), n[jm].tolist()))
         self._solved = True
 
     # --------------------------------------------------------------------- JSON
