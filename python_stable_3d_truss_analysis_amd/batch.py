@@ -933,20 +933,27 @@ class SolverWorkspace:
     def get(self, need):
         """Flat tensors of at least `need[kind]` elements each (zero-filled for the envelope metadata)."""
         t = self.torch
-        for kind, count in need.items():
-            have = self.buf.get(kind)
-            if have is None or have.numel() < count:
-                make = t.zeros if kind == "env" else t.empty
-                if have is not None:
-                    # a buffer that has to grow goes back to the driver first (the caching allocator would keep
-                    # the old block beside the new one for good), and grows with headroom: a stream of batches
-                    # of slightly different shapes settles after a few steps
-                    self.buf[kind] = have = None
-                    t.cuda.empty_cache()
-                    count = int(count) + int(count) // 8
-                self.buf[kind] = make([max(1, int(count))], dtype=getattr(t, self.KINDS[kind]), device=self.device)
-                if kind == "S" and os.environ.get("TRS_DEBUG_POISON"):
-                    self.buf[kind].fill_(float("nan"))
+        grow = {kind: int(count) for kind, count in need.items()
+                if self.buf.get(kind) is None or self.buf[kind].numel() < count}
+        regrown = [kind for kind in grow if self.buf.get(kind) is not None]
+        if regrown:
+            # buffers that have to grow are dropped first and come back with headroom: a stream of batches of
+            # slightly different shapes settles after a few steps.  The caching allocator keeps the dropped
+            # blocks for other tensors; they go back to the driver only when the device is short of memory
+            # (`empty_cache` costs a second with a hundred GB cached - never on the ordinary path)
+            for kind in regrown:
+                self.buf[kind] = None
+                grow[kind] += grow[kind] // 8
+            wanted = sum(grow[k] * t.empty((), dtype=getattr(t, self.KINDS[k])).element_size() for k in grow)
+            free, _ = t.cuda.mem_get_info(self.device)
+            reusable = t.cuda.memory_reserved(self.device) - t.cuda.memory_allocated(self.device)
+            if free + reusable // 2 < wanted:
+                t.cuda.empty_cache()
+        for kind, count in grow.items():
+            make = t.zeros if kind == "env" else t.empty
+            self.buf[kind] = make([max(1, count)], dtype=getattr(t, self.KINDS[kind]), device=self.device)
+            if kind == "S" and os.environ.get("TRS_DEBUG_POISON"):
+                self.buf[kind].fill_(float("nan"))
         return self.buf
 
 
