@@ -1509,6 +1509,9 @@ def solve_batch_streamed(packed: PackedBatch, device=None, reorder=True, pool=No
     `solve_batch(packed, reorder=...)`.  `solve_batch(..., pool=...)` routes big pinned batches here by itself."""
     torch, dev = _require_gpu(device)
     B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
+    if B == 0:
+        return BatchResult(np.zeros([0, nJ_max, 3]), np.zeros([0, nJ_max, 3]), np.zeros([0, nM_max]),
+                           np.zeros([0], dtype=np.int32))
     pool = pool if pool is not None else ResultPool()
     host_out = host_result_arrays(torch, pool, B, nJ_max, nM_max, dev)
     host_in = {f: torch.from_numpy(getattr(packed, f)) for f in RaggedSolver.GATHER}

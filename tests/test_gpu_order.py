@@ -379,6 +379,12 @@ def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
         import torch
         gpu.RaggedSolver(packed, host_io=({f: torch.from_numpy(getattr(packed, f)) for f in gpu.RaggedSolver.GATHER},
                                           {}))
+    # the ends of the range: no truss at all, one truss, a batch that is all small trusses (fused kernel, no order)
+    assert gpu.solve_batch_streamed(packed.take(np.arange(0)).pinned()).displace.shape == (0, packed.nJ_max, 3)
+    for sub in (packed.take(np.array([7])), gen.generate_cube_batch(np.array([3, 4, 5]), gridRange=(4, 4, 4), seed=1)):
+        a, b = gpu.solve_batch(sub, reorder=True), gpu.solve_batch_streamed(sub.pinned(), reorder=True)
+        for k in ("displace", "external", "internal", "info"):
+            np.testing.assert_array_equal(getattr(a, k), getattr(b, k), err_msg=k)
 
 
 def _random_trusses(rng, count):
