@@ -43,10 +43,18 @@ def test_time_consuming_flow_repeated_solves_of_a_2d_truss():
     truss = Truss(dim=2)
     truss.LoadFromJSON(_data("bar-47_input_0"))
     stored = H.load_json("bar-47_output_0")
+    import time
+    truss.Solve()                                    # (first call: library load, first launches)
+    ts = []
     for _ in range(30):
+        t0 = time.time()
         truss.Solve()
+        ts.append(time.time() - t0)
         assert truss.isSolved
     _same_results(truss, stored, truss.nJoint, truss.nMember, 2)
+    # the flow's own output is the mean time: the reference publishes 2.53 ms for this case (README.md:91, a laptop
+    # CPU); a call here - pack, upload, one kernel, download, result dicts - takes about 0.14 ms
+    assert sum(ts) / len(ts) < 2.53e-3
 
 
 def test_example_flow_build_a_space_truss_by_hand(tmp_path):
