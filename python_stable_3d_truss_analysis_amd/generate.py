@@ -237,12 +237,14 @@ def packed_to_json(packed: PackedBatch, b):
     dim, nJ, nM = int(packed.dim[b]), int(packed.nJ[b]), int(packed.nM[b])
     names = _SUPPORT_3D if dim == 3 else _SUPPORT_2D
     mask = 7 if dim == 3 else 3          # a 2D truss carries an extra z bit in the packed form
+    xyz, loads = packed.xyz[b, :nJ, :dim].tolist(), packed.loads[b, :nJ, :dim]
+    loaded = np.flatnonzero((np.abs(loads) >= 1e-10).any(axis=1))
     return {
-        "joint": [[packed.xyz[b, j, :dim].tolist(), names[int(packed.cbits[b, j]) & mask]] for j in range(nJ)],
-        "force": [[j, packed.loads[b, j, :dim].tolist()] for j in range(nJ)
-                  if np.any(np.abs(packed.loads[b, j, :dim]) >= 1e-10)],
-        "member": [[packed.conn[b, m].tolist(), [float(packed.A[b, m]), float(packed.E[b, m]),
-                                                 float(packed.rho[b, m])]] for m in range(nM)],
+        "joint": [[p, names[c & mask]] for p, c in zip(xyz, packed.cbits[b, :nJ].tolist())],
+        "force": [[int(j), loads[j].tolist()] for j in loaded],
+        "member": [[ends, [a, e, rho]] for ends, a, e, rho in zip(
+            packed.conn[b, :nM].tolist(), packed.A[b, :nM].tolist(), packed.E[b, :nM].tolist(),
+            packed.rho[b, :nM].tolist())],
     }
 
 

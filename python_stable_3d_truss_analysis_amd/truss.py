@@ -21,6 +21,13 @@ from .utils import (CheckDim, DimensionError, GetLength, InvaildJointError, IsZe
 
 
 def _distance(p, q):
+    """sqrt of the sum of the squared differences - the squares as `x ** 2.0`, summed left to right, exactly as
+    the generic form `sqrt(sum((b - a) ** 2.0 ...))` rounds (unrolled: this runs once per member of every truss
+    object that is built)."""
+    if len(p) == 3:
+        return math.sqrt((q[0] - p[0]) ** 2.0 + (q[1] - p[1]) ** 2.0 + (q[2] - p[2]) ** 2.0)
+    if len(p) == 2:
+        return math.sqrt((q[0] - p[0]) ** 2.0 + (q[1] - p[1]) ** 2.0)
     return math.sqrt(sum((b - a) ** 2.0 for a, b in zip(p, q)))
 
 
