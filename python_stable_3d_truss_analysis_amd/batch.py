@@ -969,6 +969,15 @@ def shared_workspace(torch, device):
     return _SHARED_WORKSPACES[key]
 
 
+def release_workspaces():
+    """Drop the shared workspaces of every device (they hold the largest slab a call on that device needed, up to
+    48 GB, for the life of the process) and hand the cached blocks back to the driver."""
+    import torch
+    _SHARED_WORKSPACES.clear()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
 class _MaskedStreams:
     """The three streams of the host-fed pipeline with their compute units set apart (`trs_stream_create_masked`):
     pull and push get CUs of their own - consecutive mask bits go round the XCDs, so eight are one CU of every
