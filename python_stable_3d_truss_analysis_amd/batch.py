@@ -1048,7 +1048,12 @@ def _pipeline_streams(torch, dev, lib):
         if pull_cus <= 0 or 2 * (pull_cus + push_cus) > n_cu:   # (a partitioned or small device: no CUs to spare)
             _PIPELINE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         else:
-            _PIPELINE_STREAMS[key] = _MaskedStreams(torch, dev, lib, pull_cus, push_cus)
+            try:
+                _PIPELINE_STREAMS[key] = _MaskedStreams(torch, dev, lib, pull_cus, push_cus)
+            except HipExtensionError as exc:   # (a runtime that refuses CU masks: the pipeline still works, slower)
+                import warnings
+                warnings.warn(f"CU-masked streams are not available ({exc}); the host-fed pipeline uses ordinary streams")
+                _PIPELINE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev))
     return _PIPELINE_STREAMS[key]
 
 
