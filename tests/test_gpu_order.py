@@ -317,7 +317,10 @@ def test_masked_streams_run_kernels_and_refuse_bad_masks(gpu):
     import ctypes
     import torch
     lib = gpu._capi.load()
-    streams = gpu._MaskedStreams(torch, torch.device("cuda:0"), lib, 8, 4)
+    try:
+        streams = gpu._MaskedStreams(torch, torch.device("cuda:0"), lib, 8, 4)
+    except gpu.HipExtensionError as exc:       # (the pipeline then runs on ordinary streams, `_pipeline_streams`)
+        pytest.skip(f"this runtime refuses CU-masked streams: {exc}")
     P, Z = ctypes.c_void_p, ctypes.c_size_t
     src = torch.arange(64 * 100, dtype=torch.float64, device="cuda").reshape(64, 100)
     rows = torch.arange(63, -1, -1, dtype=torch.int64, device="cuda")
