@@ -82,15 +82,26 @@ def member_cosines(p0, p1, length):
     return [(p1[i] - p0[i]) / length for i in range(len(p0))]
 
 
-def member_matK(p0, p1, a, e):
-    """truss.py:65-86: k * [[cc^T, -cc^T], [-cc^T, cc^T]] built entry by entry."""
-    length = member_length(p0, p1)
+def member_matK(p0, p1, a, e, length=None):
+    """truss.py:65-86: k * [[cc^T, -cc^T], [-cc^T, cc^T]] from the direction cosines, one nested list ->
+    one np.array -> one scalar multiplication, as the reference builds it (the products l*m etc. are formed
+    once and negated by the unary minus, so the entries carry the same bits).  `length` is the member's cached
+    length (the reference computes it once per member, truss.py:19,98, not once per matK)."""
+    if length is None:
+        length = member_length(p0, p1)
     k = e * a / length                                   # truss.py:56-58
     cs = member_cosines(p0, p1, length)
-    dim = len(cs)
-    cc = [[cs[r] * cs[s] if r != s else cs[r] ** 2. for s in range(dim)] for r in range(dim)]
-    top = [cc[r] + [-v for v in cc[r]] for r in range(dim)]
-    bot = [[-v for v in cc[r]] + cc[r] for r in range(dim)]
+    if len(cs) == 3:
+        x, y, z = cs
+        xx, yy, zz, xy, xz, yz = x ** 2., y ** 2., z ** 2., x * y, x * z, y * z
+        r0, r1, r2 = [xx, xy, xz], [xy, yy, yz], [xz, yz, zz]
+    else:
+        x, y = cs
+        xx, yy, xy = x ** 2., y ** 2., x * y
+        r0, r1, r2 = [xx, xy], [xy, yy], None
+    rows = [r for r in (r0, r1, r2) if r is not None]
+    top = [r + [-v for v in r] for r in rows]
+    bot = [[-v for v in r] + r for r in rows]
     return k * np.array(top + bot)
 
 
@@ -99,14 +110,35 @@ def joint_positions(data):
     return [tuple(float(vec[i]) for i in range(dim)) for vec, _ in data["joint"]]
 
 
+class Prepared:
+    """A truss as the reference holds it between `LoadFromJSON` and `Solve()` (truss.py:110-121, 401-421):
+    positions as float tuples, members with their CACHED length (Member.__init__, truss.py:19), the load dict
+    and the supports.  `solve(prepare(data))` then costs what the reference's `Truss.Solve()` costs - the
+    reference's published protocol (example.py:1-25) loads the truss once and times only `Solve()`."""
+    __slots__ = ("data", "dim", "pos", "members", "loads", "supports", "lengths")
+
+    def __init__(self, data):
+        self.data = data
+        self.dim = truss_dim(data)
+        self.pos = joint_positions(data)
+        self.members = [(int(j0), int(j1), float(a), float(e), float(rho)) for (j0, j1), (a, e, rho) in data["member"]]
+        self.lengths = [member_length(self.pos[j0], self.pos[j1]) for j0, j1, _a, _e, _r in self.members]
+        self.loads = applied_loads(data)
+        self.supports = [s for _, s in data["joint"]]
+
+
+def prepare(data):
+    return data if isinstance(data, Prepared) else Prepared(data)
+
+
 def global_K(data):
     """truss.py:307-316: dense zero-initialised K, four dim x dim block += per member,
     members in ID order."""
-    dim = truss_dim(data)
-    pos = joint_positions(data)
+    p = prepare(data)
+    dim, pos = p.dim, p.pos
     K = np.zeros([len(pos) * dim, len(pos) * dim])
-    for (j0, j1), (a, e, _rho) in data["member"]:
-        Ke = member_matK(pos[j0], pos[j1], float(a), float(e))
+    for (j0, j1, a, e, _rho), length in zip(p.members, p.lengths):
+        Ke = member_matK(pos[j0], pos[j1], a, e, length)
         for i, x in ((0, j0 * dim), (dim, j1 * dim)):
             for j, y in ((0, j0 * dim), (dim, j1 * dim)):
                 K[x: x + dim, y: y + dim] += Ke[i: i + dim, j: j + dim]
@@ -115,43 +147,44 @@ def global_K(data):
 
 def force_vector(data):
     """truss.py:303-304."""
-    dim = truss_dim(data)
-    f = np.zeros([len(data["joint"]), dim])
-    for joint_id, vec in applied_loads(data).items():
+    p = prepare(data)
+    f = np.zeros([len(p.pos), p.dim])
+    for joint_id, vec in p.loads.items():
         f[joint_id] = vec
     return f.ravel()
 
 
 def free_mask(data):
     """truss.py:319-326: True where the displacement is unknown."""
-    dim = truss_dim(data)
-    mask = np.ones([len(data["joint"]) * dim], dtype=np.bool_)
-    for joint_id, (_, support) in enumerate(data["joint"]):
+    p = prepare(data)
+    dim = p.dim
+    mask = np.ones([len(p.pos) * dim], dtype=np.bool_)
+    for joint_id, support in enumerate(p.supports):
         mask[joint_id * dim: (joint_id + 1) * dim] = np.logical_not(resistance_mask(support, dim))
     return mask
 
 
 def truss_weight(data):
     """truss.py:52-54,166-168: sum of a * L * density."""
-    pos = joint_positions(data)
-    return sum(float(a) * member_length(pos[j0], pos[j1]) * float(rho)
-               for (j0, j1), (a, _e, rho) in data["member"])
+    p = prepare(data)
+    return sum(a * length * rho for (_j0, _j1, a, _e, rho), length in zip(p.members, p.lengths))
 
 
 def solve(data, check_stable=True):
-    """truss.py:329-364 with dense (un-sparsified) outputs.
+    """truss.py:329-364 with dense (un-sparsified) outputs.  `data`: the JSON dict, or `prepare(data)` (the
+    truss as the reference holds it once loaded - what a timing of `Solve()` alone must start from).
 
     Returns dict: u [nJ,dim], f_ext [nJ,dim] (applied load at free DOFs, K@u at
     constrained DOFs), N [nM] (axial force, tension positive), weight, K_ff, mask.
     Raises OracleNotStable (counting test) or numpy.linalg.LinAlgError (singular K_ff).
     """
-    if check_stable and not is_stable(data):
+    p = prepare(data)
+    if check_stable and not is_stable(p.data):
         raise OracleNotStable("The truss is not stable !")
-    dim = truss_dim(data)
-    pos = joint_positions(data)
-    K = global_K(data)
-    f = force_vector(data)
-    mask = free_mask(data)
+    dim, pos = p.dim, p.pos
+    K = global_K(p)
+    f = force_vector(p)
+    mask = free_mask(p)
 
     u = np.zeros([len(pos) * dim])
     K_ff = K[mask, :][:, mask]
@@ -160,16 +193,16 @@ def solve(data, check_stable=True):
     not_mask = np.logical_not(mask)
     f[not_mask] = (K[not_mask, :] @ u.reshape(-1, 1)).ravel()   # truss.py:348-349
 
-    N = np.zeros([len(data["member"])])
-    for m, ((j0, j1), (a, e, _rho)) in enumerate(data["member"]):
+    N = np.zeros([len(p.members)])
+    for m, ((j0, j1, a, e, _rho), length) in enumerate(zip(p.members, p.lengths)):
         idx = list(range(j0 * dim, (j0 + 1) * dim)) + list(range(j1 * dim, (j1 + 1) * dim))
-        Ke = member_matK(pos[j0], pos[j1], float(a), float(e))
+        Ke = member_matK(pos[j0], pos[j1], a, e, length)
         v = (Ke[dim:] @ u[idx].reshape(-1, 1)).ravel()   # force on joint1, truss.py:357
         axis = np.array(pos[j1]) - np.array(pos[j0])     # truss.py:89-91
         sign = 1. if np.dot(axis, v) > 0 else -1.
         N[m] = sign * (v ** 2).sum() ** 0.5              # utils.py:87-88
     return {"u": u.reshape(-1, dim), "f_ext": f.reshape(-1, dim), "N": N,
-            "weight": truss_weight(data), "K_ff": K_ff, "mask": mask}
+            "weight": truss_weight(p), "K_ff": K_ff, "mask": mask}
 
 
 def sparsify(result):

@@ -806,20 +806,20 @@ def envelope_reach(packed: PackedBatch, perm=None):
 
 
 def joint_order(packed: PackedBatch, reorder):
-    """The permutation `solve_batch(..., reorder=...)` applies: "profile" = `profile_permutation` with every
-    candidate (what a RESIDENT batch wants: the order is found once, `DeviceBatch(reorder=True)`), True /
-    "fast" = the same with one coordinate sweep instead of six (80 % of the gain for half the host time:
-    what a host-in / host-out call wants, where finding the order is the longest step), "rcm" =
-    `rcm_permutation`; an int32 array [B, nJ_max] found earlier (e.g. on another thread) passes through."""
+    """The HOST-side permutation for a `reorder=` argument, with the same meaning of the names as `order_plan`:
+    True / "profile" = `profile_permutation` with every candidate, "fast" = the same with one coordinate sweep
+    instead of six (80 % of the gain for half the host time: what a host-in / host-out call wants when the order
+    has to be found on the host, where it is the longest step), "rcm" = `rcm_permutation`; an int32 array
+    [B, nJ_max] found earlier (e.g. on another thread) passes through."""
     if isinstance(reorder, np.ndarray):
         if reorder.shape != (packed.B, packed.nJ_max):
             raise ValueError(f"joint order of shape {reorder.shape}, expected {(packed.B, packed.nJ_max)}")
         return np.ascontiguousarray(reorder, dtype=np.int32)
-    if reorder is True or reorder == "fast":
+    if reorder == "fast":
         return profile_permutation(packed, effort=1)
     if reorder == "rcm":
         return rcm_permutation(packed)
-    if reorder == "profile":
+    if reorder is True or reorder == "profile":
         return profile_permutation(packed)
     raise ValueError(f"unknown joint order {reorder!r} (True, 'profile', 'fast', 'rcm' or a permutation array)")
 
@@ -961,9 +961,14 @@ _SHARED_WORKSPACES = {}
 
 
 def shared_workspace(torch, device):
-    """The process's `SolverWorkspace` of `device` for bucket pipelines that run one after the other on the
-    current stream (the chunks of `data.dataset_chunks`): one slab for all of them instead of one per call."""
-    key = str(device)
+    """The process's `SolverWorkspace` of (`device`, CURRENT STREAM) for bucket pipelines that run one after the
+    other on that stream (the chunks of `data.dataset_chunks`): one slab for all of them instead of one per call.
+    The buffers are re-used without any synchronisation of their own - stream order is the only thing that keeps
+    one call's factorisation from the next call's assembly -, hence one workspace per stream: calls issued on
+    different streams of a device (or from threads with different current streams) get different buffers.  Two
+    threads that drive the SAME stream must serialise their calls themselves, as for any other stream-ordered
+    resource."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
     if key not in _SHARED_WORKSPACES:
         _SHARED_WORKSPACES[key] = SolverWorkspace(torch, device)
     return _SHARED_WORKSPACES[key]
@@ -991,16 +996,20 @@ class _MaskedStreams:
         words = (n_cu + 31) // 32
         sets = (range(0, pull_cus), range(pull_cus + push_cus, n_cu), range(pull_cus, pull_cus + push_cus))   # pull, run, push
         self.lib, self.handles, self.streams = lib, [], []
-        with torch.cuda.device(dev):
-            for cus in sets:
-                mask = (ctypes.c_uint32 * words)()
-                for c in cus:
-                    mask[c // 32] |= 1 << (c % 32)
-                handle = ctypes.c_void_p()
-                _capi.check(lib.trs_stream_create_masked(mask, words, ctypes.byref(handle)), "trs_stream_create_masked")
-                self.handles.append(handle)
-                self.streams.append(torch.cuda.ExternalStream(handle.value, device=dev))
         self.torch, self.dev = torch, dev
+        with torch.cuda.device(dev):
+            try:
+                for cus in sets:
+                    mask = (ctypes.c_uint32 * words)()
+                    for c in cus:
+                        mask[c // 32] |= 1 << (c % 32)
+                    handle = ctypes.c_void_p()
+                    _capi.check(lib.trs_stream_create_masked(mask, words, ctypes.byref(handle)), "trs_stream_create_masked")
+                    self.handles.append(handle)
+                    self.streams.append(torch.cuda.ExternalStream(handle.value, device=dev))
+            except Exception:
+                self.close()   # (a runtime that refuses the 2nd or 3rd mask must not leak the streams made so far)
+                raise
 
     def __iter__(self):
         return iter(self.streams)
@@ -1113,8 +1122,15 @@ class RaggedSolver:
             self.inputs = {f: (tensors[f].contiguous() if tensors is not None else up(getattr(packed, f))) for f in self.GATHER}
         plan = order_plan(reorder, nJ_max, nM_max) if B else None
         self.plan = plan
+        # A batch whose LARGEST truss does not fit `trs_joint_order` gets a host plan - but its buckets are ordered
+        # one by one with tables sized by the bucket, so every bucket that fits is still ordered on the device
+        # (unless the caller forced a host order or gave a permutation).
+        self.device_effort = plan[1] if plan is not None and plan[0] == "device" else None
+        if plan is not None and plan[0] == "host" and (reorder is True or reorder in ("profile", "fast")):
+            self.device_effort = 1 if reorder == "fast" else 2
         self.ordered = None        # host plan: renumbered xyz / conn / cbits / loads + perm of the FULL batch
         if plan is not None and plan[0] != "device":
+            # (found for the whole batch: the buckets that do not fit the device kernel take their rows from it)
             host = packed if isinstance(packed, PackedBatch) else packed.to_packed(tensors)
             perm = joint_order(host, plan[1])
             renum = permute_joints(host, perm)
@@ -1173,7 +1189,8 @@ class RaggedSolver:
                 need["uf"] = max(need["uf"], Bb * db.rows)
                 need["work"] = max(need["work"], Bb * self.lib.trs_assemble_work_bytes(nJ_b, nM_b, n_b))
                 need["env"] = max(need["env"], Bb * self.lib.trs_env_ints(n_b))
-            on_device = renumbered and plan[0] == "device"
+            on_device = renumbered and self.device_effort is not None and \
+                (plan[0] == "device" or bool(self.lib.trs_joint_order_fits(nJ_b, nM_b)))
             if on_device and not self.host_io:   # the bucket's rows in the caller's numbering: input of its trs_joint_order
                 need["raw_j"], need["raw_m"] = max(need["raw_j"], Bb * nJ_b), max(need["raw_m"], Bb * nM_b)
             self.buckets.append({"rows": up(np.ascontiguousarray(idx, dtype=np.int64)), "dev": db, "count": Bb,
@@ -1301,7 +1318,7 @@ class RaggedSolver:
                     timed("gather", lambda: _capi.check(self.lib.trs_copy_rows(
                         *gather, bk["count"], bk["rows"].data_ptr(), 0, 0, stream), "trs_copy_rows (gather)"))
                     if bk["order_on_device"]:
-                        timed("order", lambda: joint_order_device(torch, bk["raw"], effort=self.plan[1], out=bk["ordered"]))
+                        timed("order", lambda: joint_order_device(torch, bk["raw"], effort=self.device_effort, out=bk["ordered"]))
                     for slot in slots:
                         if sections[slot] is not None:
                             bk["dev"].A.fill_(float(sections[slot][0]))
@@ -1334,7 +1351,7 @@ class RaggedSolver:
                     s_run.wait_event(pulled)
                     mark(f"bucket {k} run begins", s_run)
                     if bk["order_on_device"]:
-                        joint_order_device(torch, bk["raw"], effort=self.plan[1], out=bk["ordered"])
+                        joint_order_device(torch, bk["raw"], effort=self.device_effort, out=bk["ordered"])
                     bk["dev"].solve()
                     solved = torch.cuda.Event()
                     solved.record(s_run)
@@ -1567,7 +1584,10 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     uploaded, reordered and bucketed once, only A and E change between the solves.
 
     `on_device=True` leaves the results on the GPU (`DeviceResult`, torch tensors in the caller's joint
-    order, plus the resident inputs) for device-side consumers such as the graph-feature kernel.
+    order, plus the resident inputs) for device-side consumers such as the graph-feature kernel.  With
+    `device_inputs` such a call runs in the `shared_workspace` of (device, current stream): its kernels - and
+    the tensors it returns - are ordered by THAT stream only; a consumer on another stream must wait for it
+    (`stream.wait_stream`), and callers that drive one stream from several threads must serialise their calls.
 
     Host side of a large batch: the joint order is found on a worker thread while the inputs go up; a
     `PackedBatch.pinned()` uploads by DMA; `pool=ResultPool()` downloads into reused page-locked buffers

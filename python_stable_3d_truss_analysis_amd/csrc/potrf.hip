@@ -806,7 +806,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
     ChScratch& sc = scratch[wave];
     double* Wl = &wlds[wave][0][0];
     int bad_col = 0;
-    Stamps st;  // 0 tile loads, 1 block update, 2 factorisation, 3 load column + block stores, 4 items, 5 fence
+    Stamps st;  // 0 tile loads, 1 block update, 2 factorisation, 3 load column + block stores, 4 items, 5 fence, 6 substitution
     st.start();
 
     // The diagonal block's stiffness tiles and load-vector entries of a panel are not touched by the panel before
@@ -935,7 +935,9 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
 #endif
                 t[s][s] = f.u;
                 __builtin_amdgcn_wave_barrier();
+#ifndef TRS_EXP_IGNORE_PIVOT   // (knock-out timing builds: their wrong values must not end the panel loop early)
                 if (f.bad >= 0) bad_col = r0 + 16 * s + f.bad + 1;
+#endif
             }
             if (bad_col == 0) {
                 if (s + 1 < CT) {
@@ -1021,7 +1023,6 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
 #endif
         st.mark(5);
     }
-    st.flush();
     if (lane == 0) info[b] = bad_col;
     // The substitution U u = y by the same wave, right behind its factorisation (trs_subst.h): the factor's last
     // panels are still in the caches, the launch of trs_potrs_batched finds nothing left to do for this matrix,
@@ -1033,7 +1034,10 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
             int* meta = const_cast<int*>(env.last) + n_pad_max / 64;
             meta[0] = env.slack | TRS_ENV_SUBSTITUTED;
         }
+        st.drain();
+        st.mark(6);
     }
+    st.flush();
 }
 
 }  // namespace

@@ -41,22 +41,101 @@ def shard_batch(packed: PackedBatch, rank, world_size):
     return packed.take(idx), idx
 
 
-def gather_results(local: BatchResult, idx, total, group=None):
-    """Reassemble the full-batch dense results on every rank (host-side gather of small arrays)."""
+def _same_host(group):
+    """True when every rank of the group runs on this host (then results travel through shared memory)."""
+    import socket
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    parts = [None] * world
-    dist.all_gather_object(parts, (idx, local.displace, local.external, local.internal, local.info),
+    names = [None] * dist.get_world_size(group)
+    dist.all_gather_object(names, (socket.gethostname(), os.stat("/dev/shm").st_dev if os.path.isdir("/dev/shm") else -1),
                            group=group)
-    nJ = max(p[1].shape[1] for p in parts)
-    nM = max(p[3].shape[1] for p in parts)
+    return all(n == names[0] and n[1] != -1 for n in names)
+
+
+def gather_results(local: BatchResult, idx, total, group=None, widths=None):
+    """Reassemble the full-batch dense results on every rank.  `widths` = (nJ_max, nM_max) of the full batch
+    (every rank holds the same `packed`, so `solve_batch_distributed` passes them; else they are agreed on first).
+
+    Ranks of ONE host (the case this package is built for: the GPUs of one node): rank 0 creates four files of
+    the full-batch shapes in /dev/shm (fresh pages are zero = the result padding), every rank maps them
+    (`numpy.memmap`) and writes ITS rows, and every rank returns arrays that are views of the same memory - no
+    pickling, no copy of another rank's rows, nothing left in /dev/shm (the names are unlinked once every rank has
+    mapped them; the memory lives until the last array is dropped, the mapping being the array's base object).
+    65 536 cube trusses (2.2 GB of results): one memcpy of each rank's share.
+    Across hosts: one `all_gather` of a contiguous float64 buffer per rank (no Python objects)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if widths is None:
+        w = [None] * world
+        dist.all_gather_object(w, (local.displace.shape[1], local.internal.shape[1]), group=group)
+        widths = (max(x[0] for x in w), max(x[1] for x in w))
+    nJ, nM = int(widths[0]), int(widths[1])
+    shapes = (([total, nJ, 3], np.float64), ([total, nJ, 3], np.float64), ([total, nM], np.float64), ([total], np.int32))
+    parts = (local.displace, local.external, local.internal, local.info)
+    if _same_host(group):
+        import tempfile
+        paths = [None] * 4
+        if rank == 0:
+            for k in range(4):
+                fd, paths[k] = tempfile.mkstemp(prefix="trs_gather_", dir="/dev/shm")
+                os.close(fd)
+        dist.broadcast_object_list(paths, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        try:
+            if rank == 0:   # sizes the files; the others map what exists
+                views = []
+                for path, (shape, dt) in zip(paths, shapes):
+                    shape1 = tuple(max(1, d) for d in shape)
+                    # the pages are allocated (zeroed) HERE, in one call: ranks that fault fresh pages of one
+                    # tmpfs file in at the same time serialise on it (measured: 1.8 s instead of 0.3 s for 0.55 GB)
+                    with open(path, "r+b") as fh:
+                        os.posix_fallocate(fh.fileno(), 0, int(np.prod(shape1)) * np.dtype(dt).itemsize)
+                    views.append(np.memmap(path, dtype=dt, mode="r+", shape=shape1))
+            dist.barrier(group)
+            if rank != 0:
+                views = [np.memmap(path, dtype=dt, mode="r+", shape=tuple(max(1, d) for d in shape))
+                         for path, (shape, dt) in zip(paths, shapes)]
+            dist.barrier(group)               # every rank has mapped the files:
+        finally:
+            if rank == 0:
+                for path in paths:            # the names can go (nothing stays in /dev/shm whatever happens next)
+                    try:
+                        os.unlink(path)
+                    except OSError:
+                        pass
+        views = [np.asarray(v)[tuple(slice(0, d) for d in shape)] for v, (shape, _) in zip(views, shapes)]
+        for view, part in zip(views, parts):
+            if part.ndim == 1:
+                view[idx] = part
+            else:
+                view[idx, :part.shape[1]] = part
+        dist.barrier(group)               # every rank's rows are in place
+        return BatchResult(views[0], views[1], views[2], views[3])
+    # several hosts: one contiguous buffer per rank (rows padded to the largest shard), gathered as tensors
+    counts = [None] * world
+    dist.all_gather_object(counts, len(idx), group=group)
+    cmax, width = max(counts + [1]), 6 * nJ + nM + 2
+    buf = np.zeros([cmax, width])
+    k = len(idx)
+    buf[:k, 0] = idx
+    buf[:k, 1] = local.info
+    buf[:k, 2:2 + 3 * local.displace.shape[1]] = local.displace.reshape(k, -1)
+    buf[:k, 2 + 3 * nJ:2 + 3 * nJ + 3 * local.external.shape[1]] = local.external.reshape(k, -1)
+    buf[:k, 2 + 6 * nJ:2 + 6 * nJ + local.internal.shape[1]] = local.internal
+    on_gpu = dist.get_backend(group) == "nccl"
+    mine = torch.from_numpy(buf)
+    if on_gpu:
+        mine = mine.cuda()
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine, group=group)
     out = BatchResult(np.zeros([total, nJ, 3]), np.zeros([total, nJ, 3]), np.zeros([total, nM]),
                       np.zeros([total], dtype=np.int32))
-    for pidx, u, f, n, info in parts:
-        out.displace[pidx, :u.shape[1]] = u
-        out.external[pidx, :f.shape[1]] = f
-        out.internal[pidx, :n.shape[1]] = n
-        out.info[pidx] = info
+    for r, t in enumerate(got):
+        a = t.cpu().numpy()[:counts[r]]
+        rows = a[:, 0].astype(np.int64)
+        out.info[rows] = a[:, 1].astype(np.int32)
+        out.displace[rows] = a[:, 2:2 + 3 * nJ].reshape(-1, nJ, 3)
+        out.external[rows] = a[:, 2 + 3 * nJ:2 + 6 * nJ].reshape(-1, nJ, 3)
+        out.internal[rows] = a[:, 2 + 6 * nJ:2 + 6 * nJ + nM]
     return out
 
 
@@ -86,7 +165,7 @@ def solve_batch_distributed(packed: PackedBatch, device=None, gather=True, reord
         np.zeros([0], dtype=np.int32))
     if not gather:
         return local, idx
-    return gather_results(local, idx, packed.B, group)
+    return gather_results(local, idx, packed.B, group, widths=(packed.nJ_max, packed.nM_max))
 
 
 # ---- single-controller path: one persistent worker process per GPU ------------------------------------

@@ -114,6 +114,35 @@ def test_bench_launches_its_own_ranks():
     assert line["dataset"]["rank0_samples"] == 512
 
 
+def test_bench_eight_ranks_smoke():
+    """What the driver's scaling run does at N = 8, made boring beforehand: `bench.py --gpus 8` (ranks sharing the
+    box's GPU(s) where there are fewer than eight: --oversubscribe) with tiny workloads - eight processes come up,
+    rendezvous, run every leg, and rank 0 prints ONE JSON line; every rank's native host helpers are limited to its
+    share of the host CPUs."""
+    import torch
+    from python_stable_3d_truss_analysis_amd.generate import available_cpus
+    ndev = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--batch", "128", "--no-cpu-baseline", "--no-pcie", "--cube-batch", "256", "--cube-steps", "1",
+           "--dataset-samples", "256", "--no-dense-ref"]
+    if ndev < 8:
+        cmd.append("--oversubscribe")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["ranks"] == 8 and line["n_gpus"] == min(8, ndev)
+    assert line["info_nonzero"] == 0 and line["value"] > 0
+    assert line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"]
+    assert line["host_threads_per_rank"] == max(1, available_cpus() // 8)
+    cube = line["cube_batch"]
+    assert "error" not in cube and cube["info_nonzero"] == 0 and cube["batch_per_gpu"] == 256
+    assert cube["value"] > 0 and cube["rank_ms_per_step"]["min"] <= cube["rank_ms_per_step"]["max"]
+    assert line["dataset"]["value"] > 0 and line["dataset"]["rank0_samples"] == 256
+
+
 def test_ga_population_sharded_over_two_workers():
     """Config 4 in its sharded form: the population split over two workers gives the same fitness
     triples as the single-device evaluation."""

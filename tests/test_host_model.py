@@ -324,7 +324,8 @@ def test_profile_order_is_valid_never_worse_than_rcm_and_cheaper_on_cube_trusses
     # effort levels: more candidates never cost more; `True` is the one-sweep order of host-in / host-out calls
     costs = [sum(_envelope_cost(p, b, batch.profile_permutation(p, effort=e)[b])[0] for b in range(12)) for e in (0, 1, 2)]
     assert costs[2] <= costs[1] <= costs[0]
-    np.testing.assert_array_equal(batch.joint_order(p, True), batch.profile_permutation(p, effort=1))
+    np.testing.assert_array_equal(batch.joint_order(p, "fast"), batch.profile_permutation(p, effort=1))
+    np.testing.assert_array_equal(batch.joint_order(p, True), perm)   # True = every candidate, as order_plan(True)
     np.testing.assert_array_equal(batch.joint_order(p, "profile"), perm)
     np.testing.assert_array_equal(batch.joint_order(p, perm), perm)
     with pytest.raises(ValueError):

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build experiment variants of the solver library with different potrf tuning macros:
 #   tools/build_variants.sh "tag1:-DTRS_POTRF_RS=2 -DTRS_POTRF_WAVES_PER_SIMD=4" "tag2:..."
+#   ONLY="potrf" tools/build_variants.sh ...   recompiles just the named sources and links the product build's other objects
 # -> python_stable_3d_truss_analysis_amd/variants/libtrs_<tag>.so   (git-ignored; travels with gpurun)
 set -e
 cd "$(dirname "$0")/../python_stable_3d_truss_analysis_amd/csrc"
@@ -9,6 +10,7 @@ for spec in "$@"; do
   tag=${spec%%:*}; flags=${spec#*:}
   objs=""
   for f in dofmap assemble potrf potrs recover small graphfeat order rows cubegen capi; do
+    if [ -n "${ONLY:-}" ] && ! echo " $ONLY " | grep -q " $f "; then objs="$objs $f.o"; continue; fi
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-value $flags -c $f.hip -o /tmp/var_${tag}_$f.o &
     objs="$objs /tmp/var_${tag}_$f.o"
   done
