@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define TRS_ABI_VERSION 8
+#define TRS_ABI_VERSION 9
 
 /* trs_assemble flags */
 #define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests); implies the slab form */
@@ -215,6 +215,22 @@ int trs_graph_features_dev(int B, int nJ_max, int nM_max, const double *xyz, con
                            const double *u_pri, const double *N_pri, double fixedArea, double forceScale,
                            double displaceScale, double positionScale, int regression, float *joint_x,
                            float *member_x, float *joint_y, float *member_y, double *weight, void *stream);
+
+/* The same features in PACKED form - the sink of the dataset path (BASELINE config 5: "results streamed to PyG
+ * HeteroData"; reference TrussHeteroDataCreator.__CreateGraphData / __CreateEdges, data.py:238-282): the joint rows of
+ * all trusses back to back (truss b: rows joint_off[b] .. joint_off[b] + nJ[b] - 1 of joint_x [sum nJ][FJ] and
+ * joint_y [sum nJ][3]), the member rows likewise (member_off, member_x [sum nM][FM], member_y [sum nM][1]) - exactly
+ * the tensors a HeteroData of every sample slices, with no padding to carry across PCIe - and j2m_joint
+ * [sum nM][2] (int32), the members' end joints = row 0 of a sample's `j2m` edge index (row 1 is 0,0,1,1,2,2,...;
+ * `m2j` is the two rows swapped; data.py:238-247), or NULL.  joint_off / member_off: exclusive prefix sums of nJ / nM
+ * (int64, device).  Values bit-identical to trs_graph_features_dev. */
+int trs_graph_features_packed(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
+                              const double *A, const double *rho, const uint8_t *cbits, const double *loads,
+                              const int32_t *nJ, const int32_t *nM, const double *u_act, const double *N_act,
+                              const double *u_pri, const double *N_pri, double fixedArea, double forceScale,
+                              double displaceScale, double positionScale, int regression,
+                              const int64_t *joint_off, const int64_t *member_off, float *joint_x, float *member_x,
+                              float *joint_y, float *member_y, int32_t *j2m_joint, double *weight, void *stream);
 
 /* Joint order on the device (no reference counterpart: slientruss3d numbers joints in insertion order,
  * truss.py:175; the workload is its GenerateRandomCubeTrusses loop, generate.py:342-374, whose trusses are far

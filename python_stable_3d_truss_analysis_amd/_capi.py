@@ -33,6 +33,8 @@ SIGNATURES = {
                              _D, _D, _P, _P, _P, _P]),
     "trs_graph_features_dev": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D,
                                     _I, _P, _P, _P, _P, _P, _P]),
+    "trs_graph_features_packed": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _D, _D,
+                                       _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "trs_joint_order_fits": (_I, [_I, _I]),
     "trs_joint_order": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "trs_cubegen_dev": (_I, [_I, ctypes.c_uint64, _I, _I, _I, _P, _I, _I, _I, _D, _D, _P, _I, _I, _P, _I, _I, _I,
@@ -45,7 +47,7 @@ SIGNATURES = {
 }
 
 #: must equal TRS_ABI_VERSION of include/trs_solver.h
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 

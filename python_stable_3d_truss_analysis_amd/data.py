@@ -461,6 +461,296 @@ def dataset_chunks(n_samples, rank=0, world=1, chunk=32768, seed=0, numCubeRange
             yield first, packed, device_side(packed, order)
 
 
+class _PackedFeatureJob:
+    """The two solves + the packed feature kernel of one batch, split into SET-UP (everything that copies between
+    host and device: the bucket index lists of the `RaggedSolver`, the row offsets) and RUN (kernel launches only).
+    `dataset_stream` sets a chunk up BEFORE it queues the previous chunk's large device -> host copy: small copies
+    of either direction submitted behind a 2 GB copy wait for all of it, and the chunk's device work with them."""
+
+    def __init__(self, packed, fixedMemberType, taskType, forceScale, displaceScale, positionScale, device, reorder,
+                 device_inputs):
+        import torch
+        from .batch import DeviceBatch, RaggedSolver, _require_gpu, shared_workspace
+        if (np.asarray(packed.dim) != 3).any():
+            raise NotImplementedError("graph features are defined for 3D trusses (utils.py:105-113)")
+        torch, dev = _require_gpu(device if device_inputs is None else device_inputs["xyz"].device)
+        self.torch, self.dev, self.packed = torch, dev, packed
+        self.regression = taskType == TaskType.REGRESSION
+        self.fixed = fixedMemberType
+        self.scales = (float(forceScale), float(displaceScale), float(positionScale))
+        self.sections = [None] + ([(fixedMemberType.a, fixedMemberType.e, fixedMemberType.density)]
+                                  if fixedMemberType is not None else [])
+        if device_inputs is None:
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            device_inputs = {f: up(getattr(packed, f)) for f in DeviceBatch.INPUT_FIELDS}
+        self.inputs = device_inputs
+        B = packed.B
+        self.solver = RaggedSolver(packed, dev, reorder=reorder, tensors=device_inputs,
+                                   workspace=shared_workspace(torch, dev), n_variants=len(self.sections))
+        self.FJ, self.FM = _feature_shapes(B, 0, 0, fixedMemberType is not None, self.regression)
+        self.joint_off = np.zeros([B + 1], dtype=np.int64)
+        self.member_off = np.zeros([B + 1], dtype=np.int64)
+        np.cumsum(packed.nJ, out=self.joint_off[1:])
+        np.cumsum(packed.nM, out=self.member_off[1:])
+        self.offs = torch.from_numpy(np.stack([self.joint_off[:-1], self.member_off[:-1]])).to(dev)
+        SJ, SM = int(self.joint_off[-1]), int(self.member_off[-1])
+        self.shapes = {"joint_x": ([SJ, self.FJ], torch.float32), "member_x": ([SM, self.FM], torch.float32),
+                       "joint_y": ([SJ, 3], torch.float32), "member_y": ([SM, 1], torch.float32),
+                       "j2m_joint": ([SM, 2], torch.int32), "weight": ([B], torch.float64)}
+        if not self.regression:
+            del self.shapes["joint_y"], self.shapes["member_y"]
+
+    def need(self):
+        """Elements per flat output buffer (plus `info`: 2 B int32)."""
+        out = {name: int(np.prod(shape)) for name, (shape, _) in self.shapes.items()}
+        out["info"] = 2 * self.packed.B
+        return out
+
+    def run(self, out=None):
+        """Launch the solves and the feature kernel on the current stream; `out`: flat device buffers to write
+        into (`need()` elements each).  Returns the dict of device tensors."""
+        from . import _capi
+        torch, dev, packed = self.torch, self.dev, self.packed
+        self.solver.step(sections=self.sections)
+        actual = self.solver.outs[0]
+        prior = self.solver.outs[1] if self.fixed is not None else None
+        t = {}
+        for name, (shape, dt) in self.shapes.items():
+            t[name] = out[name][:int(np.prod(shape))].view(shape) if out is not None else \
+                torch.empty(shape, dtype=dt, device=dev)
+        inp = self.inputs
+        ptr = lambda x: None if x is None else x.data_ptr()
+        ua, na = (actual["u"], actual["N"]) if self.regression else (None, None)
+        up, npr = (prior["u"], prior["N"]) if prior is not None else (None, None)
+        if B := packed.B:
+            with torch.cuda.device(dev):
+                _capi.check(_capi.load().trs_graph_features_packed(
+                    B, packed.nJ_max, packed.nM_max, inp["xyz"].data_ptr(), inp["conn"].data_ptr(),
+                    inp["A"].data_ptr(), inp["rho"].data_ptr(), inp["cbits"].data_ptr(), inp["loads"].data_ptr(),
+                    inp["nJ"].data_ptr(), inp["nM"].data_ptr(), ptr(ua), ptr(na), ptr(up), ptr(npr),
+                    float(self.fixed.a if prior is not None else 1.0), *self.scales, int(self.regression),
+                    self.offs[0].data_ptr(), self.offs[1].data_ptr(), ptr(t["joint_x"]), ptr(t["member_x"]),
+                    ptr(t.get("joint_y")), ptr(t.get("member_y")), ptr(t["j2m_joint"]), t["weight"].data_ptr(),
+                    torch.cuda.current_stream(dev).cuda_stream), "trs_graph_features_packed")
+        info = torch.stack([actual["info"], prior["info"] if prior is not None else torch.zeros_like(actual["info"])])
+        if out is not None:
+            out["info"][:2 * packed.B].view(2, packed.B).copy_(info)
+            info = out["info"][:2 * packed.B].view(2, packed.B)
+        t["info"] = info
+        t.setdefault("joint_y", None)
+        t.setdefault("member_y", None)
+        return t
+
+
+def feature_tensors_packed(packed, fixedMemberType, taskType, forceScale=1., displaceScale=1., positionScale=1.,
+                           device=None, reorder=False, device_inputs=None, out=None):
+    """`feature_tensors_device` with the PACKED output of `trs_graph_features_packed`: the joint rows of all trusses
+    back to back (`joint_x` [sum nJ, FJ], `joint_y` [sum nJ, 3]), the member rows likewise (`member_x`, `member_y`),
+    `j2m_joint` [sum nM, 2] int32 (the members' end joints = row 0 of every sample's `j2m` edge index), `weight`
+    [B], `info` [2, B] - on the device, nothing padded: what a `HeteroData` of every sample slices and what the
+    dataset stream sends across PCIe.  `out`: a dict of flat device buffers to write into.  Returns (tensors,
+    joint offsets, member offsets) - the offsets as host int64 arrays [B + 1]."""
+    job = _PackedFeatureJob(packed, fixedMemberType, taskType, forceScale, displaceScale, positionScale, device,
+                            reorder, device_inputs)
+    return job.run(out), job.joint_off, job.member_off
+
+
+class PackedGraphs:
+    """The graphs of a chunk of samples over PACKED feature tensors (host or device): `len`, indexing, slicing,
+    iteration; a graph object (`HeteroData` when torch_geometric is importable, else `GraphStores`) is built when
+    it is asked for and holds SLICES of the chunk's tensors (`joint.x`, `member.x`, `y`) plus its edge indices
+    (reference data.py:238-282: `j2m` = [end joints of member 0, 0, 1, 1, ...; 0, 0, 1, 1, ...], `m2j` the rows
+    swapped; `j2j` / `m2m` with `MetapathType.USE_IMPLICIT`).  `first` = global index of the chunk's first sample."""
+
+    def __init__(self, first, nJ, nM, joint_off, member_off, tensors, metapathType=MetapathType.NO_IMPLICIT,
+                 sources=None):
+        self.first, self.nJ, self.nM = int(first), np.asarray(nJ), np.asarray(nM)
+        self.joint_off, self.member_off = joint_off, member_off
+        self.tensors, self.metapathType, self.sources = tensors, metapathType, sources
+
+    def __len__(self):
+        return len(self.nJ)
+
+    def __iter__(self):
+        return (self[b] for b in range(len(self)))
+
+    @property
+    def nbytes(self):
+        """Bytes of the chunk's tensors (what crossed PCIe for a host chunk)."""
+        return sum(int(v.numel() * v.element_size()) for v in self.tensors.values() if v is not None)
+
+    def __getitem__(self, b):
+        import torch
+        if isinstance(b, slice):
+            return [self[i] for i in range(*b.indices(len(self)))]
+        if b < 0:
+            b += len(self)
+        if not 0 <= b < len(self):
+            raise IndexError(b)
+        t = self.tensors
+        j0, j1 = int(self.joint_off[b]), int(self.joint_off[b + 1])
+        m0, m1 = int(self.member_off[b]), int(self.member_off[b + 1])
+        g = _new_graph()
+        g["src"] = None if self.sources is None else self.sources[b]
+        g["originWeight"] = float(t["weight"][b])
+        g["joint"].x = t["joint_x"][j0:j1]
+        g["member"].x = t["member_x"][m0:m1]
+        if t.get("joint_y") is not None:
+            g["joint"].y = t["joint_y"][j0:j1]
+            g["member"].y = t["member_y"][m0:m1]
+        ends = t["j2m_joint"][m0:m1]
+        members = torch.arange(m1 - m0, device=ends.device).repeat_interleave(2)
+        j2m = torch.stack([ends.reshape(-1).long(), members])
+        g["joint", "j2m", "member"].edge_index = j2m
+        g["member", "m2j", "joint"].edge_index = torch.flip(j2m, dims=[0])
+        if self.metapathType == MetapathType.USE_IMPLICIT:
+            jj, mm = _implicit_edges(ends.cpu().numpy().astype(np.int64), j1 - j0, m1 - m0)
+            g["joint", "j2j", "joint"].edge_index = torch.from_numpy(jj).to(ends.device)
+            g["member", "m2m", "member"].edge_index = torch.from_numpy(mm).to(ends.device)
+        return g
+
+
+class _PackedRing:
+    """`slots` pairs of grow-only flat buffers - device staging + page-locked host memory - for the packed feature
+    tensors of the dataset stream, and the events that order their reuse."""
+    KINDS = {"joint_x": "float32", "member_x": "float32", "joint_y": "float32", "member_y": "float32",
+             "j2m_joint": "int32", "weight": "float64", "info": "int32"}
+
+    def __init__(self, torch, device, slots):
+        self.torch, self.device = torch, device
+        self.dev = [dict() for _ in range(slots)]
+        self.host = [dict() for _ in range(slots)]
+        self.done = [None] * slots      # event: the slot's last D2H copies have finished
+
+    def reserve(self, slot, need):
+        """Buffers of slot `slot` with at least `need[name]` elements (12 % headroom when one has to grow)."""
+        t = self.torch
+        for name, count in need.items():
+            have = self.dev[slot].get(name)
+            if have is None or have.numel() < count:
+                if self.done[slot] is not None:
+                    self.done[slot].synchronize()    # nothing of the old buffers is in flight any more
+                cap = max(1, int(count) + int(count) // 8)
+                dt = getattr(t, self.KINDS[name])
+                self.dev[slot][name] = t.empty([cap], dtype=dt, device=self.device)
+                self.host[slot][name] = t.empty([cap], dtype=dt, pin_memory=True)
+        return self.dev[slot], self.host[slot]
+
+
+_RINGS = {}
+
+
+def release_stream_buffers():
+    """Drop the page-locked rings and staging buffers `dataset_stream` keeps per device."""
+    _RINGS.clear()
+
+
+def dataset_stream(n_samples, rank=0, world=1, chunk=32768, seed=0, numCubeRange=(8, 190), gridRange=(6, 6, 6),
+                   fixedMemberType=None, taskType=TaskType.OPTIMIZATION, metapathType=MetapathType.NO_IMPLICIT,
+                   forceScale=1., displaceScale=1., positionScale=1., device=None, reorder=True, slots=2,
+                   record=None, **generator_args):
+    """BASELINE config 5 END TO END: "cube-truss dataset generation ... results streamed to PyG HeteroData".  This
+    rank's share of a dataset of `n_samples` random cube trusses, chunk by chunk, DELIVERED ON THE HOST: generation,
+    joint order, both solves and the feature kernel on `device` as in `dataset_chunks`, the features written in
+    packed form (`trs_graph_features_packed`: no padding, 60-70 KB per sample of 8 .. 190 cubes instead of ~100 KB
+    of padded rows) into a device staging buffer and copied by DMA into page-locked host memory on a second
+    stream WHILE the device works on the next chunk.  Yields `PackedGraphs` whose tensors are views of the
+    page-locked ring: `graphs[i]` is sample `graphs.first + i` as a `HeteroData` (torch_geometric present) or
+    `GraphStores`.  A yielded chunk stays valid until the generator has been advanced `slots - 1` more times -
+    a consumer that keeps samples longer copies them (`torch.save`, a collate into its own batch, ...).
+    `record` (a list): (name, start event, end event) of every chunk's device work and copy are appended.
+    The dataset is defined by (seed, global sample index) exactly as in `dataset_chunks`."""
+    import torch
+    from .batch import _require_gpu
+    from .generate import generate_cube_batch_device
+    torch, dev = _require_gpu(device)
+    slots = max(2, int(slots))
+    n_chunks = (int(n_samples) + chunk - 1) // chunk
+    mine = list(range(rank, n_chunks, world))
+    # (the ring lives as long as the process: page-locking a few GB costs as much as solving a chunk)
+    ring = _RINGS.setdefault((str(dev), slots), _PackedRing(torch, dev, slots))
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev)
+    regression = taskType == TaskType.REGRESSION
+    span = lambda k: (k * chunk, min(chunk, int(n_samples) - k * chunk))
+
+    def plan(k):
+        # The generator's size pass + its ONE small device -> host readback.  Placed at the END of a chunk's device
+        # work and BEFORE that chunk's large copy is queued: device -> host copies share a DMA queue, and a small
+        # readback submitted behind a 2 GB copy waits for all of it - the stream then runs compute and copy one
+        # after the other (measured: 104 instead of 64 ms per chunk of 32 768).
+        first, count = span(k)
+        sizes = dataset_sizes(seed, first, count, numCubeRange)
+        return generate_cube_batch_device(sizes, gridRange=gridRange, seed=seed, first_index=first, device=dev,
+                                          pad_to=(8, 64), plan_only=True, **generator_args)
+
+    def prepare(k):
+        meta, fill = plan(k)
+        inputs = fill()
+        return meta, _PackedFeatureJob(meta, fixedMemberType, taskType, forceScale, displaceScale, positionScale, dev,
+                                       reorder, inputs)
+
+    def launch(i, meta, job):
+        """Chunk mine[i]: kernels only, into staging slot i % slots; returns what the copy and the hand-over need."""
+        slot = i % slots
+        need = job.need()
+        dbuf, hbuf = ring.reserve(slot, need)
+        if ring.done[slot] is not None:
+            main.wait_event(ring.done[slot])      # the slot's previous chunk has left the staging buffer
+        if record is not None:
+            c0 = torch.cuda.Event(enable_timing=True); c0.record(main)
+        job.run(dbuf)
+        packed_ev = torch.cuda.Event(enable_timing=record is not None)
+        packed_ev.record(main)
+        if record is not None:
+            record.append((f"chunk {mine[i]} device work", c0, packed_ev))
+        return slot, need, dbuf, hbuf, packed_ev, meta, job
+
+    def copy_out(i, slot, need, dbuf, hbuf, packed_ev, meta, job):
+        """Queue the chunk's device -> host copies on the side stream; returns (graphs, done event)."""
+        host = {}
+        with torch.cuda.stream(side):
+            side.wait_event(packed_ev)
+            if record is not None:
+                d0 = torch.cuda.Event(enable_timing=True); d0.record(side)
+            for name, cnt in need.items():
+                hbuf[name][:cnt].copy_(dbuf[name][:cnt], non_blocking=True)
+                host[name] = hbuf[name][:cnt]
+            ring.done[slot] = torch.cuda.Event(enable_timing=record is not None)
+            ring.done[slot].record(side)
+            if record is not None:
+                record.append((f"chunk {mine[i]} copy", d0, ring.done[slot]))
+        SJ, SM, count = int(job.joint_off[-1]), int(job.member_off[-1]), meta.B
+        host = {"joint_x": host["joint_x"].view(SJ, job.FJ), "member_x": host["member_x"].view(SM, job.FM),
+                "joint_y": host["joint_y"].view(SJ, 3) if regression else None,
+                "member_y": host["member_y"].view(SM, 1) if regression else None,
+                "j2m_joint": host["j2m_joint"].view(SM, 2), "weight": host["weight"],
+                "info": host["info"].view(2, count)}
+        first = span(mine[i])[0]
+        return PackedGraphs(first, meta.nJ, meta.nM, job.joint_off, job.member_off, host, metapathType), ring.done[slot]
+
+    # Order of one round (chunk k running on the device):
+    #   set up chunk k + 1 (size readback - waits for chunk k's kernels -, index lists, offsets: all the small copies)
+    #   -> queue chunk k's large copy -> launch chunk k + 1 (kernels only) -> hand over chunk k - 1
+    # so that no small copy is ever submitted while a large one is in flight, and the device always has the next
+    # chunk's kernels queued while the host is with the consumer.
+    if not mine:
+        return
+    running = launch(0, *prepare(mine[0]))
+    pending = None
+    for i in range(len(mine)):
+        nxt = prepare(mine[i + 1]) if i + 1 < len(mine) else None
+        copied = copy_out(i, *running)
+        if nxt is not None:
+            running = launch(i + 1, *nxt)
+        if pending is not None:
+            pending[1].synchronize()
+            yield pending[0]
+        pending = copied
+    pending[1].synchronize()
+    yield pending[0]
+
+
 class TrussHeteroDataCreator:
     """Reference-compatible front end (`data.py:11-44`)."""
 

@@ -170,7 +170,7 @@ def generate_cube_batch_device(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 
                                nForceRange=None, method=GenerateMethod.Random, linkType=LinkType.Random,
                                memberTypes=((1., 1e7, 0.1),), isAllowParallel=False, seed=0,
                                isAddPinSupport=True, first_index=0, device=None, return_retries=False,
-                               pad_to=(1, 1)):
+                               pad_to=(1, 1), plan_only=False):
     """`generate_cube_batch` ON THE GPU (`trs_cubegen_dev`, `csrc/cubegen.hip`): the same trusses, bit for bit, as
     the host generator gives for the same arguments (same per-truss streams keyed by (seed, first_index + b)),
     written straight into device tensors - nothing of the batch ever exists on the host.
@@ -180,7 +180,9 @@ def generate_cube_batch_device(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 
     the batch's own maxima.  Two passes like the host generator (sizes only, then the arrays); one
     synchronisation in between for the maxima.  `pad_to=(j, m)`: the padded widths are rounded up to multiples of
     j joints / m members (a stream of chunks then repeats a few tensor shapes instead of one per chunk, which
-    the caching allocator can reuse; the extra padding is inert)."""
+    the caching allocator can reuse; the extra padding is inert).  `plan_only=True` returns `(sizes, fill)` after
+    the size pass: `fill()` launches the second pass and returns the tensors - a pipeline can then place the
+    generator's one device-to-host readback where it does not queue behind a large copy (`data.dataset_stream`)."""
     import torch
     from . import _capi
     from .batch import BatchSizes, _require_gpu
@@ -211,20 +213,30 @@ def generate_cube_batch_device(num_cubes, gridRange=(5, 5, 5), lengthRange=(50, 
                 status.data_ptr(), int(first_index), torch.cuda.current_stream(dev).cuda_stream), "trs_cubegen_dev")
 
     run(nJ_b.value, nM_b.value, None)                      # pass 1: sizes only -> exact padding
-    h_nJ, h_nM, h_free, h_status = nJ.cpu().numpy(), nM.cpu().numpy(), n_free.cpu().numpy(), status.cpu().numpy()
+    # (ONE small device -> host copy: the four arrays side by side)
+    h_all = torch.cat([nJ, nM, n_free, status]).cpu().numpy()
+    h_nJ, h_nM, h_free, h_status = h_all[:B].copy(), h_all[B:2 * B].copy(), h_all[2 * B:3 * B].copy(), h_all[3 * B:]
     if B and h_status[1]:
         raise RuntimeError("trs_cubegen_dev: a truss does not fit the grid's bounds")
     retries = int(h_status[0])
     up_to = lambda v, q: (max(1, int(v)) + int(q) - 1) // int(q) * int(q)
     jm, mm = up_to(h_nJ.max(initial=1), pad_to[0]), up_to(h_nM.max(initial=1), pad_to[1])
-    f64 = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
-    tensors = {"xyz": f64(B, jm, 3), "loads": f64(B, jm, 3), "cbits": torch.empty([B, jm], dtype=torch.uint8, device=dev),
-               "conn": torch.empty([B, mm, 2], dtype=torch.int32, device=dev), "E": f64(B, mm), "A": f64(B, mm),
-               "rho": f64(B, mm), "nJ": nJ, "nM": nM}
-    status.zero_()
-    if B:
-        run(jm, mm, tensors)                               # pass 2: the batch itself (same streams)
     sizes = BatchSizes(h_nJ, h_nM, h_free, jm, mm)
+
+    def fill():
+        """Pass 2: the batch itself (same per-truss streams), asynchronous on the current stream."""
+        f64 = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+        tensors = {"xyz": f64(B, jm, 3), "loads": f64(B, jm, 3), "cbits": torch.empty([B, jm], dtype=torch.uint8, device=dev),
+                   "conn": torch.empty([B, mm, 2], dtype=torch.int32, device=dev), "E": f64(B, mm), "A": f64(B, mm),
+                   "rho": f64(B, mm), "nJ": nJ, "nM": nM}
+        status.zero_()
+        if B:
+            run(jm, mm, tensors)
+        return tensors
+
+    if plan_only:   # (sizes now - the one host synchronisation of the generator -, arrays when `fill()` is called)
+        return (sizes, fill, retries) if return_retries else (sizes, fill)
+    tensors = fill()
     return (sizes, tensors, retries) if return_retries else (sizes, tensors)
 
 

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_host_side_helpers_of_the_abi():
     lib = _capi.load()
-    assert lib.trs_abi_version() == _capi.ABI_VERSION == 8
+    assert lib.trs_abi_version() == _capi.ABI_VERSION == 9
     assert lib.trs_assemble_work_bytes(244, 942, 696) % 256 == 0
     assert lib.trs_slab_rows(696) == 704 and lib.trs_slab_ld(696) == 720
     assert lib.trs_slab_rows(64) == 64 and lib.trs_slab_rows(65) == 128 and lib.trs_slab_rows(0) == 64

@@ -136,7 +136,8 @@ def test_bench_eight_ranks_smoke():
     assert line["ranks"] == 8 and line["n_gpus"] == min(8, ndev)
     assert line["info_nonzero"] == 0 and line["value"] > 0
     assert line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"]
-    assert line["host_threads_per_rank"] == max(1, available_cpus() // 8)
+    # (its share of the CPUs at most; torchrun's OMP_NUM_THREADS=1 for multi-process jobs wins where it is set)
+    assert 1 <= line["host_threads_per_rank"] <= max(1, available_cpus() // 8)
     cube = line["cube_batch"]
     assert "error" not in cube and cube["info_nonzero"] == 0 and cube["batch_per_gpu"] == 256
     assert cube["value"] > 0 and cube["rank_ms_per_step"]["min"] <= cube["rank_ms_per_step"]["max"]
