@@ -553,8 +553,29 @@ def ga_leg(device, torch):
     for _ in range(reps):
         fit = ga.GetFitnessBatch(pop)
     dt = (time.perf_counter() - t0) / reps
+    # the WHOLE loop of config 4 (ga.GA.Evolve, reference ga.py:192-237): selection, offspring and the batched fitness
+    # of every generation, under one seed, by the native generation loop and by the reference-shaped Python loop
+    evolve = {}
+    gens = 30
+    for name, native in (("native_loop", True), ("python_loop", False)):
+        try:
+            state = random.getstate()
+            random.seed(1)
+            run = GA(truss, types, nIteration=gens, nPatience=10 ** 6, nPop=1024, nElite=256)
+            run._device, run._typeTable = ga._device, ga._typeTable    # (the resident population batch, built above)
+            t0 = time.perf_counter()
+            _, info, _, history = run.Evolve(isPrintMessage=False, native=native)
+            wall = time.perf_counter() - t0
+            random.setstate(state)
+            evolve[name] = {"ms_per_generation": wall / gens * 1e3, "generations": gens,
+                            "best_fitness": history[-1], "x_fitness_call": wall / gens / dt}
+        except Exception as exc:
+            evolve[name] = {"error": repr(exc)}
+    if all("best_fitness" in v for v in evolve.values()):
+        evolve["same_trajectory"] = evolve["native_loop"]["best_fitness"] == evolve["python_loop"]["best_fitness"]
     return {"nPop": 1024, "truss": "bar-120 (120 members, 111 free DOFs), 20 member types", "ms_per_generation_eval": dt * 1e3,
             "fitness_evals_per_s": 1024 / dt, "feasible_in_population": int(sum(1 for f in fit if f[1] and f[2])),
+            "evolve": evolve,
             "note": "wall time of GA.GetFitnessBatch (gene matrix -> sections on the device -> trs_solve_small with "
                     "the fitness reductions -> one download); informational"}
 

@@ -37,6 +37,17 @@ int trs_cubegen(int B, uint64_t seed, int gx, int gy, int gz, const int32_t *num
                 int64_t first_index /* global index of truss 0: the stream of truss b is keyed by
                                        (seed, first_index + b), so chunks / shards of one dataset agree */);
 
+/* One generation's offspring of the GA (reference ga.py:173-190 UpdatePop with Crossover ga.py:162-165, Mutate
+ * ga.py:167-171, GetRandomGene ga.py:136-137) on gene matrices of bytes, drawing from PYTHON's global Mersenne
+ * Twister exactly as the reference's calls to random.random / sample / choice / randint / choices would:
+ * state = random.getstate()[1] (624 words + position) in, the advanced state out (csrc/gaops.c).  elite
+ * [nElite][nMember] in rank order, pop / out [nPop][nMember]; toCross <= toMutate <= toKeep are the cumulative
+ * probabilities; counts [4] or NULL receives the offspring by crossover / mutation / kept / fresh.  Returns 0, -1
+ * for shapes the caller must handle in Python (fewer than two elites, members or types; more than 256 types). */
+int trs_ga_update_pop(uint32_t *state /* [625] */, int nPop, int nElite, int nMember, int nType, double toCross,
+                      double toMutate, double toKeep, const uint8_t *elite, const uint8_t *pop, uint8_t *out,
+                      int32_t *counts /* [4] or NULL */);
+
 /* Team size of the OpenMP loops of this library: n > 0 sets it, the return value is the size in effect.
  * The Python loader sets it once to the CPUs the process may actually use (affinity mask and cgroup quota;
  * `generate.available_cpus`) unless OMP_NUM_THREADS is set. */

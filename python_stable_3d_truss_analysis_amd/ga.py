@@ -142,7 +142,7 @@ class GA:
         dev = self._population_device(len(genes))
         count = len(genes)
         loci = torch.zeros([dev.B, dev.nM_max], dtype=torch.int64, device=dev.device)
-        loci[:count, :self.nMember] = torch.from_numpy(self._gene_matrix(genes)).to(dev.device)
+        loci[:count, :self.nMember] = torch.from_numpy(self._gene_matrix(genes)).to(dev.device)   # (uint8 -> int64 on the device)
         sections = self._typeTable[loci]                    # [B, nM, 3] = (a, e, density)
         dev.A.copy_(sections[..., 0]); dev.E.copy_(sections[..., 1]); dev.rho.copy_(sections[..., 2])
         # one kernel for solve + reductions on the fused small path; one download for everything
@@ -155,7 +155,10 @@ class GA:
     def _gene_matrix(self, genes):
         """The population (list of lists of type indices, the reference's representation) as an int64
         array [count, nMember].  `bytes()` of a gene is 8x faster than numpy's list-of-lists conversion,
-        which was three quarters of the wall time of a generation."""
+        which was three quarters of the wall time of a generation.  A uint8 matrix (the native generation loop's
+        own representation) passes through as it is."""
+        if isinstance(genes, np.ndarray):
+            return genes
         if self.nType <= 256:
             try:
                 flat = np.frombuffer(b"".join(map(bytes, genes)), dtype=np.uint8)
@@ -258,9 +261,118 @@ class GA:
             return self._feasibleGene, (self._feasibleFitness, True, True)
         return best, bestInfo
 
+    # ------------------------------------------------------------- native generation loop
+    #: the methods whose reference behaviour `_EvolveNative` reproduces; a subclass that overrides any of them
+    #: (the reference's documented extension point is GetFitness) gets the plain Python loop
+    _NATIVE_METHODS = ("GetFitness", "Select", "Crossover", "Mutate", "UpdatePop", "GetRandomGene",
+                       "GetBestFeasibleGene", "_RecordFeasible", "_evaluate", "_compose_many")
+
+    def _native_loop_ok(self):
+        """The whole generation loop can run on gene MATRICES with the native population update (`csrc/gaops.c`):
+        stock methods, at most 256 member types, CPython's Mersenne Twister behind `random`, the host library."""
+        if any(getattr(type(self), m) is not getattr(GA, m) for m in self._NATIVE_METHODS):
+            return False
+        if not (2 <= self.nType <= 256 and self.nElite >= 2 and self.nMember >= 2):
+            return False
+        if self._devices is not None and len(self._devices) > 1:
+            return False
+        state = random.getstate()
+        if not (state[0] == 3 and len(state[1]) == 625 and type(random._inst) is random.Random):
+            return False
+        try:
+            from .generate import _load
+            return hasattr(_load(), "trs_ga_update_pop")
+        except Exception:
+            return False
+
+    def _update_pop_native(self, pop, elite, out):
+        """`UpdatePop` on uint8 gene matrices (`trs_ga_update_pop`): the draws come out of Python's global generator
+        - state handed over and put back -, in the reference's order (ga.py:173-190)."""
+        import ctypes
+        from .generate import _load
+        version, words, gauss = random.getstate()
+        state = np.array(words, dtype=np.uint32)
+        toCross = self.pCrossover
+        toMutate = toCross + self.pMutate
+        toKeep = toMutate + self.pOrigin
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        lib = _load()
+        lib.trs_ga_update_pop.restype = ctypes.c_int
+        rc = lib.trs_ga_update_pop(ptr(state), ctypes.c_int(self.nPop), ctypes.c_int(self.nElite),
+                                   ctypes.c_int(self.nMember), ctypes.c_int(self.nType), ctypes.c_double(toCross),
+                                   ctypes.c_double(toMutate), ctypes.c_double(toKeep), ptr(elite), ptr(pop), ptr(out),
+                                   None)
+        if rc != 0:
+            raise RuntimeError(f"trs_ga_update_pop refused the population ({rc})")
+        random.setstate((version, tuple(state.tolist()), gauss))
+
+    def _EvolveNative(self, isPrintMessage):
+        """`Evolve` with the population as ONE uint8 matrix [nPop, nMember]: per generation one batched fitness
+        call on the GPU, a stable argsort (= the reference's stable `sorted`, ga.py:157), the feasible-record
+        update on arrays and the native `UpdatePop`.  Same `random` consumption as the Python loop, so the same
+        trajectory; returns the reference's list-of-lists population."""
+        pop = np.array(self.Initialize(), dtype=np.uint8)
+        nxt = np.empty_like(pop)
+        bestFitness, history, nWait, earlyStop = INF, [], 0, False
+        iteration = 0
+
+        stock_batch = type(self).GetFitnessBatch is GA.GetFitnessBatch
+
+        def evaluate(matrix):
+            # (a user's own batch evaluator gets the reference's list-of-lists population)
+            info = self.GetFitnessBatch(matrix if stock_batch else matrix.tolist())   # [(fitness, okStress, okDisplace)]
+            fit = np.fromiter((t[0] for t in info), dtype=np.float64, count=len(info))
+            ok = np.fromiter((t[1] and t[2] for t in info), dtype=bool, count=len(info))
+            return info, fit, ok
+
+        while self.nIteration is None or iteration < self.nIteration:
+            info, fit, ok = evaluate(pop)
+            order = np.argsort(fit, kind="stable")
+            feasible = np.flatnonzero(ok[order])
+            if feasible.size:                         # the best feasible gene of this generation (ranked order)
+                b = int(order[feasible[0]])
+                if self._feasibleFitness is None or info[b][0] < self._feasibleFitness:
+                    self._feasibleGene[:], self._feasibleFitness = pop[b].tolist(), info[b][0]
+            minFitness, okStress, okDisplace = info[int(order[0])]
+            if minFitness < bestFitness:
+                bestFitness, nWait = minFitness, 0
+            else:
+                nWait += 1
+                if nWait >= self.nPatience:
+                    earlyStop = True
+                    break
+            history.append(bestFitness)
+            if isPrintMessage:
+                print(f"\rIteration: {iteration :6d}, nWaitBestIter: {nWait :3d}, minFitness: {minFitness :12.4f}, "
+                      f"isInternalAllowed: {str(okStress) :5s}, isDisplaceAllowed: {str(okDisplace) :5s}", end='')
+            elite = np.ascontiguousarray(pop[order[:self.nElite]])
+            self._update_pop_native(pop, elite, nxt)
+            pop, nxt = nxt, pop
+            iteration += 1
+        if isPrintMessage:
+            print('...Early stoping !' if earlyStop else "")
+        popList = pop.tolist()
+        minGene, minGeneInfo = self.GetBestFeasibleGene(popList, earlyStop)
+        if minGene is None:
+            minGene = popList[0]
+            minGeneInfo = self._evaluate([minGene])[0]
+            if isPrintMessage:
+                print('-' * 50 + '\n' + "Warning: Cannot find any feasible result, so only return the gene "
+                      "which has lowest fitness." + '\n' + '-' * 50)
+        return minGene, minGeneInfo, popList, history
+
     # -------------------------------------------------------------------------------- driver
-    def Evolve(self, isPrintMessage=True):
-        """Run the GA (ga.py:192-237).  Returns (minGene, minGeneInfo, finalPop, bestFitnessHistory)."""
+    def Evolve(self, isPrintMessage=True, native=None):
+        """Run the GA (ga.py:192-237).  Returns (minGene, minGeneInfo, finalPop, bestFitnessHistory).
+        `native` (not in the reference): None = use the native generation loop (`_EvolveNative`: gene matrix +
+        `csrc/gaops.c`) whenever no method it replaces is overridden, False = the plain Python loop; both draw the
+        same numbers from `random` in the same order."""
+        if native is None:
+            native = self._native_loop_ok()
+        elif native and not self._native_loop_ok():
+            raise ValueError("the native generation loop needs the stock GA methods, <= 256 member types and the host library")
+        if native:
+            return self._EvolveNative(isPrintMessage)
         pop = self.Initialize()
         bestFitness, history, nWait, earlyStop = INF, [], 0, False
         iteration = 0

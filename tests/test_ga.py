@@ -41,7 +41,7 @@ class OracleGA(GA):
         return out
 
 
-def _check_against_trace(ga, trace):
+def _check_against_trace(ga, trace, native=None):
     state = random.getstate()
     pop0 = ga.Initialize()
     assert pop0 == trace["pop0"]
@@ -49,20 +49,52 @@ def _check_against_trace(ga, trace):
     for (fit, ok_s, ok_d), (rfit, rs, rd) in zip(gen0, trace["gen0"]):
         assert fit == pytest.approx(rfit, rel=1e-9) and (ok_s, ok_d) == (rs, rd)
     random.setstate(state)
-    minGene, minInfo, pop, history = ga.Evolve(isPrintMessage=False)
+    minGene, minInfo, pop, history = ga.Evolve(isPrintMessage=False, native=native)
     assert history == pytest.approx(trace["bestFitnessHistory"], rel=1e-9)
     assert minGene == trace["minGene"]
     assert minInfo[0] == pytest.approx(trace["minInfo"][0], rel=1e-9) and list(minInfo[1:]) == trace["minInfo"][1:]
     assert pop == trace["finalPop"]
 
 
-def test_ga_host_logic_reproduces_reference_trace_with_oracle_fitness():
+@pytest.mark.parametrize("native", [False, True], ids=["python-loop", "native-loop"])
+def test_ga_host_logic_reproduces_reference_trace_with_oracle_fitness(native):
+    """Both generation loops - the reference-shaped Python one and the native one on a gene matrix
+    (`GA._EvolveNative`, csrc/gaops.c) - walk the trajectory captured from the reference under the same seed."""
     trace = _trace()
     truss, types = _seeded_setup(trace)
     ga = OracleGA(truss, types, trace["allowStress"], trace["allowDisplace"], nIteration=trace["nIteration"],
                   nPatience=50, nPop=trace["nPop"], nElite=trace["nElite"])
-    _check_against_trace(ga, trace)
+    assert ga._native_loop_ok()
+    _check_against_trace(ga, trace, native)
     assert ga.TranslateGene(trace["minGene"])[0] == types[trace["minGene"][0]]
+
+
+@pytest.mark.parametrize("shape", [(40, 8, 25, 4), (64, 30, 7, 2), (300, 21, 3, 256), (33, 22, 120, 20), (16, 2, 2, 3)],
+                         ids=lambda s: "nPop%d-nElite%d-nMember%d-nType%d" % s)
+def test_native_update_pop_draws_what_the_python_operators_draw(shape):
+    """`trs_ga_update_pop` against `GA.UpdatePop` (the reference's operators, ga.py:162-190) from the same
+    generator state: the same next population AND the same state afterwards - elite counts on both sides of
+    `random.sample`'s pool / set threshold (21), two types (a one-bit `_randbelow`), 256 types."""
+    nPop, nElite, nMember, nType = shape
+    truss = Truss(3).LoadFromJSON(data=H.load_json("bar-120_input_0" if nMember == 120 else "bar-25_input_0"))
+    ga = GA(truss, [MemberType(1 + t, 1e7, .1) for t in range(nType)], nPop=nPop, nElite=nElite,
+            pCrossover=0.55, pMutate=0.2, pOrigin=0.15)
+    ga.nMember = nMember                       # (the operators only look at the gene length)
+    rng = np.random.default_rng(nPop)
+    for rnd in range(3):
+        pop = rng.integers(0, nType, size=(nPop, nMember)).astype(np.uint8)
+        elite = np.ascontiguousarray(pop[rng.permutation(nPop)[:nElite]])
+        random.seed(1000 + rnd)
+        for _ in range(rnd * 311):             # somewhere inside the generator's 624-word block, and across it
+            random.random()
+        start = random.getstate()
+        want = ga.UpdatePop(pop.tolist(), elite.tolist())
+        after_python = random.getstate()
+        random.setstate(start)
+        out = np.empty_like(pop)
+        ga._update_pop_native(pop, elite, out)
+        assert out.tolist() == want
+        assert random.getstate() == after_python
 
 
 def test_ga_parameter_checks():
