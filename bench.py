@@ -62,26 +62,32 @@ def load_case(name):
         return json.load(fh)
 
 
-def algorithmic_counts(n, nJ, nM, env_cend=None, narrow=False):
+def algorithmic_counts(n, nJ, nM, env_cend=None, narrow=False, env_kmask=None):
     """Per-truss algorithmic work (DESIGN.md section 'Kernels').  With an envelope only the tiles
-    t .. cend[t]-1 of the rows of chunk t are written / read (csrc/trs_common.h).  The load vector of
-    a matrix of the wave-per-matrix factorisation (`narrow`) travels in uf (8 bytes per row); the
-    work-group factorisation carries it as a 16-wide column chunk of the slab."""
+    t .. cend[t]-1 of the rows of chunk t are written / read (csrc/trs_common.h); of those only the tiles that hold
+    an entry of K_ff (`env_kmask`, wave-per-matrix kernels) are written by the assembly and read as stiffness
+    tiles - the factor fills all of them.  The load vector of a matrix of the wave-per-matrix factorisation
+    (`narrow`) travels in uf (8 bytes per row); the work-group factorisation carries it as a 16-wide column chunk
+    of the slab."""
     npad = (n + 63) // 64 * 64
     inputs = 8 * nM + 16 * nM + 24 * nJ + nJ + 24 * nJ
     # upper part by 16-row tiles incl. diagonal tiles (+ the load-column chunk in the slab when not narrow)
     row_end = (lambda c: npad) if env_cend is None else (lambda c: 16 * int(env_cend[c // 16]))
     col = 0 if narrow else 16
     upper = sum((row_end(c) + col - (c // 16) * 16) for c in range(npad)) * 8
+    k_upper = upper
+    if env_kmask is not None and env_cend is not None and narrow:
+        k_upper = 2048 * sum(bin((int(env_kmask[t]) & 0xffffffff) & ((1 << max(0, int(env_cend[t]) - t)) - 1)).count("1")
+                             for t in range(npad // 16))
     vec = 8 * npad if narrow else 0
     return {
         "potrf_flops": n ** 3 / 3.0 + 2 * n ** 2,       # SURVEY 8d: factor + two triangular solves
-        "assemble_bytes": inputs + upper + vec,         # K written once (upper part), f, + inputs
+        "assemble_bytes": inputs + k_upper + vec,       # K written once (tiles with entries), f, + inputs
         "assemble_bytes_full_contract": inputs + 8 * n * n + 8 * n,  # SURVEY section 8d figure
-        "potrf_bytes": 2 * upper + 2 * vec,             # stored part of K read once, U written once; f in, y out
+        "potrf_bytes": k_upper + upper + 2 * vec,       # K tiles with entries read once, U written once; f in, y out
         "potrs_bytes": upper + 2 * vec + (0 if narrow else 8 * n),  # stored part of U read once, y in, u out
         "recover_bytes": 8 * nM + 16 * nM + 24 * nJ + 8 * n + 24 * nJ + 24 * nJ + 8 * nM,
-        "slab_tile_bytes": upper,
+        "slab_tile_bytes": upper, "stiffness_tile_bytes": k_upper,
     }
 
 
@@ -277,7 +283,7 @@ def cube_cpu_baseline(B, seconds=12.0, pool_too=True):
     return rec, refs
 
 
-def envelope_counts_batch(n_free, nJ, nM, ft, last, cend, narrow):
+def envelope_counts_batch(n_free, nJ, nM, ft, last, cend, narrow, kmask=None):
     """Per-truss executed MFMA FLOP of the factorisation and algorithmic bytes of every stage for a bucket of
     NARROW-envelope matrices, from the envelope metadata trs_assemble left (arrays [Bb, ...]): the vectorised
     form of `potrf_tile_flops(narrow=True)` and `algorithmic_counts(narrow=True)` (asserted equal in
@@ -317,11 +323,19 @@ def envelope_counts_batch(n_free, nJ, nM, ft, last, cend, narrow):
     t = np.arange(width)[None, :]
     tiles = ((cend - t) * (t < nch[:, None])).sum(axis=1)
     upper = tiles * 2048
+    k_upper = upper
+    if kmask is not None:   # stiffness tiles with an entry of K_ff: the ones the assembly writes and the factorisation reads
+        km = np.asarray(kmask, dtype=np.int64) & 0xffffffff
+        live = km & ((np.int64(1) << np.clip(cend - t, 0, 32)) - 1)
+        bits = np.zeros_like(live)
+        for b in range(32):
+            bits += (live >> b) & 1
+        k_upper = (bits * (t < nch[:, None])).sum(axis=1) * 2048
     vec = 8 * npad
     inputs = 24 * np.asarray(nM, dtype=np.int64) + 49 * np.asarray(nJ, dtype=np.int64)
-    return {"potrf_tile_flops": 2048.0 * mfma, "tiles": tiles,
-            "assemble_bytes": inputs + upper + vec,
-            "potrf_bytes": 3 * upper + 4 * vec,            # factor + substitution by the same wave
+    return {"potrf_tile_flops": 2048.0 * mfma, "tiles": tiles, "stiffness_tiles": k_upper // 2048,
+            "assemble_bytes": inputs + k_upper + vec,
+            "potrf_bytes": k_upper + 2 * upper + 4 * vec,  # factor + substitution by the same wave
             "recover_bytes": 24 * np.asarray(nM) + 24 * np.asarray(nJ) + 8 * n_free + 48 * np.asarray(nJ) + 8 * np.asarray(nM),
             "order_bytes": 2 * (49 * np.asarray(nJ, dtype=np.int64) + 8 * np.asarray(nM, dtype=np.int64)) + 4 * np.asarray(nJ)}
 
@@ -412,7 +426,7 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
             host_fed = {"error": repr(exc)}
     # executed matrix-core work and algorithmic bytes of this rank's batch, from the envelope metadata of every
     # bucket (the buckets share one workspace: re-assemble bucket by bucket to read it)
-    flops = bytes_alg = tiles = 0.0
+    flops = bytes_alg = tiles = ktiles = 0.0
     n_wide = 0
     per_stage = {"order": 0.0, "assemble": 0.0, "potrf": 0.0, "recover": 0.0}
     for bk in solver.buckets:
@@ -433,7 +447,9 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
         narrow = (env[:, nchm + npan] & 0xff) == 1
         n_wide += int((~narrow).sum())
         c = envelope_counts_batch(nf, nJ, nM, env[:, :nchm], env[:, nchm:nchm + npan],
-                                  env[:, nchm + npan + 8: nchm + npan + 8 + nchm], narrow)
+                                  env[:, nchm + npan + 8: nchm + npan + 8 + nchm], narrow,
+                                  kmask=env[:, 2 * nchm + npan + 8: 3 * nchm + npan + 8])
+        ktiles += float(c["stiffness_tiles"].sum())
         flops += float(c["potrf_tile_flops"][narrow].sum())
         tiles += float(c["tiles"].sum())
         for k in ("assemble", "potrf", "recover"):
@@ -459,11 +475,13 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
                                                 "per step and GPU, over the WHOLE step time"},
                          "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                  "byte_model": "order (inputs read, renumbered inputs + permutation written) + assembly "
-                                               "(inputs, stored tiles, load vector) + factorisation with fused "
-                                               "substitution (3 x tiles, vectors) + recovery, over the WHOLE step time; "
+                                               "(inputs, the stored tiles that hold an entry of K_ff, load vector) + "
+                                               "factorisation with fused substitution (those tiles read, every stored tile "
+                                               "written as factor and read back, vectors) + recovery, over the WHOLE step time; "
                                                "the bucket gather / scatter copies are overhead, not counted",
                                  "bytes_per_step": bytes_alg, "by_stage": per_stage},
-                         "stored_tiles_per_truss": tiles / max(1, packed.B)},
+                         "stored_tiles_per_truss": tiles / max(1, packed.B),
+                         "stiffness_tiles_per_truss": ktiles / max(1, packed.B)},
             "device_generate_s": t_gen, "host_fed": host_fed,
             "cpu_baseline": cpu[0] if cpu is not None else None,
             "max_rel_err_vs_oracle": check,
@@ -753,6 +771,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.warmup > 0:
+        dev.adopt_tile_hint()   # (bar-942: too few envelope tiles without an entry of K_ff - the masks are not formed again)
     # Events are recorded on torch's current stream, which is the stream the C ABI launches on.  The TIMED
     # steps carry two events each, around the factorisation (roofline.avg_launch_ms); an event pair around
     # every stage costs 2.5 % of the step (tools/event_overhead.py), so the per-stage breakdown comes from an
@@ -797,6 +817,7 @@ def main():
         plain = batch.DeviceBatch(packed, device, use_envelope=True)
         for _ in range(args.warmup):
             plain.solve()
+        plain.adopt_tile_hint()
         torch.cuda.synchronize(device)
         t0g = time.perf_counter()
         for _ in range(args.steps):
@@ -822,6 +843,7 @@ def main():
             inner.solve()
         for _ in range(args.warmup):
             ordered_step()
+        inner.adopt_tile_hint()
         torch.cuda.synchronize(device)
         t0o = time.perf_counter()
         for _ in range(args.steps):
@@ -897,8 +919,9 @@ def main():
             potrf_kernel = ("trs_potrf_narrow_kernel<true, 2>" if compact else f"trs_potrf_narrow_kernel<false, {rs}>") \
                 if narrow else "trs_potrf_kernel"
             env_cend = env[nchm + dev.rows // 64 + 8: nchm + dev.rows // 64 + 8 + nchm]
+            env_kmask = env[2 * nchm + dev.rows // 64 + 8: 3 * nchm + dev.rows // 64 + 8]
             tile_flops = potrf_tile_flops(n, env_ft, env_last, env_cend, narrow)
-            counts = algorithmic_counts(n, nJ, nM, env_cend, narrow)
+            counts = algorithmic_counts(n, nJ, nM, env_cend, narrow, env_kmask)
             if compact:  # the factorisation reads the entry lists instead of the stiffness tiles
                 meta = env[nchm + dev.rows // 64: nchm + dev.rows // 64 + 8]
                 work = dev.work.view(-1)
@@ -945,8 +968,8 @@ def main():
                     "hbm": {"achieved": potrf_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac},
                     "flop_model": "MFMA work inside the 16x16-tile envelope of K_ff (what the kernel "
                                   "executes; equals the dense tile count with --dense)",
-                    "byte_model": "stiffness tiles inside the envelope (or their compact entry lists) read once, "
-                                  "factor tiles written once, load vector in / out (uf)" +
+                    "byte_model": "stiffness tiles inside the envelope that hold an entry of K_ff (or their compact "
+                                  "entry lists) read once, factor tiles written once, load vector in / out (uf)" +
                                   ("; the same wave then substitutes: factor tiles read once more, y in, u out "
                                    "(the trs_potrs launch finds nothing left to do)" if substituted else ""),
                     "fused_substitution": substituted,

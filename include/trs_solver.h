@@ -67,6 +67,10 @@ extern "C" {
                                     TRS_ASM_FULL_SYMMETRIC, without uf, or for an envelope forced narrow by
                                     TRS_ASM_ALL_NARROW that reaches further than the lists are sized for */
 #define TRS_ASM_ALL_NARROW 4     /* every matrix is routed to the wave-per-matrix kernels, whatever its envelope */
+#define TRS_ASM_ALL_TILES 8      /* write EVERY tile of the envelope, also those that hold no entry of K_ff (by default the
+                                    matrices of the wave-per-matrix kernels leave such tiles unwritten and mark them in
+                                    the envelope metadata, csrc/trs_common.h `kmask`: the factorisation takes them as zeros
+                                    without reading them; about 30 % of the stored tiles of a cube truss) */
 
 /* hints of trs_potrf_batched / trs_potrs_batched / trs_solve: what the caller knows about the batch, so that
  * kernels that would find no matrix of theirs are not launched at all (each such launch costs 4-9 us).
@@ -82,6 +86,9 @@ extern "C" {
 #define TRS_HINT_SEPARATE_STAGES 8   /* trs_potrf_batched / trs_solve: the factorising wave does NOT go on to the
                                         back substitution; trs_potrs_batched substitutes every matrix */
 #define TRS_HINT_NO_SMALL 16         /* trs_solve: never the fused small-system kernel, always the staged pipeline */
+#define TRS_HINT_ALL_TILES 64         /* trs_solve: assemble with TRS_ASM_ALL_TILES (the caller has seen - in the envelope
+                                        metadata of an earlier solve of the same topology - that no matrix of the
+                                        batch skips tiles: the mask need not be formed again) */
 #define TRS_HINT_RECOVER_UNSTAGED 32 /* trs_recover / trs_solve: the path for trusses whose tables exceed a CU's LDS
                                         (u, f_ext in the output arrays, reactions by FP64 atomics), whatever the size */
 
@@ -329,7 +336,8 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound,
               void *work, int32_t *env /* workspace for the envelope metadata, or NULL = dense */,
               const int32_t *joint_out /* [B][nJ_max] or NULL */,
               int hints /* TRS_HINT_NO_WIDE: route and treat every matrix as narrow; TRS_HINT_COMPACT,
-                           TRS_HINT_SEPARATE_STAGES, TRS_HINT_NO_SMALL, TRS_HINT_RECOVER_UNSTAGED as above */,
+                           TRS_HINT_SEPARATE_STAGES, TRS_HINT_NO_SMALL, TRS_HINT_RECOVER_UNSTAGED, TRS_HINT_ALL_TILES
+                           as above */,
               void *stream);
 
 #ifdef __cplusplus

@@ -441,6 +441,11 @@ class DeviceBatch:
         #: (TRS_ASM_ALL_NARROW) and the work-group kernels, which would find nothing, are not launched.  Safe
         #: either way - with the flag the device routes so regardless - it only must not outlive the topology.
         self.all_narrow = False
+        #: the host has SEEN (`adopt_tile_hint`) that no matrix of this resident batch leaves tiles of its envelope
+        #: unwritten (trs_common.h `kmask`: a tower-like truss has too few tiles without an entry of K_ff for the
+        #: skipping to pay): the assembly is then told not to form the masks again (TRS_ASM_ALL_TILES).  Like
+        #: `all_narrow` it must not outlive the topology (`upload` resets it); a wrong value costs time, never a result.
+        self.all_tiles = False
         self._potrf_fused = False
         self.options = default_options()
 
@@ -494,6 +499,8 @@ class DeviceBatch:
             flags |= ASM_ALL_NARROW
         if self.options["compact"] and self.env is not None:
             flags |= ASM_COMPACT
+        if self.all_tiles and self.env is not None:
+            flags |= ASM_ALL_TILES
         _capi.check(self.lib.trs_assemble(
             self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
             self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
@@ -567,7 +574,8 @@ class DeviceBatch:
                 self.info.data_ptr(), self.work.data_ptr(), self._env_ptr(),
                 self.joint_out.data_ptr() if self.joint_out is not None else None,
                 # (not on the fused small path here, by shape or by request: the staged pipeline in any case)
-                (HINT_NO_WIDE if self.all_narrow and self.env is not None else 0) | self._stage_hints() | HINT_NO_SMALL,
+                (HINT_NO_WIDE if self.all_narrow and self.env is not None else 0) | self._stage_hints() | HINT_NO_SMALL |
+                (HINT_ALL_TILES if self.all_tiles and self.env is not None else 0),
                 self._stream()), "trs_solve")
 
     def fitness(self, allow_stress, allow_displace):
@@ -581,6 +589,16 @@ class DeviceBatch:
             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), self._stream()), "trs_fitness")
         return out
 
+    def adopt_tile_hint(self):
+        """After a solve (or an assembly) of the resident batch: read back whether ANY matrix left tiles of its
+        envelope unwritten (one int per truss of the envelope metadata) and, if none did, tell the later assemblies
+        of this topology not to form the tile masks again (`all_tiles`).  Synchronises.  Returns `all_tiles`."""
+        if self.small or self.env is None or self.B == 0:
+            return False
+        off = 2 * (self.rows // 16) + self.rows // 64 + 8       # kmask[0] of every truss (csrc/trs_common.h)
+        self.all_tiles = bool((self.env[:, off] == -1).all().item())
+        return self.all_tiles
+
     def pinned_inputs(self, packed: PackedBatch):
         """Page-locked host copies of a batch's inputs (same padded shapes as this device batch)."""
         t = self.torch
@@ -590,6 +608,7 @@ class DeviceBatch:
         """Replace the resident inputs by another batch of the same padded shapes (asynchronous on
         the current stream when `host_inputs` come from `pinned_inputs`)."""
         self.all_narrow = False   # another topology: the host's knowledge of the envelopes is gone
+        self.all_tiles = False
         for f in self.INPUT_FIELDS:
             getattr(self, f).copy_(host_inputs[f], non_blocking=True)
 
@@ -781,7 +800,8 @@ def profile_permutation(packed: PackedBatch, return_choice=False, effort=2):
 NARROW_MAX_BELOW = 24   # csrc/trs_common.h TRS_NARROW_MAX_BELOW: reach up to which a matrix goes to a wave of its own
 # include/trs_solver.h
 HINT_NO_WIDE, HINT_SUBSTITUTED, HINT_COMPACT, HINT_SEPARATE_STAGES, HINT_NO_SMALL, HINT_RECOVER_UNSTAGED = 1, 2, 4, 8, 16, 32
-ASM_FULL_SYMMETRIC, ASM_COMPACT, ASM_ALL_NARROW = 1, 2, 4
+HINT_ALL_TILES = 64
+ASM_FULL_SYMMETRIC, ASM_COMPACT, ASM_ALL_NARROW, ASM_ALL_TILES = 1, 2, 4, 8
 
 
 def envelope_reach(packed: PackedBatch, perm=None):

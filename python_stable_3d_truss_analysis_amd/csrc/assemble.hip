@@ -55,7 +55,7 @@ __host__ __device__ inline AsmLds asm_lds_layout(int nJ_max, int nM_max, int n_p
     l.rhs = l.diag + (size_t)nJ_max * 48;                        // double[n_pad_max]
     l.tile = l.rhs + (size_t)n_pad_max * 8;                      // double[TR][WT + 16]
     l.ints = l.tile + (size_t)TR * (WT + 16) * 8;
-    const size_t nints = (size_t)6 * nJ_max + 1 + 2 * (size_t)nM_max + 2 * (n_pad_max / 16) + n_pad_max + 4;
+    const size_t nints = (size_t)6 * nJ_max + 1 + 2 * (size_t)nM_max + 3 * (n_pad_max / 16) + n_pad_max + 4;
     l.total = (l.ints + nints * 4 + 15) / 16 * 16;
     return l;
 }
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     int* cendl = chunkmin + n_pad_max / 16;                          // [n_pad_max/16] envelope: stored extent
     int* rowdof = cendl + n_pad_max / 16;                            // [n_pad_max] DOF of a reduced row
     int* wgflag = rowdof + n_pad_max;                                // [4] [0]: this matrix leaves as entry lists
+    unsigned* kmask = reinterpret_cast<unsigned*>(wgflag + 4);       // [n_pad_max/16] tiles of a chunk's rows that hold entries of K
 
     // ---- phase 0 ---------------------------------------------------------------------------------------
     // The end joints of a thread's first MR members stay in registers: three passes over the members need
@@ -156,7 +157,10 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         }
     }
     for (int j = tid; j < nJ; j += NT) cnt[j] = 0;
-    for (int q = tid; q < nch; q += NT) chunkmin[q] = q;  // padding rows: diagonal only
+    for (int q = tid; q < nch; q += NT) {
+        chunkmin[q] = q;  // padding rows: diagonal only
+        kmask[q] = 1u;    // the diagonal tile always holds entries (a row's own diagonal, the identity padding)
+    }
     // The adjacency lists are sorted by RANK when the unsorted lists fit the row tile (still unused here):
     // every member counts the keys of its end joints' lists that are smaller than its own - independent LDS
     // reads instead of the dependent chain of a per-joint insertion sort, which cost 0.046 of the stage's
@@ -200,10 +204,49 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     }
     for (int j = tid; j < nJ; j += NT) fill[j] = 0;
     __syncthreads();
+    // (the caller may know that skipping does not pay for this batch - TRS_ASM_ALL_TILES -: no mask is formed then)
+    const bool want_mask = env_all != nullptr && (flags & (TRS_ASM_ALL_TILES | TRS_ASM_FULL_SYMMETRIC)) == 0;
+    // kmask (trs_common.h): which tiles of a chunk's rows hold an entry of K - edge-parallel.  A joint's free rows
+    // are consecutive and lie in at most two chunks, its columns in at most two tiles: a member couples the rows of
+    // either end with the columns of the other, (2 x 2 tiles) x 2 directions, upper part only; a joint's own block
+    // adds the tile right of the diagonal tile when its rows straddle two chunks.
+    auto span_of = [&](int j, int& lo, int& hi) {
+        const int f0 = fi[3 * j], f1 = fi[3 * j + 1], f2 = fi[3 * j + 2];
+        hi = max(f0, max(f1, f2));
+        lo = min(f0 >= 0 ? f0 : 0x7fffffff, min(f1 >= 0 ? f1 : 0x7fffffff, f2 >= 0 ? f2 : 0x7fffffff));
+    };
+    auto couple = [&](int rlo, int rhi, int qlo, int qhi) {  // rows rlo .. rhi x columns qlo .. qhi, upper part
+        const int r0c = rlo >> 4, r1c = rhi >> 4, q0t = qlo >> 4, q1t = qhi >> 4;
+        unsigned m0 = 0u, m1 = 0u;
+        if (q0t >= r0c && q0t - r0c < 32) m0 |= 1u << (q0t - r0c);
+        if (q1t >= r0c && q1t - r0c < 32) m0 |= 1u << (q1t - r0c);
+        if (q0t >= r1c && q0t - r1c < 32) m1 |= 1u << (q0t - r1c);
+        if (q1t >= r1c && q1t - r1c < 32) m1 |= 1u << (q1t - r1c);
+        // (most members find their bits set already: a plain read first, the atomic only for new bits)
+        if ((kmask[r0c] & m0) != m0) atomicOr(&kmask[r0c], m0);
+        if (r1c != r0c && (kmask[r1c] & m1) != m1) atomicOr(&kmask[r1c], m1);
+    };
     for_members([&](int m, int j0, int j1) {
         unsorted[start[j0] + atomicAdd(&fill[j0], 1)] = ((unsigned)j1 << 16) | (unsigned)m;
         unsorted[start[j1] + atomicAdd(&fill[j1], 1)] = ((unsigned)j0 << 16) | (unsigned)m;
+#ifndef TRS_NO_KMASK   // (A/B build without it: every tile of the envelope is written and read, as before ABI 9)
+        if (want_mask) {
+            int alo, ahi, blo, bhi;
+            span_of(j0, alo, ahi);
+            span_of(j1, blo, bhi);
+            if (ahi >= 0 && bhi >= 0) {
+                couple(alo, ahi, blo, bhi);
+                couple(blo, bhi, alo, ahi);
+            }
+        }
+#endif
     });
+    if (want_mask)
+        for (int j = tid; j < nJ; j += NT) {  // a joint's own block
+            int lo, hi;
+            span_of(j, lo, hi);
+            if (hi >= 0 && (hi >> 4) != (lo >> 4)) atomicOr(&kmask[lo >> 4], 2u);
+        }
     __syncthreads();
     if (rank_sort) {
         for_members([&](int m, int j0, int j1) {
@@ -325,12 +368,38 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 wgflag[0] = compact ? 1 : 0;
                 // wave-per-matrix kernels read the load vector from uf: no load column in the slab
                 wgflag[1] = (narrow && uf_all != nullptr) ? 1 : 0;
+                // ... and skip the tiles of the envelope that hold no entry of K (kmask, trs_common.h); a matrix only
+                // FORCED narrow may reach further than the 32 bits of a mask word: it keeps every tile
+#ifdef TRS_NO_KMASK
+                wgflag[2] = 0;
+#else
+                wgflag[2] = (narrow && uf_all != nullptr && widest <= TRS_NARROW_MAX_BELOW && !full && (flags & TRS_ASM_ALL_TILES) == 0) ? 1 : 0;
+#endif
             }
+            int empty = 0, stored_tiles = 0;
             for (int t = tid; t < nch; t += 64) {  // t | 3 lies in the same step: reads precede the writes
                 const int e = narrow ? max(cendl[t] + 1, (t | 3) + 1) : cendl[t | 3] + 1 + (TRS_WIDE_ITEM - 1);
                 __builtin_amdgcn_wave_barrier();
                 cendl[t] = min(nch, e);
                 cend[t] = min(nch, e);
+                const int w = min(nch, e) - t;
+                stored_tiles += w;
+                empty += w - __popc(kmask[t] & (w >= 32 ? 0xffffffffu : ((1u << w) - 1u)));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                empty += __shfl_xor(empty, off);
+                stored_tiles += __shfl_xor(stored_tiles, off);
+            }
+            // skipping pays only when enough tiles are skipped (the row loop tests a bit per 16 bytes stored):
+            // a tower-like truss (bar-942: 6 of 158 tiles without an entry) keeps every tile
+            const bool worth = 8 * empty >= stored_tiles;
+            if (tid == 0 && !worth) wgflag[2] = 0;
+            {
+                int* km = env + trs_env_kmask_offset(n_pad_max);
+                __builtin_amdgcn_wave_barrier();
+                const bool masked = wgflag[2] != 0;
+                for (int t = tid; t < nch; t += 64) km[t] = masked ? (int)kmask[t] : -1;
             }
         }
         __syncthreads();
@@ -478,6 +547,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
 #endif
     // ---- phase 1 ---------------------------------------------------------------------------------------
     const bool with_col = !(has_env && wgflag[1] != 0);  // the 16-wide load-column chunk rides in the slab
+    const bool masked = has_env && wgflag[2] != 0;       // tiles without an entry of K are not written
     // A matrix whose load vector has gone to uf needs neither the staged vector nor the tile's 16 columns for
     // it any more: the row tile then takes over both (the vector lies right in front of it in LDS) and is wide
     // enough - WTn columns - for a whole row of a narrow envelope, which otherwise goes out in two segments.
@@ -552,6 +622,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         const int chunk = __builtin_amdgcn_readfirstlane(c0 + rr) >> 4;  // of this wave's rows
         const int i_lo = full ? 0 : 16 * chunk;
         const int i_hi = (has_env && !full) ? 16 * cendl[chunk] : npad;
+        const unsigned kmw = masked ? kmask[chunk] : 0xffffffffu;  // (wave-uniform: a wave's rows lie in one chunk)
         for (int seg_lo = i_lo; seg_lo < i_hi; seg_lo += WTe) {
             const int seg_hi = min(i_hi, seg_lo + WTe);
             const int Ws = seg_hi - seg_lo;  // multiple of 16
@@ -589,6 +660,9 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 double* src = Tt + (size_t)rr * Wstride;
                 for (int x = e_first * 2; x < W; x += 2 * TPR) {
                     const int col = x < Ws ? seg_lo + x : npad + (x - Ws);  // envelope part | load column
+                    // a tile without an entry of K: nothing was scattered into it, nothing is stored (masked rows
+                    // carry no load column, so col is an envelope column here)
+                    if (masked && ((kmw >> (((unsigned)col >> 4) - (unsigned)chunk)) & 1u) == 0u) continue;
                     *reinterpret_cast<d2*>(dst + col) = *reinterpret_cast<const d2*>(src + x);
                     *reinterpret_cast<d2*>(src + x) = d2{0.0, 0.0};
                 }

@@ -189,7 +189,8 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
     const int compact = env != nullptr && (hints & TRS_HINT_COMPACT) != 0;
     const int fused = (hints & TRS_HINT_SEPARATE_STAGES) == 0;
     rc = trs_assemble(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM, ld, slab_rows, S,
-                      (no_wide ? TRS_ASM_ALL_NARROW : 0) | (compact ? TRS_ASM_COMPACT : 0), work, env, uf, ld_uf,
+                      (no_wide ? TRS_ASM_ALL_NARROW : 0) | (compact ? TRS_ASM_COMPACT : 0) |
+                          ((hints & TRS_HINT_ALL_TILES) ? TRS_ASM_ALL_TILES : 0), work, env, uf, ld_uf,
                       stream);
     if (rc) return rc;
     rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, env, work, uf, ld_uf,

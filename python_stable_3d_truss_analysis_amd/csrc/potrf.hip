@@ -601,7 +601,7 @@ template <int NV, bool FUSED>
 __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const int c0, const int kstart,
                                             const int* __restrict__ ft, const int* __restrict__ cend,
                                             const double* Wl, const d4 (&t)[CT][CT], const KLists& K,
-                                            const int (&tb)[CT]) {
+                                            const int (&tb)[CT], const int* __restrict__ kmask) {
     const int rowbase = 16 * c0, lane = threadIdx.x & 63;
     d4 acc[NV][CT];
     // cend is non-decreasing: chunk c0+v is stored in the panel's tiles smin[v] .. 3 (one scalar
@@ -642,11 +642,15 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
         }
     } else {
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
+        for (int s = 0; s < CT; ++s) {
+            // stiffness tiles that hold no entry of K_ff were not written by trs_assemble (kmask, trs_common.h):
+            // they are zeros, taken through the out-of-range lane offset like the tiles outside the envelope
+            // (a mask word covers 32 tiles; only a matrix FORCED narrow reaches further, and its tiles are all written)
+            const unsigned km = (unsigned)kmask[r0 / 16 + s], d0 = (unsigned)(c0 - (r0 / 16 + s));
 #pragma unroll
-            for (int s = 0; s < CT; ++s) {
+            for (int v = 0; v < NV; ++v) {
                 const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
-                const unsigned vo = S.lane_off(s >= smin[v]);
+                const unsigned vo = S.lane_off(s >= smin[v] && (d0 + v >= 32u || ((km >> (d0 + v)) & 1u) != 0u));
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #ifdef TRS_EXP_NO_KLOADS
@@ -655,6 +659,7 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
                     acc[v][s][r] = S.load_at(vo, o + r * (S.ld * 32));
 #endif
             }
+        }
     }
 #ifdef TRS_EXP_NO_ITEMUPDATE  // timing experiment only (wrong results): no update loop in the items
     if (false) {
@@ -816,14 +821,22 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
     double yr[CT];
     auto load_block = [&](int r0) {
 #pragma unroll
-        for (int u = 0; u < CT; ++u)
+        for (int s = 0; s < CT; ++s) {
+            // (behind the last panel, r0 = npad, any word will do: the tiles requested there lie outside the slab's
+            // descriptor and nobody reads them - the index is only kept inside the array)
+            const unsigned km = (unsigned)env.kmask[min(r0 / 16 + s, npad / 16 - 1)];
 #pragma unroll
-            for (int s = 0; s <= u; ++s)
+            for (int u = s; u < CT; ++u) {
 #ifdef TRS_EXP_NO_KLOADS   // timing experiment only (wrong results): the stiffness tile loads
                 for (int r = 0; r < 4; ++r) t[u][s][r] = (u == s && (lane >> 4) + 4 * r == (lane & 15)) ? 1e6 : 0.0;
 #else
-                tile_load(t[u][s], S, r0 + 16 * s, r0 + 16 * u);
+                const int o = S.at(r0 + 16 * s, r0 + 16 * u);
+                const unsigned vo = S.lane_off(((km >> (u - s)) & 1u) != 0u);   // no entry of K_ff in the tile: zeros
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[u][s][r] = S.load_at(vo, o + r * (S.ld * 32));
 #endif
+            }
+        }
 #pragma unroll
         for (int s = 0; s < CT; ++s) yr[s] = YR.load((r0 + 16 * s) * 8);
     };
@@ -1003,13 +1016,13 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
             const int ks = 16 * env.ft[c0];
             const int left = lastq - c0 + 1;
             if (RSV >= 4 && left >= 4) {
-                narrow_item<(RSV >= 4 ? 4 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
+                narrow_item<(RSV >= 4 ? 4 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb, env.kmask);
                 c0 += 4;
             } else if (RSV >= 2 && left >= 2) {
-                narrow_item<(RSV >= 2 ? 2 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
+                narrow_item<(RSV >= 2 ? 2 : 1), FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb, env.kmask);
                 c0 += 2;
             } else {
-                narrow_item<1, FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb);
+                narrow_item<1, FUSED>(S, r0, c0, ks, env.ft, env.cend, Wl, t, K, tb, env.kmask);
                 c0 += 1;
             }
         }

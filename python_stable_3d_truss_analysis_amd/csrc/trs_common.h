@@ -45,6 +45,12 @@ __device__ static inline double readlane_f64(double v) {
 //                         lastc[t] = last chunk q with ft[q] <= t - the exact envelope at tile
 //                         granularity (tiles outside are skipped with out-of-range buffer offsets);
 //                       work-group kernel:      cend[t] = last[t / 4] + 1 + slack (rectangular per panel).
+//   kmask[t] t < nch: (wave-per-matrix kernels only) bit d set <=> the STIFFNESS matrix has an entry in tile
+//                     (slab rows 16 t .. 16 t + 15, columns of chunk t + d), d < 32.  About 30 % of the tiles inside
+//                     the envelope of a cube truss hold no entry of K_ff (they fill in during the factorisation):
+//                     trs_assemble does not write them and the factorisation does not read them (it takes zeros
+//                     through the out-of-range lane offset); the factor is written to every tile of the envelope
+//                     as before.  All ones for a matrix of the work-group kernel (every stored tile is written).
 // Cholesky fill stays inside the row envelope, so tiles outside it are exact zeros.
 #ifndef TRS_NARROW_MAX_BELOW
 #define TRS_NARROW_MAX_BELOW 24  // widest reach below a diagonal block (chunks) for the narrow kernel;
@@ -59,14 +65,16 @@ struct TrsEnv {
     const int* last;
     const int* cend;
     int slack;
+    const int* kmask;
 };
-// ints per truss: ft[nch_max] | last[nch_max / 4] | slack + 7 reserved | cend[nch_max]
-__host__ __device__ static inline int trs_env_stride(int n_pad_max) { return 2 * (n_pad_max / 16) + n_pad_max / 64 + 8; }
+// ints per truss: ft[nch_max] | last[nch_max / 4] | slack + 7 reserved | cend[nch_max] | kmask[nch_max]
+__host__ __device__ static inline int trs_env_stride(int n_pad_max) { return 3 * (n_pad_max / 16) + n_pad_max / 64 + 8; }
 __host__ __device__ static inline int trs_env_cend_offset(int n_pad_max) { return n_pad_max / 16 + n_pad_max / 64 + 8; }
+__host__ __device__ static inline int trs_env_kmask_offset(int n_pad_max) { return 2 * (n_pad_max / 16) + n_pad_max / 64 + 8; }
 __host__ __device__ static inline TrsEnv trs_env_of(const int* env, int b, int n_pad_max) {
     const int* base = env + (size_t)b * trs_env_stride(n_pad_max);
     return TrsEnv{base, base + n_pad_max / 16, base + trs_env_cend_offset(n_pad_max),
-                  base[n_pad_max / 16 + n_pad_max / 64]};
+                  base[n_pad_max / 16 + n_pad_max / 64], base + trs_env_kmask_offset(n_pad_max)};
 }
 // Routing code in `slack`: low byte = chunks an item may overhang (TRS_NARROW_ITEM - 1: the matrix goes
 // to a wave-per-matrix kernel, TRS_WIDE_ITEM - 1: to the work-group kernel); bit 8 set = the stiffness

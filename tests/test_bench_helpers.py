@@ -59,10 +59,17 @@ def test_vectorised_envelope_counts_equal_the_scalar_models():
         ft[b, :nch] = f
         last[b, :nch // 4] = [lastc[4 * j + 3] for j in range(nch // 4)]
         cend[b, :nch] = [min(nch, max(lastc[t] + 1, (t | 3) + 1)) for t in range(nch)]
-    got = bench.envelope_counts_batch(n_free, nJ, nM, ft, last, cend, np.ones(B, bool))
+    # which stored tiles hold an entry of K_ff (csrc/trs_common.h kmask): random, diagonal tile always
+    kmask = (rng.integers(0, 2 ** 32, size=[B, nchm], dtype=np.int64) | 1).astype(np.int64)
+    plain = bench.envelope_counts_batch(n_free, nJ, nM, ft, last, cend, np.ones(B, bool))
+    got = bench.envelope_counts_batch(n_free, nJ, nM, ft, last, cend, np.ones(B, bool), kmask=kmask)
+    assert (got["stiffness_tiles"] <= got["tiles"]).all() and (got["stiffness_tiles"] < got["tiles"]).any()
+    assert (plain["assemble_bytes"] >= got["assemble_bytes"]).all()
     for b in range(B):
         n = int(n_free[b])
-        want = bench.algorithmic_counts(n, int(nJ[b]), int(nM[b]), cend[b], narrow=True)
+        assert plain["potrf_bytes"][b] == 3 * plain["tiles"][b] * 2048 + 4 * 8 * ((n + 63) // 64 * 64)
+        want = bench.algorithmic_counts(n, int(nJ[b]), int(nM[b]), cend[b], narrow=True, env_kmask=kmask[b])
+        assert got["stiffness_tiles"][b] * 2048 == want["stiffness_tile_bytes"]
         assert got["potrf_tile_flops"][b] == bench.potrf_tile_flops(n, ft[b], last[b], cend[b], narrow=True), b
         assert got["assemble_bytes"][b] == want["assemble_bytes"]
         assert got["potrf_bytes"][b] == want["potrf_bytes"] + want["potrs_bytes"]   # fused substitution

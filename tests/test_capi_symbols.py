@@ -34,7 +34,7 @@ def test_host_side_helpers_of_the_abi():
     # argument validation happens before any launch: bad leading dimension is refused
     assert lib.trs_potrf_batched(1, None, 100, 64, None, None, None, None, None, 64, 0, None) != 0
     assert not hasattr(lib, "trs_set_option")        # ABI 7: no process-wide switches, flags per call
-    assert lib.trs_env_ints(696) == 2 * (704 // 16) + 704 // 64 + 8
+    assert lib.trs_env_ints(696) == 3 * (704 // 16) + 704 // 64 + 8   # ft, last, routing word + 7, cend, kmask (ABI 9)
     # ABI 8: masked streams refuse an empty mask (no compute unit) before touching the runtime
     import ctypes
     handle, empty = ctypes.c_void_p(), (ctypes.c_uint32 * 8)()

@@ -40,9 +40,18 @@ def _upper_from_slab(S, npad):
 
 @pytest.mark.parametrize("compact_mode", [False, True], ids=["slab", "compact"])
 @pytest.mark.parametrize("name", ["bar-6_input_0", "bar-25_input_0", "bar-47_input_0", "bar-120_input_0",
-                                  "bar-942_input_0"])
+                                  "bar-942_input_0", "cube-fixture"])
 def test_stages_against_oracle(gpu, name, compact_mode):
-    data = H.load_json(name)
+    if name == "cube-fixture":   # a generated cube truss in a sweep order: its envelope has tiles without an entry of K_ff
+        cases = list(H.ragged_cube_cases())
+        data = max((d for _, d, _ in cases), key=lambda d: len(d["member"]) if len(d["member"]) < 900 else 0)
+        perm = gpu.profile_permutation(gpu.pack_json([data]))[0][:len(data["joint"])]
+        inv = np.argsort(perm)
+        data = {"joint": [data["joint"][int(j)] for j in perm],
+                "force": [[int(inv[j]), f] for j, f in data["force"]],
+                "member": [[[int(inv[a]), int(inv[b])], t] for (a, b), t in data["member"]]}
+    else:
+        data = H.load_json(name)
     ref = orc.solve(data)
     dev = _device_batch(gpu, [data], options={"compact": compact_mode})   # per-batch switch -> per-call flags
     n = int(dev.packed.n_free[0])
@@ -107,6 +116,19 @@ def test_stages_against_oracle(gpu, name, compact_mode):
     dev.assemble(flags=0)
     S = dev.S.cpu().numpy()[0]
     meta = dev.env.cpu().numpy()[0][nchm + dev.rows // 64: nchm + dev.rows // 64 + 8]
+    # tiles of the envelope that hold no entry of K_ff are not written for the wave-per-matrix kernels (kmask,
+    # csrc/trs_common.h: bit d of word t <=> tile (rows of chunk t, columns of chunk t + d) is written)
+    kmask = dev.env.cpu().numpy()[0][2 * nchm + dev.rows // 64 + 8: 2 * nchm + dev.rows // 64 + 8 + nch].astype(np.int64) & 0xffffffff
+    rows_c, cols_c = np.arange(npad)[:, None] // 16, np.arange(npad)[None, :] // 16
+    in_env = (cols_c >= rows_c) & (cols_c < env_cend[rows_c])
+    written = in_env & (((kmask[rows_c] >> np.clip(cols_c - rows_c, 0, 63)) & 1) == 1)
+    if slack != 1:
+        assert (kmask == 0xffffffff).all()          # the work-group kernel's matrices: every stored tile is written
+    want_full = np.zeros([npad, npad])
+    want_full[:n, :n] = ref["K_ff"]
+    want_full[np.arange(n, npad), np.arange(n, npad)] = 1.0           # identity padding
+    assert not want_full[in_env & ~written].any()   # a tile that is skipped holds no entry of the oracle's K_ff
+    assert written[np.arange(npad), np.arange(npad)].all()
     compact = bool(int(meta[0]) & 0x100)
     # with the option on, narrow envelopes leave the assembly as entry lists
     assert compact == (compact_mode and slack == 1) and int(meta[0]) & 0xff == slack
@@ -151,16 +173,19 @@ def test_stages_against_oracle(gpu, name, compact_mode):
         dev.options["compact"] = True
         S2 = dev.S.cpu().numpy()[0]
         inside = stored & (np.arange(npad)[None, :] < 16 * env_cend[np.arange(npad) // 16][:, None])
-        assert np.array_equal(S2[:npad, :npad][inside], K[inside])
+        assert np.array_equal(S2[:npad, :npad][inside & written], K[inside & written])
+        assert not K[inside & ~written].any() and np.isnan(S2[:npad, :npad][inside & ~written]).all()
         dev.S.fill_(float("nan"))
         dev.assemble(flags=0)
     else:
-        for c in (0, n // 2, n - 1):
-            lo = c // 16 * 16
-            hi = 16 * int(env_cend[c // 16])                        # end of the written part of the row
-            assert H.max_scaled_err(S[c, lo:min(hi, n)], ref["K_ff"][c, lo:min(hi, n)]) <= 1e-14
-            assert not ref["K_ff"][c, min(hi, n):].any()            # beyond it K is structurally zero
-            assert np.isnan(S[c, hi:npad]).all() or hi >= npad      # ... and nothing was written there
+        # every written tile equals the oracle's K_ff; nothing else of the slab was touched (NaN poison)
+        assert H.max_scaled_err(S[:npad, :npad][written], want_full[written]) <= 1e-14
+        assert np.isnan(S[:npad, :npad][~written]).all()
+        assert not want_full[(cols_c >= rows_c) & ~in_env].any()    # beyond the envelope K is structurally zero
+        if name == "cube-fixture":
+            assert (in_env & ~written).any()                        # (this envelope does contain tiles without an entry)
+        if not (in_env & ~written).any():
+            assert (kmask == 0xffffffff).all()                      # skipping is all or nothing per matrix
 
     # --- potrf: U^T U = K_ff, y = L^-1 f ------------------------------------------------------
     # (the stages apart: by default the wave that factors a narrow-envelope matrix substitutes it as well)
@@ -478,7 +503,8 @@ def test_resident_batch_with_a_joint_order_delivers_results_in_the_given_numberi
     given = gpu.DeviceBatch(packed)
     given.solve()
     ref = given.result()
-    tiles = lambda dev: int((dev.env.cpu().numpy()[:, -dev.rows // 16:] - np.arange(dev.rows // 16)).clip(0).sum())
+    cend_of = lambda dev: dev.env.cpu().numpy()[:, dev.rows // 16 + dev.rows // 64 + 8: 2 * (dev.rows // 16) + dev.rows // 64 + 8]
+    tiles = lambda dev: int((cend_of(dev) - np.arange(dev.rows // 16)).clip(0).sum())
     for order in ("profile", "rcm", "fast", gpu.profile_permutation(packed)):
         dev = gpu.DeviceBatch(packed, reorder=order)
         assert dev.joint_out is not None and dev.joint_out.dtype == dev.torch.int32
@@ -640,3 +666,24 @@ def test_get_k_matrix_matches_the_reference_layout(gpu):
     for data, K in zip(datas, many):
         assert H.max_scaled_err(K, orc.global_K(data)) <= 1e-14
     assert gpu.global_stiffness([]) == []
+
+
+def test_tile_hint_is_adopted_only_where_no_matrix_skips_tiles(gpu):
+    """`DeviceBatch.adopt_tile_hint`: a tower-like truss (bar-942) has too few envelope tiles without an entry of
+    K_ff for the skipping to pay - every matrix reports "all tiles written", the hint is adopted and the hinted
+    solves (TRS_ASM_ALL_TILES: no masks formed) return the same bits; generated cube trusses do skip tiles and keep
+    the default."""
+    tower = gpu.DeviceBatch(gpu.pack_json([H.load_json("bar-942_input_0")]).replicate(8), reorder="profile")
+    tower.solve()
+    before = tower.result()
+    assert tower.adopt_tile_hint() and tower.all_tiles
+    tower.S.fill_(float("nan"))
+    tower.solve()
+    after = tower.result()
+    for k in ("displace", "external", "internal", "info"):
+        np.testing.assert_array_equal(getattr(after, k), getattr(before, k))
+    cubes = gpu.DeviceBatch(gpu.pack_json([d for _, d, _ in H.ragged_cube_cases()][6:]), reorder="profile", use_small=False)
+    cubes.solve()
+    assert not cubes.adopt_tile_hint() and not cubes.all_tiles
+    tower.upload(tower.pinned_inputs(tower.packed))      # another topology may follow: the hint goes
+    assert not tower.all_tiles

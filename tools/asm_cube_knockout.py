@@ -19,7 +19,8 @@ def load(tag):
 sizes, tensors = bench.cube_workload(65536, 0, device="cuda:0")
 solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors)
 solver.step(); torch.cuda.synchronize()
-libs = {t: load(t) for t in ("default", "nophase1", "nowalk")}
+libs = {t: load(t) for t in ["default"] + (sys.argv[1:] or ["nophase1", "nowalk"])}
+total = {t: 0.0 for t in libs}
 for bk in solver.buckets:
     db = bk["dev"]
     if db.small:
@@ -35,5 +36,7 @@ for bk in solver.buckets:
             db.assemble()
         e1.record(); torch.cuda.synchronize()
         line += f"  {tag} {e0.elapsed_time(e1) / 3:.3f} ms"
+        total[tag] += e0.elapsed_time(e1) / 3
     db.lib = libs["default"]
     print(line)
+print("sum over the buckets (ms): " + "  ".join(f"{t} {v:.2f}" for t, v in total.items()))

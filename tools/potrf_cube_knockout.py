@@ -30,7 +30,7 @@ sizes, tensors = bench.cube_workload(65536, 0, device="cuda:0")
 solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors)
 solver.step(); torch.cuda.synchronize()
 solver.adopt_launch_hints()
-libs = {t: load(t) for t in tags}
+libs = {t: load(t[4:] if t.startswith("asm-") else t) for t in tags}
 total = {t: 0.0 for t in tags}
 for bk in solver.buckets:
     db = bk["dev"]
@@ -40,9 +40,10 @@ for bk in solver.buckets:
     for tag, lib in libs.items():
         ms = 0.0
         for rep in range(3):
-            db.lib = libs["default"]
+            # ("asm-<tag>": the variant assembles - e.g. nokm: every envelope tile written - and the product factors)
+            db.lib = lib if tag.startswith("asm-") else libs["default"]
             db.dofmap(); db.assemble()
-            db.lib = lib
+            db.lib = libs["default"] if tag.startswith("asm-") else lib
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); db.potrf(); e1.record(); torch.cuda.synchronize()
             if rep:
