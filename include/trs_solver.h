@@ -41,7 +41,7 @@
  *    TrsCompactLayout in csrc/trs_common.h) and the load vector in uf; trs_potrf_batched forms the
  *    tiles from the lists where it consumes them and writes only the factor to the slab.  K_ff then
  *    never exists in dense form in HBM.  Without the flag every matrix goes through the slab (the default:
- *    measured faster end to end).
+ *    measured faster end to end, EXPERIMENTS.md Part II section 3.3 and R4.1).
  *
  * Thread safety: the library keeps NO mutable process-wide state.  Everything that selects a kernel or a data
  * path is an argument of the call (flags / hints below), so concurrent calls on distinct streams with distinct

@@ -701,8 +701,15 @@ inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
     // Geometry in the workspace only when even a whole CU's LDS cannot hold it, and everything but
     // the row tile there when the tables alone do not fit.
     const size_t geom_bytes = ((size_t)(nM_max < 1 ? 1 : nM_max) * 32 + 255) / 256 * 256;
-    for (int g = 1; g >= 0; --g) {
+#ifdef TRS_EXP_ASM_GEOM_IN_WORK_FROM   // A/B: trusses from this many members keep the member geometry in the workspace
+    const int first_g = nM_max >= TRS_EXP_ASM_GEOM_IN_WORK_FROM ? 0 : 1;   // if that gets them two work-groups per CU
+#else
+    const int first_g = 1;
+#endif
+    for (int gi = 0; gi < 2; ++gi) {
+        const int g = gi == 0 ? first_g : 1 - first_g;
         for (int big = 0; big <= 1; ++big) {
+            if (g == 0 && first_g == 0 && gi == 0 && big == 1) continue;   // (the experiment wants the small form only)
             const size_t budget = big ? 160 * 1024 : 80 * 1024;
             const int TR = tile_rows(big ? NT_BIG : NT_DEFAULT);
             const size_t fixed = asm_lds_layout(nJ_max, nM_max, n_pad_max, -16, g, TR).total;
