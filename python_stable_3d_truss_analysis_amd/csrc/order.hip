@@ -776,7 +776,11 @@ extern "C" int trs_joint_order_launch(int B, int nJ_max, int nM_max, const doubl
     static const int lds_limit_set = (int)hipFuncSetAttribute(   // once per process, not per launch
         reinterpret_cast<const void*>(trs_joint_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)lds_limit_set;
+#ifdef TRS_EXP_ORDER_IDLE_LDS   // occupancy experiment: LDS nobody uses, fewer work-groups per CU
+    const size_t lds = ord_layout(nJ_max, nM_max).total + TRS_EXP_ORDER_IDLE_LDS;
+#else
     const size_t lds = ord_layout(nJ_max, nM_max).total;
+#endif
     hipLaunchKernelGGL(trs_joint_order_kernel, dim3(B), dim3(NT), lds, stream, xyz, conn, cbits, loads, nJ, nM, nJ_max,
                        nM_max, perm, choice, reach, xyz_out, conn_out, cbits_out, loads_out, effort);
     return (int)hipGetLastError();

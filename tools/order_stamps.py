@@ -16,7 +16,9 @@ rng = np.random.default_rng(0)
 cubes = gen.generate_cube_batch(rng.integers(8, 191, size=16384), gridRange=(6, 6, 6), seed=7)
 with open(os.path.join(ROOT, "tests", "golden", "data", "bar-942_input_0.json")) as fh:
     bar = batch.pack_json([json.load(fh)]).replicate(4096)
-for label, packed in (("16384 cubes", cubes), ("bar-942 x 4096", bar)):
+big = gen.generate_cube_batch(rng.integers(150, 191, size=8192), gridRange=(6, 6, 6), seed=9)   # the largest buckets' trusses
+small = gen.generate_cube_batch(rng.integers(8, 40, size=16384), gridRange=(6, 6, 6), seed=10).trimmed()
+for label, packed in (("16384 cubes", cubes), ("8192 cubes of 150..190", big), ("16384 cubes of 8..39", small), ("bar-942 x 4096", bar)):
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     tensors = {f: up(getattr(packed, f)) for f in ("xyz", "conn", "cbits", "loads", "nJ", "nM")}
     for effort in (2, 0):

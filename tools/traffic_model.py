@@ -59,14 +59,14 @@ def price(ft, cend, nch, panel_tiles=4, item=2, b_on_chip=False):
     for j in range(0, nch, P):
         blk = list(range(j, min(j + P, nch)))
         kd = ft[j]
-        rd_b += sum(j - max(kd, ft[u]) for u in blk)           # block update: the panel's own rows, once
+        rd_b += sum(max(0, j - max(kd, ft[u])) for u in blk)   # block update: the panel's own rows, once
         lastq = max(int(np.nonzero(ft <= blk[-1])[0].max()), blk[-1])
         c0 = blk[-1] + 1
         while c0 <= lastq:
             nv = min(item, lastq - c0 + 1)
             if not b_on_chip:
-                rd_b += len(blk) * (j - ft[c0])
-            rd_a += sum(j - max(ft[c0], ft[c0 + v]) for v in range(nv))
+                rd_b += len(blk) * max(0, j - ft[c0])
+            rd_a += sum(max(0, j - max(ft[c0], ft[c0 + v])) for v in range(nv))
             c0 += nv
     return rd_a, rd_b
 
