@@ -177,6 +177,17 @@ int trs_recover(int B, int nJ_max, int nM_max, const double *xyz, const int32_t 
                 const int32_t *joint_out /* [B][nJ_max] or NULL */,
                 int hints /* TRS_HINT_RECOVER_UNSTAGED or 0 */, void *stream);
 
+/* trs_recover with the bucket SCATTER of a ragged batch folded in (ABI 9; `batch.RaggedSolver`): the results of truss b
+ * go to row out_rows[b] (int64, device) of result arrays whose rows are nJ_out_max joints / nM_out_max members wide
+ * (>= nJ_max / nM_max; what lies beyond this batch's width is not touched: the caller keeps it zero), through
+ * joint_out as in trs_recover; info[b] (the status trs_potrf_batched left) is copied to info_out[out_rows[b]]
+ * (info_out may be NULL).  No separate copy of the bucket's result rows. */
+int trs_recover_rows(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn, const double *E,
+                     const double *A, const double *loads, const int32_t *free_index, const int32_t *nJ,
+                     const int32_t *nM, const double *uf, int ld_uf, const int32_t *joint_out /* or NULL */,
+                     const int32_t *info, const int64_t *out_rows, int nJ_out_max, int nM_out_max, double *u,
+                     double *f_ext, double *N, int32_t *info_out, int hints, void *stream);
+
 /* Constraint reductions of the GA fitness (truss.py:166-168,429-462; ga.py:139-149):
  *   weight[b]   = sum_m A*L*rho
  *   stress_vio[b] = sum_m max(|N|/A - allow_stress, 0) over members with |N| >= 1e-10
@@ -262,6 +273,18 @@ int trs_graph_features_packed(int B, int nJ_max, int nM_max, const double *xyz, 
  * nJ_max < 8192); trs_joint_order returns hipErrorInvalidValue for a shape that cannot (callers then use the host
  * version). */
 int trs_joint_order_fits(int nJ_max, int nM_max);
+/* trs_joint_order with the bucket GATHER of a ragged batch folded in (ABI 9; `batch.RaggedSolver`): truss b of the
+ * launch is row rows[b] (int64, device) of the input arrays, whose rows are nJ_in_max joints / nM_in_max members wide;
+ * the renumbered truss, its member sections E / A (members keep their order) and its counts nJ / nM are written as
+ * row b of the bucket's arrays (nJ_max / nM_max wide, padding zeroed) - no separate copy of the bucket's rows, no
+ * intermediate in the caller's numbering.  The truss's own sizes must fit nJ_max / nM_max (the bucket's maxima), for
+ * which trs_joint_order_fits must hold.  perm, reach as trs_joint_order. */
+int trs_joint_order_rows(int B, int nJ_max, int nM_max, const int64_t *rows, int nJ_in_max, int nM_in_max,
+                         const double *xyz, const int32_t *conn, const uint8_t *cbits, const double *loads,
+                         const double *E, const double *A, const int32_t *nJ, const int32_t *nM, int32_t *perm,
+                         int32_t *reach /* or NULL */, double *xyz_out, int32_t *conn_out, uint8_t *cbits_out,
+                         double *loads_out, double *E_out, double *A_out, int32_t *nJ_out, int32_t *nM_out, int effort,
+                         void *stream);
 int trs_joint_order(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn, const uint8_t *cbits,
                     const double *loads /* may be NULL when loads_out is */, const int32_t *nJ, const int32_t *nM,
                     int32_t *perm, int32_t *choice, int32_t *reach, double *xyz_out, int32_t *conn_out,
@@ -335,10 +358,20 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound,
               double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info,
               void *work, int32_t *env /* workspace for the envelope metadata, or NULL = dense */,
               const int32_t *joint_out /* [B][nJ_max] or NULL */,
-              int hints /* TRS_HINT_NO_WIDE: route and treat every matrix as narrow; TRS_HINT_COMPACT,
+              int hints /* TRS_HINT_NO_WIDE: route and treat every matrix as narrow, TRS_HINT_COMPACT,
                            TRS_HINT_SEPARATE_STAGES, TRS_HINT_NO_SMALL, TRS_HINT_RECOVER_UNSTAGED, TRS_HINT_ALL_TILES
                            as above */,
               void *stream);
+
+/* trs_solve of ONE size bucket of a ragged batch with the result scatter folded in (trs_recover_rows as the last
+ * stage; never the fused small-system kernel): u, f_ext, N, info_out are the FULL batch's result arrays (rows
+ * nJ_out_max / nM_out_max wide), out_rows[b] the row of truss b in them; `info` is the bucket's own status array. */
+int trs_solve_rows(int B, int nJ_max, int nM_max, int n_max_bound, const double *xyz, const int32_t *conn,
+                   const double *E, const double *A, const uint8_t *cbits, const double *loads, const int32_t *nJ,
+                   const int32_t *nM, int32_t *free_index, int32_t *n_free, int ld, int slab_rows, double *S,
+                   double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info, void *work, int32_t *env,
+                   const int32_t *joint_out, const int64_t *out_rows, int nJ_out_max, int nM_out_max,
+                   int32_t *info_out, int hints, void *stream);
 
 #ifdef __cplusplus
 }

@@ -37,11 +37,17 @@ SIGNATURES = {
                                        _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "trs_joint_order_fits": (_I, [_I, _I]),
     "trs_joint_order": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "trs_joint_order_rows": (_I, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                  _P, _P, _I, _P]),
+    "trs_recover_rows": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P,
+                              _I, _P]),
     "trs_cubegen_dev": (_I, [_I, ctypes.c_uint64, _I, _I, _I, _P, _I, _I, _I, _D, _D, _P, _I, _I, _P, _I, _I, _I,
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int64, _P]),
     "trs_copy_rows": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P]),
     "trs_stream_create_masked": (_I, [_P, _I, _P]),
     "trs_stream_destroy": (_I, [_P]),
+    "trs_solve_rows": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
+                            _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),
     "trs_solve": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
                        _P, _P, _P, _P, _P, _P, _P, _I, _P]),
 }

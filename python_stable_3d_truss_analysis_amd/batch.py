@@ -531,6 +531,35 @@ class DeviceBatch:
             self.joint_out.data_ptr() if self.joint_out is not None else None,
             self._stage_hints() & HINT_RECOVER_UNSTAGED, self._stream()), "trs_recover")
 
+    def recover_rows(self, rows, out, nJ_out_max, nM_out_max):
+        """`trs_recover_rows`: the recovery with a ragged batch's bucket scatter folded in - the results of truss b go
+        to row rows[b] (int64 device tensor) of `out["u"]`, `out["f_ext"]` [*, nJ_out_max, 3], `out["N"]`
+        [*, nM_out_max] and `out["info"]`."""
+        _capi.check(self.lib.trs_recover_rows(
+            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
+            self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
+            self.nJ.data_ptr(), self.nM.data_ptr(), self.uf.data_ptr(), self.rows,
+            self.joint_out.data_ptr() if self.joint_out is not None else None, self.info.data_ptr(),
+            rows.data_ptr(), int(nJ_out_max), int(nM_out_max), out["u"].data_ptr(), out["f_ext"].data_ptr(),
+            out["N"].data_ptr(), out["info"].data_ptr(), self._stage_hints() & HINT_RECOVER_UNSTAGED, self._stream()),
+            "trs_recover_rows")
+
+    def solve_rows(self, rows, out, nJ_out_max, nM_out_max):
+        """`trs_solve_rows`: the staged pipeline in one C call with `recover_rows` as its last stage."""
+        with self.torch.cuda.device(self.device):
+            _capi.check(self.lib.trs_solve_rows(
+                self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), self.conn.data_ptr(),
+                self.E.data_ptr(), self.A.data_ptr(), self.cbits.data_ptr(), self.loads.data_ptr(),
+                self.nJ.data_ptr(), self.nM.data_ptr(), self.free_index.data_ptr(),
+                self.n_free.data_ptr(), self.ld, self.rows, self.S.data_ptr(), self.uf.data_ptr(),
+                self.rows, out["u"].data_ptr(), out["f_ext"].data_ptr(), out["N"].data_ptr(),
+                self.info.data_ptr(), self.work.data_ptr(), self._env_ptr(),
+                self.joint_out.data_ptr() if self.joint_out is not None else None, rows.data_ptr(),
+                int(nJ_out_max), int(nM_out_max), out["info"].data_ptr(),
+                (HINT_NO_WIDE if self.all_narrow and self.env is not None else 0) | self._stage_hints() |
+                (HINT_ALL_TILES if self.all_tiles and self.env is not None else 0),
+                self._stream()), "trs_solve_rows")
+
     def _solve_small(self, fitness=None):
         """`trs_solve_small`: the whole of `Truss.Solve()` in one kernel (optionally with the GA
         reductions); returns the three reduction tensors or None."""
@@ -1211,10 +1240,14 @@ class RaggedSolver:
                 need["env"] = max(need["env"], Bb * self.lib.trs_env_ints(n_b))
             on_device = renumbered and self.device_effort is not None and \
                 (plan[0] == "device" or bool(self.lib.trs_joint_order_fits(nJ_b, nM_b)))
-            if on_device and not self.host_io:   # the bucket's rows in the caller's numbering: input of its trs_joint_order
+            # A resident bucket that is ordered on the device needs neither a gather nor a scatter launch: its
+            # trs_joint_order_rows reads the trusses' rows straight out of the full batch and its trs_recover_rows
+            # writes the results straight into the caller's rows (`fused_io`).
+            fused = on_device and not self.host_io and os.environ.get("TRS_RAGGED_FUSED_IO", "1") != "0"
+            if on_device and not self.host_io and not fused:   # the bucket's rows in the caller's numbering: input of its trs_joint_order
                 need["raw_j"], need["raw_m"] = max(need["raw_j"], Bb * nJ_b), max(need["raw_m"], Bb * nM_b)
             self.buckets.append({"rows": up(np.ascontiguousarray(idx, dtype=np.int64)), "dev": db, "count": Bb,
-                                 "renumbered": renumbered, "order_on_device": on_device, "idx": idx,
+                                 "renumbered": renumbered, "order_on_device": on_device, "idx": idx, "fused_io": fused,
                                  "reach": e([Bb], torch.int32) if on_device else None})
         # one workspace for all buckets (they run one after the other on the stream)
         ws = workspace if workspace is not None else SolverWorkspace(torch, dev)
@@ -1232,7 +1265,9 @@ class RaggedSolver:
                 db._slab = (self._S[:Bb * db.rows * db.ld].view(Bb, db.rows, db.ld),
                             self._uf[:Bb * db.rows].view(Bb, db.rows), self._work[:Bb * wb].view(Bb, wb),
                             self._env[:Bb * ei].view(Bb, ei))
-            if bk["order_on_device"] and self.host_io:
+            if bk["fused_io"]:
+                pass
+            elif bk["order_on_device"] and self.host_io:
                 # (the pull of bucket k + 1 runs while bucket k is being ordered: every bucket its own buffers)
                 nJ_b, nM_b = db.nJ_max, db.nM_max
                 bk["raw"] = {"xyz": e([Bb, nJ_b, 3], torch.float64), "loads": e([Bb, nJ_b, 3], torch.float64),
@@ -1262,7 +1297,7 @@ class RaggedSolver:
         for bk in self.buckets:
             db = bk["dev"]
             pairs = []
-            for f in self.gather_fields:
+            for f in (() if bk["fused_io"] else self.gather_fields):
                 if bk["order_on_device"] and f in self.JOINT_ORDERED:
                     pairs.append((f, self.inputs[f], bk["raw"][f]))       # caller's numbering -> input of the order
                 elif bk["renumbered"] and f in self.JOINT_ORDERED:
@@ -1293,7 +1328,7 @@ class RaggedSolver:
                 live = None if trimmed_is_dst else (P * n)(*[self.live[f].data_ptr() if f in self.live else None
                                                              for f, _, _ in pairs])
                 return n, src, sp, dst, dp, width, fill, counts, elem, live
-            tables.append((pack(pairs, True), [pack(o, False) for o in outs]))
+            tables.append((pack(pairs, True) if pairs else None, [pack(o, False) for o in outs]))
         return tables
 
     def step(self, record=None, sections=None):
@@ -1334,7 +1369,25 @@ class RaggedSolver:
         with torch.cuda.device(self.device):
             if not self.host_io:
                 stream = torch.cuda.current_stream(self.device).cuda_stream
+                nJ_full, nM_full = int(self.u.shape[1]), int(self.N.shape[1])
                 for bk, (gather, scatters) in zip(self.buckets, self._tables):
+                    if bk["fused_io"]:
+                        db, inp, ordr = bk["dev"], self.inputs, bk["ordered"]
+                        timed("order", lambda: _capi.check(self.lib.trs_joint_order_rows(
+                            bk["count"], db.nJ_max, db.nM_max, bk["rows"].data_ptr(), int(inp["xyz"].shape[1]),
+                            int(inp["conn"].shape[1]), inp["xyz"].data_ptr(), inp["conn"].data_ptr(),
+                            inp["cbits"].data_ptr(), inp["loads"].data_ptr(), inp["E"].data_ptr(), inp["A"].data_ptr(),
+                            inp["nJ"].data_ptr(), inp["nM"].data_ptr(), ordr["perm"].data_ptr(), ordr["reach"].data_ptr(),
+                            db.xyz.data_ptr(), db.conn.data_ptr(), db.cbits.data_ptr(), db.loads.data_ptr(),
+                            db.E.data_ptr(), db.A.data_ptr(), db.nJ.data_ptr(), db.nM.data_ptr(), int(self.device_effort),
+                            stream), "trs_joint_order_rows"))
+                        for slot in slots:
+                            if sections[slot] is not None:
+                                db.A.fill_(float(sections[slot][0]))
+                                db.E.fill_(float(sections[slot][1]))
+
+                            timed("solve", lambda: db.solve_rows(bk["rows"], self.outs[slot], nJ_full, nM_full))
+                        continue
                     timed("gather", lambda: _capi.check(self.lib.trs_copy_rows(
                         *gather, bk["count"], bk["rows"].data_ptr(), 0, 0, stream), "trs_copy_rows (gather)"))
                     if bk["order_on_device"]:

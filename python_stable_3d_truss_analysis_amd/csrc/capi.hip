@@ -15,9 +15,10 @@ int trs_potrf_launch(int, const int*, int, size_t, int, double*, int*, const int
 int trs_potrs_launch(int, const int*, int, size_t, int, const double*, double*, int, const int*, int, hipStream_t);
 int trs_recover_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, const int*, const double*, int, double*,
-                       double*, double*, const int*, int, hipStream_t);
+                       double*, double*, const int*, int, hipStream_t, const long long*, int, int, const int*, int*);
 int trs_joint_order_launch(int, int, int, const double*, const int*, const unsigned char*, const double*, const int*,
-                           const int*, int*, int*, int*, double*, int*, unsigned char*, double*, int, hipStream_t);
+                           const int*, int*, int*, int*, double*, int*, unsigned char*, double*, int, hipStream_t,
+                           const long long*, int, int, const double*, const double*, double*, double*, int*, int*);
 int trs_cubegen_dev_launch(int, unsigned long long, int, int, int, const int*, int, int, int, double, double, const double*,
                            int, int, const double*, int, int, int, double*, int*, double*, double*, double*, unsigned char*,
                            double*, int*, int*, int*, int*, long long, hipStream_t);
@@ -105,7 +106,21 @@ int trs_recover(int B, int nJ_max, int nM_max, const double* xyz, const int32_t*
     if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
     return trs_recover_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf,
                               u, f_ext, N, joint_out, (hints & TRS_HINT_RECOVER_UNSTAGED) != 0,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, nullptr, 0, 0, nullptr, nullptr);
+}
+
+int trs_recover_rows(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const double* E,
+                     const double* A, const double* loads, const int32_t* free_index, const int32_t* nJ,
+                     const int32_t* nM, const double* uf, int ld_uf, const int32_t* joint_out, const int32_t* info,
+                     const int64_t* out_rows, int nJ_out_max, int nM_out_max, double* u, double* f_ext, double* N,
+                     int32_t* info_out, int hints, void* stream) {
+    if (B < 0 || nJ_max <= 0 || nM_max < 0 || out_rows == nullptr || nJ_out_max < nJ_max || nM_out_max < nM_max ||
+        (info_out != nullptr && info == nullptr))
+        return (int)hipErrorInvalidValue;
+    return trs_recover_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf,
+                              u, f_ext, N, joint_out, (hints & TRS_HINT_RECOVER_UNSTAGED) != 0,
+                              (hipStream_t)stream, reinterpret_cast<const long long*>(out_rows), nJ_out_max,
+                              nM_out_max, info, info_out);
 }
 
 int trs_fitness(int B, int nJ_max, int nM_max, const double* xyz, const int32_t* conn, const double* A,
@@ -169,7 +184,23 @@ int trs_joint_order(int B, int nJ_max, int nM_max, const double* xyz, const int3
     if (outs == 4 && (xyz_out == xyz || conn_out == conn || cbits_out == cbits || loads_out == loads))
         return (int)hipErrorInvalidValue;                                                  // out of place only
     return trs_joint_order_launch(B, nJ_max, nM_max, xyz, conn, cbits, loads, nJ, nM, perm, choice, reach, xyz_out,
-                                  conn_out, cbits_out, loads_out, effort, (hipStream_t)stream);
+                                  conn_out, cbits_out, loads_out, effort, (hipStream_t)stream, nullptr, 0, 0, nullptr,
+                                  nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int trs_joint_order_rows(int B, int nJ_max, int nM_max, const int64_t* rows, int nJ_in_max, int nM_in_max,
+                         const double* xyz, const int32_t* conn, const uint8_t* cbits, const double* loads,
+                         const double* E, const double* A, const int32_t* nJ, const int32_t* nM, int32_t* perm,
+                         int32_t* reach, double* xyz_out, int32_t* conn_out, uint8_t* cbits_out, double* loads_out,
+                         double* E_out, double* A_out, int32_t* nJ_out, int32_t* nM_out, int effort, void* stream) {
+    if (B < 0 || nJ_max <= 0 || nM_max < 0 || nJ_in_max <= 0 || nM_in_max < 0) return (int)hipErrorInvalidValue;
+    if (B > 0 && (!rows || !perm || !xyz_out || !conn_out || !cbits_out || !loads_out || !E_out || !A_out || !nJ_out ||
+                  !nM_out || !E || !A || !loads))
+        return (int)hipErrorInvalidValue;
+    return trs_joint_order_launch(B, nJ_max, nM_max, xyz, conn, cbits, loads, nJ, nM, perm, nullptr, reach, xyz_out,
+                                  conn_out, cbits_out, loads_out, effort, (hipStream_t)stream,
+                                  reinterpret_cast<const long long*>(rows), nJ_in_max, nM_in_max, E, A, E_out, A_out,
+                                  nJ_out, nM_out);
 }
 
 int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz, const int32_t* conn,
@@ -204,5 +235,36 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
     return trs_recover(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf, u,
                        f_ext, N, joint_out, hints & TRS_HINT_RECOVER_UNSTAGED, stream);
 }
+
+int trs_solve_rows(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz, const int32_t* conn,
+              const double* E, const double* A, const uint8_t* cbits, const double* loads,
+              const int32_t* nJ, const int32_t* nM, int32_t* free_index, int32_t* n_free, int ld,
+              int slab_rows, double* S, double* uf, int ld_uf, double* u, double* f_ext, double* N,
+              int32_t* info, void* work, int32_t* env, const int32_t* joint_out, const int64_t* out_rows,
+                   int nJ_out_max, int nM_out_max, int32_t* info_out, int hints, void* stream) {
+    if (n_max_bound > slab_rows) return (int)hipErrorInvalidValue;
+    int rc = trs_dofmap(B, nJ_max, cbits, nJ, free_index, n_free, stream);
+    if (rc) return rc;
+    const int no_wide = env != nullptr && (hints & TRS_HINT_NO_WIDE) != 0;
+    const int compact = env != nullptr && (hints & TRS_HINT_COMPACT) != 0;
+    const int fused = (hints & TRS_HINT_SEPARATE_STAGES) == 0;
+    rc = trs_assemble(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, n_free, nJ, nM, ld, slab_rows, S,
+                      (no_wide ? TRS_ASM_ALL_NARROW : 0) | (compact ? TRS_ASM_COMPACT : 0) |
+                          ((hints & TRS_HINT_ALL_TILES) ? TRS_ASM_ALL_TILES : 0), work, env, uf, ld_uf,
+                      stream);
+    if (rc) return rc;
+    rc = trs_potrf_batched(B, n_free, ld, slab_rows, S, info, env, work, uf, ld_uf,
+                           (no_wide ? TRS_HINT_NO_WIDE : 0) | (compact ? TRS_HINT_COMPACT : 0) |
+                               (fused ? 0 : TRS_HINT_SEPARATE_STAGES), stream);
+    if (rc) return rc;
+    rc = trs_potrs_batched(B, n_free, ld, slab_rows, S, uf, ld_uf, env,
+                           no_wide ? (TRS_HINT_NO_WIDE | (fused && slab_rows <= 1024 ? TRS_HINT_SUBSTITUTED : 0)) : 0,
+                           stream);
+    if (rc) return rc;
+    return trs_recover_rows(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf, joint_out, info,
+                            out_rows, nJ_out_max, nM_out_max, u, f_ext, N, info_out, hints & TRS_HINT_RECOVER_UNSTAGED,
+                            stream);
+}
+
 
 }  // extern "C"

@@ -264,11 +264,18 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     const double* __restrict__ loads, const int* __restrict__ nJ_arr, const int* __restrict__ nM_arr,
     const int nJ_max, const int nM_max, int* __restrict__ perm_out, int* __restrict__ choice_out,
     int* __restrict__ reach_out, double* __restrict__ xyz_out, int* __restrict__ conn_out,
-    unsigned char* __restrict__ cbits_out, double* __restrict__ loads_out, const int effort) {
+    unsigned char* __restrict__ cbits_out, double* __restrict__ loads_out, const int effort,
+    // gather form (trs_joint_order_rows; all null / 0 otherwise): truss b of this launch is row rows[b] of the INPUT
+    // arrays, whose rows are nJ_in / nM_in wide; its member sections and counts are copied along
+    const long long* __restrict__ rows, const int nJ_in, const int nM_in, const double* __restrict__ E_in,
+    const double* __restrict__ A_in, double* __restrict__ E_out, double* __restrict__ A_out,
+    int* __restrict__ nJ_out, int* __restrict__ nM_out) {
     extern __shared__ unsigned char lds[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nj = nJ_arr[b], nm = nM_arr[b];
+    const size_t src = rows != nullptr ? (size_t)rows[b] : (size_t)b;   // row of the input arrays
+    const int nJ_src = rows != nullptr ? nJ_in : nJ_max, nM_src = rows != nullptr ? nM_in : nM_max;
+    const int nj = nJ_arr[src], nm = nM_arr[src];
     const OrdLds lay = ord_layout(nJ_max, nM_max);
     Tables t;
     t.nfr = lds + lay.nfr;
@@ -296,9 +303,9 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     t.ctrl = reinterpret_cast<int*>(lds + lay.ctrl);
     t.red = reinterpret_cast<unsigned long long*>(lds + lay.red);
 
-    const unsigned char* CB = cbits + (size_t)b * nJ_max;
-    const int* CN = conn + (size_t)b * 2 * nM_max;
-    const double* X = xyz + (size_t)b * 3 * nJ_max;
+    const unsigned char* CB = cbits + src * nJ_src;
+    const int* CN = conn + src * 2 * nM_src;
+    const double* X = xyz + src * 3 * nJ_src;
     int* P = perm_out + (size_t)b * nJ_max;
 
     OrdStamp st;
@@ -722,15 +729,18 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     // the renumbered inputs (reorder.c trs_apply_joint_order): joint k := old joint perm[k], members keep their
     // order with renumbered ends, padding members stay (0, 0)
     if (xyz_out != nullptr) {
-        const double* F = loads + (size_t)b * 3 * nJ_max;
+        const double* F = loads + src * 3 * nJ_src;
         double* XO = xyz_out + (size_t)b * 3 * nJ_max;
         double* FO = loads_out + (size_t)b * 3 * nJ_max;
         unsigned char* CO = cbits_out + (size_t)b * nJ_max;
         for (int j = tid; j < nJ_max; j += NT) {  // a joint per thread, coalesced reads: old joint j -> row inverse[j]
             const int k = j < nj ? inverse[j] : j;
-            const double x0 = X[3 * j], x1 = X[3 * j + 1], x2 = X[3 * j + 2];
-            const double f0 = F[3 * j], f1 = F[3 * j + 1], f2 = F[3 * j + 2];
-            const unsigned char cb = CB[j];
+            // (the padding of the output rows is copied from the input's where that exists - the plain form, where
+            // input and output rows are equally wide - and zero-filled in the gather form)
+            const bool in = rows == nullptr || j < nj;
+            const double x0 = in ? X[3 * j] : 0.0, x1 = in ? X[3 * j + 1] : 0.0, x2 = in ? X[3 * j + 2] : 0.0;
+            const double f0 = in ? F[3 * j] : 0.0, f1 = in ? F[3 * j + 1] : 0.0, f2 = in ? F[3 * j + 2] : 0.0;
+            const unsigned char cb = in ? CB[j] : (unsigned char)0;
             XO[3 * k] = x0; XO[3 * k + 1] = x1; XO[3 * k + 2] = x2;
             FO[3 * k] = f0; FO[3 * k + 1] = f1; FO[3 * k + 2] = f2;
             CO[k] = cb;
@@ -744,6 +754,20 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
                 c.y = inverse[c.y];
             }
             CNO[m] = c;
+        }
+    }
+    if (rows != nullptr) {  // gather form: the member sections and the counts travel with the truss
+        const double* EI = E_in + src * nM_src;
+        const double* AI = A_in + src * nM_src;
+        double* EO = E_out + (size_t)b * nM_max;
+        double* AO = A_out + (size_t)b * nM_max;
+        for (int m = tid; m < nM_max; m += NT) {
+            EO[m] = m < nm ? EI[m] : 0.0;
+            AO[m] = m < nm ? AI[m] : 0.0;
+        }
+        if (tid == 0) {
+            nJ_out[b] = nj;
+            nM_out[b] = nm;
         }
     }
     st.mark(8);
@@ -770,7 +794,9 @@ extern "C" int trs_joint_order_fits(int nJ_max, int nM_max) {
 extern "C" int trs_joint_order_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
                                       const unsigned char* cbits, const double* loads, const int* nJ, const int* nM,
                                       int* perm, int* choice, int* reach, double* xyz_out, int* conn_out,
-                                      unsigned char* cbits_out, double* loads_out, int effort, hipStream_t stream) {
+                                      unsigned char* cbits_out, double* loads_out, int effort, hipStream_t stream,
+                                      const long long* rows, int nJ_in, int nM_in, const double* E_in,
+                                      const double* A_in, double* E_out, double* A_out, int* nJ_out, int* nM_out) {
     if (B <= 0) return 0;
     if (!trs_joint_order_fits(nJ_max, nM_max)) return (int)hipErrorInvalidValue;
     static const int lds_limit_set = (int)hipFuncSetAttribute(   // once per process, not per launch
@@ -782,6 +808,7 @@ extern "C" int trs_joint_order_launch(int B, int nJ_max, int nM_max, const doubl
     const size_t lds = ord_layout(nJ_max, nM_max).total;
 #endif
     hipLaunchKernelGGL(trs_joint_order_kernel, dim3(B), dim3(NT), lds, stream, xyz, conn, cbits, loads, nJ, nM, nJ_max,
-                       nM_max, perm, choice, reach, xyz_out, conn_out, cbits_out, loads_out, effort);
+                       nM_max, perm, choice, reach, xyz_out, conn_out, cbits_out, loads_out, effort, rows, nJ_in, nM_in,
+                       E_in, A_in, E_out, A_out, nJ_out, nM_out);
     return (int)hipGetLastError();
 }

@@ -49,18 +49,26 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     const int* __restrict__ free_index, const int* __restrict__ nJ, const int* __restrict__ nM,
     const int nJ_max, const int nM_max, const double* __restrict__ uf, const int ld_uf,
     double* __restrict__ u_out, double* __restrict__ f_out, double* __restrict__ N_out,
-    const int* __restrict__ joint_out) {
+    const int* __restrict__ joint_out,
+    // scatter form (trs_recover_rows; null / 0 otherwise): the results of truss b go to row out_rows[b] of result
+    // arrays whose rows are nJ_out / nM_out wide (>= this batch's), and its factorisation status to info_out
+    const long long* __restrict__ out_rows, const int nJ_out, const int nM_out, const int* __restrict__ info_in,
+    int* __restrict__ info_out) {
     extern __shared__ double sh[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int joints = nJ[b];
     const int ndof = 3 * joints, ndof_max = 3 * nJ_max;
+    const size_t orow = out_rows != nullptr ? (size_t)out_rows[b] : (size_t)b;
+    const size_t odof = out_rows != nullptr ? (size_t)3 * nJ_out : (size_t)ndof_max;   // doubles per output row of u / f_ext
+    const size_t omem = out_rows != nullptr ? (size_t)nM_out : (size_t)nM_max;
+    if (out_rows != nullptr && tid == 0 && info_out != nullptr) info_out[orow] = info_in[b];
     double *u, *f;  // [ndof_max] each
     if constexpr (STAGED) {
         u = sh;
         f = sh + ndof_max;
     } else {
-        u = u_out + (size_t)b * ndof_max;
-        f = f_out + (size_t)b * ndof_max;
+        u = u_out + orow * odof;
+        f = f_out + orow * odof;
     }
     // STAGED only: integer tables behind u and f
     int* cnt = reinterpret_cast<int*>(sh + 2 * ndof_max);  // [nJ_max]   member ends at a constrained joint
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
                 }
             }
         }
-        N_out[mm] = axial;
+        N_out[orow * omem + m] = axial;
     }
     if constexpr (STAGED) {
         __syncthreads();
@@ -165,8 +173,8 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         __syncthreads();
         for (int d = tid; d < ndof_max; d += 256) {
             const int o = jo ? 3 * jo[d / 3] + d % 3 : d;
-            u_out[(size_t)b * ndof_max + o] = u[d];
-            f_out[(size_t)b * ndof_max + o] = d < ndof ? f[d] : 0.0;
+            u_out[orow * odof + o] = u[d];
+            f_out[orow * odof + o] = d < ndof ? f[d] : 0.0;
         }
     }
 }
@@ -226,14 +234,17 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
                                   const double* E, const double* A, const double* loads,
                                   const int* free_index, const int* nJ, const int* nM,
                                   const double* uf, int ld_uf, double* u, double* f_ext, double* N,
-                                  const int* joint_out, int force_unstaged, hipStream_t stream) {
+                                  const int* joint_out, int force_unstaged, hipStream_t stream,
+                                  const long long* out_rows, int nJ_out, int nM_out, const int* info_in,
+                                  int* info_out) {
     if (B <= 0) return 0;
     // u, f_ext (doubles) + member-end tables (ints)
     const size_t lds = ((size_t)6 * nJ_max * sizeof(double) +
                         ((size_t)2 * nJ_max + 1 + 2 * (size_t)nM_max) * sizeof(int) + 15) / 16 * 16;
     if (lds > 160 * 1024 || force_unstaged) {
         hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), 0, stream, xyz, conn, E, A, loads,
-                           free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out);
+                           free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out, out_rows, nJ_out,
+                           nM_out, info_in, info_out);
         return (int)hipGetLastError();
     }
     static const int lds_limit_set = (int)hipFuncSetAttribute(   // once per process, not per launch
@@ -241,7 +252,8 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
         160 * 1024);
     (void)lds_limit_set;
     hipLaunchKernelGGL(trs_recover_kernel<true>, dim3(B), dim3(256), lds, stream, xyz, conn, E, A, loads,
-                       free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out);
+                       free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out, out_rows, nJ_out, nM_out,
+                       info_in, info_out);
     return (int)hipGetLastError();
 }
 

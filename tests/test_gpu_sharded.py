@@ -109,7 +109,7 @@ def test_bench_launches_its_own_ranks():
     assert "error" not in cube, cube
     assert cube["batch_per_gpu"] == 384 and cube["info_nonzero"] == 0 and cube["value"] > 0
     assert 0 < cube["roofline"]["hbm"]["frac"] < 1 and 0 < cube["roofline"]["mfma"]["frac"] < 1
-    assert set(cube["stages_ms"]) >= {"order", "gather", "solve", "scatter"}
+    assert set(cube["stages_ms"]) >= {"order", "solve"}   # (gather / scatter launches only for the small-system bucket)
     assert line["dataset"]["value"] > 0 and line["dataset"]["info_nonzero_rank0"] == 0
     assert line["dataset"]["rank0_samples"] == 512
 
