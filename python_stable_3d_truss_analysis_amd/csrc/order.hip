@@ -39,9 +39,9 @@ constexpr unsigned long long NO_COST = ~0ull;
 
 // LDS carve-up shared by host and device (byte offsets, 16-byte aligned parts)
 struct OrdLds {
-    size_t nfr, deg, start, fill, lvl, ppos, queue, nextq, order, ids, frank, bins, adj, adjU, owner, keys,
-        cand, best, newidx, c0, c1, cmin, ctrl, red, total;
-    int nch_max;
+    size_t nfr, deg, start, fill, lvl, ppos, queue, nextq, order, ids, frank, bins, adj, adjU, keys,
+        cand, best, newidx, c01, cmin, ctrl, red, total;
+    int nch_max, n4;
 };
 __host__ __device__ inline size_t ord_up(size_t v) { return (v + 15) / 16 * 16; }
 __host__ __device__ inline OrdLds ord_layout(int nJ_max, int nM_max) {
@@ -55,10 +55,10 @@ __host__ __device__ inline OrdLds ord_layout(int nJ_max, int nM_max) {
     l.start = take(4 * (n + 1));            // int [n+1]
     l.fill = take(4 * n);                   // int [n]    fill cursor; later: inverse permutation
     l.lvl = take(4 * n);                    // int [n]    visit stamps of the breadth-first sweeps
-    l.ppos = take(4 * n);                   // int [n]    queue position of the earliest parent
-    l.queue = take(4 * n);                  // int [n]    Cuthill-McKee queue of the running sweep
-    l.nextq = take(4 * n);                  // int [n]    the level being discovered, unsorted
-    l.order = take(4 * n);                  // int [n]    Cuthill-McKee order of all components so far
+    l.ppos = take(4 * n);                   // int [n]    queue position of the earliest parent; later: the whole permutation
+    l.queue = take(2 * n);                  // u16 [n]    Cuthill-McKee queue of the running sweep
+    l.nextq = take(2 * n);                  // u16 [n]    the level being discovered, unsorted
+    l.order = take(2 * n);                  // u16 [n]    Cuthill-McKee order of all components so far
     l.ids = take(2 * n);                    // u16 [n]    free joints by ascending id
     l.frank = take(2 * (n + 1));            // u16 [n+1]  number of free joints with a smaller id
     l.bins = take(2 * 3 * n);               // u16 [n][3] coordinate bins
@@ -66,15 +66,18 @@ __host__ __device__ inline OrdLds ord_layout(int nJ_max, int nM_max) {
     // the unsorted lists are dead once `adj` is sorted, before any key or candidate exists: they share their space
     const size_t shared_at = p;
     l.adjU = take(4 * (e + 4));             // u32 [2 nM + 4] ... as filled: (degree of the neighbour << 13) | neighbour
-    l.owner = take(2 * e);                  // u16 [2 nM] owner joint of an adjacency entry
     const size_t lists_end = p;
     p = shared_at;
-    l.keys = take(8 * n * NWAVE);           // u64 [4][n] sort keys (phase A: one array of 4 n for the levels)
+    // The LDS per work-group decides how many work-groups a CU holds, and the kernel's rate follows that number
+    // almost linearly (2 -> 3 work-groups: 1.36 x): 32-bit sort keys (a 64-bit sort borrows the neighbouring wave's
+    // slice), first chunk and "straddles two chunks" of a joint in one 16-bit word, 16-bit queues - 39 instead of
+    // 50 KB for the largest cube trusses, four work-groups per CU instead of three.
+    l.n4 = (nJ_max + 3) / 4 * 4;
+    l.keys = take(4 * (size_t)l.n4 * NWAVE); // u32 [4][n4] sort keys (phase A: one array of u64 [2 n4] for the levels)
     l.cand = take(2 * n * NWAVE);           // u16 [4][n] candidate order of a wave
     l.best = take(2 * n * NWAVE);           // u16 [4][n] cheapest order a wave has seen
     l.newidx = take(2 * n * NWAVE);         // u16 [4][n]
-    l.c0 = take(2 * n * NWAVE);             // u16 [4][n] first / last row chunk of a joint
-    l.c1 = take(2 * n * NWAVE);
+    l.c01 = take(2 * n * NWAVE);            // u16 [4][n] (first row chunk of a joint << 1) | its rows straddle two chunks
     p = p > lists_end ? p : lists_end;
     l.cmin = take(4 * (size_t)l.nch_max * NWAVE);  // int [4][nch]
     l.ctrl = take(4 * 32);
@@ -125,11 +128,12 @@ struct OrdStamp {
 
 struct Tables {
     unsigned char* nfr;
-    int *deg, *start, *fill, *lvl, *ppos, *queue, *nextq, *order;
-    unsigned short *ids, *frank, *bins, *adj, *owner;
+    int *deg, *start, *fill, *lvl, *ppos;
+    unsigned short *queue, *nextq, *order;
+    unsigned short *ids, *frank, *bins, *adj;
     unsigned* adjU;
-    unsigned long long* keys;
-    unsigned short *cand, *best, *newidx, *c0, *c1;
+    unsigned long long* keys;   // phase A: u64 [2 n4] level-sort keys; phase B: u32 [4][n4] (see the waves' slices)
+    unsigned short *cand, *best, *newidx, *c01;
     int *cmin, *ctrl;
     unsigned long long* red;
 };
@@ -147,12 +151,12 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
     if constexpr (SORTED)
         for (int j = tid; j < nj; j += NT) t.ppos[j] = 0x7fffffff;
     if (tid == 0) {
-        t.queue[0] = root;
+        t.queue[0] = (unsigned short)root;
         t.lvl[root] = stamp;
         *tail_next = 1;
     }
     __syncthreads();
-    int* found = SORTED ? t.nextq : t.queue;  // a sorted level is copied into the queue by rank
+    unsigned short* found = SORTED ? t.nextq : t.queue;  // a sorted level is copied into the queue by rank
     int head = 0, tail = 1, depth = 0, begin = 0;
     const int sub = tid & 3;
     while (head < tail) {
@@ -164,7 +168,7 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
             for (int e = t.start[v] + sub; e < e1; e += 4) {
                 const int w = t.adj[e];
                 const int old = atomicMax(&t.lvl[w], mark);
-                if (old < stamp) found[atomicAdd(tail_next, 1)] = w;                          // first to reach w
+                if (old < stamp) found[atomicAdd(tail_next, 1)] = (unsigned short)w;          // first to reach w
                 if (SORTED && (old < stamp || old == mark)) atomicMin(&t.ppos[w], i);          // w's earliest parent
             }
         }
@@ -183,7 +187,7 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
                     const unsigned long long mine = t.keys[x];
                     int rank = 0;
                     for (int y = 0; y < m; ++y) rank += t.keys[y] < mine ? 1 : 0;
-                    t.queue[tail + rank] = (int)(mine & 0xfffffu);
+                    t.queue[tail + rank] = (unsigned short)(mine & 0xfffffu);
                 }
             } else if (m == 1 && tid == 0) {
                 t.queue[tail] = t.nextq[tail];
@@ -202,7 +206,7 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
 // ord(k) = old id of the joint at position k.  Returns sum_q w_q (w_q + 12); *n_out = free DOFs.
 template <typename Ord>
 __device__ unsigned long long price_order(const Tables& t, int nf, Ord ord, unsigned short* newidx,
-                                          unsigned short* c0, unsigned short* c1, int* cmin, int lane, int* n_out) {
+                                          unsigned short* c01, int* cmin, int lane, int* n_out) {
     int carry = 0;
     for (int base = 0; base < nf; base += 64) {
         const int k = base + lane;
@@ -212,8 +216,7 @@ __device__ unsigned long long price_order(const Tables& t, int nf, Ord ord, unsi
         const int ds = carry + incl - v;
         if (k < nf) {
             newidx[old] = (unsigned short)k;
-            c0[k] = (unsigned short)(ds >> 4);
-            c1[k] = (unsigned short)((ds + v - 1) >> 4);
+            c01[k] = (unsigned short)(((ds >> 4) << 1) | ((((ds + v - 1) >> 4) != (ds >> 4)) ? 1 : 0));
         }
         carry += __shfl(incl, 63);
     }
@@ -230,9 +233,9 @@ __device__ unsigned long long price_order(const Tables& t, int nf, Ord ord, unsi
                       i3 = e + 3 < e1 ? (int)newidx[w3] : k;
             m = min(min(m, i0), min(min(i1, i2), i3));
         }
-        const int col = c0[m];
-        atomicMin(&cmin[c0[k]], col);
-        atomicMin(&cmin[c1[k]], col);
+        const int col = c01[m] >> 1, mine = c01[k];
+        atomicMin(&cmin[mine >> 1], col);
+        if (mine & 1) atomicMin(&cmin[(mine >> 1) + 1], col);
     }
     __builtin_amdgcn_wave_barrier();
     unsigned long long cost = 0;
@@ -284,21 +287,19 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     t.fill = reinterpret_cast<int*>(lds + lay.fill);
     t.lvl = reinterpret_cast<int*>(lds + lay.lvl);
     t.ppos = reinterpret_cast<int*>(lds + lay.ppos);
-    t.queue = reinterpret_cast<int*>(lds + lay.queue);
-    t.nextq = reinterpret_cast<int*>(lds + lay.nextq);
-    t.order = reinterpret_cast<int*>(lds + lay.order);
+    t.queue = reinterpret_cast<unsigned short*>(lds + lay.queue);
+    t.nextq = reinterpret_cast<unsigned short*>(lds + lay.nextq);
+    t.order = reinterpret_cast<unsigned short*>(lds + lay.order);
     t.ids = reinterpret_cast<unsigned short*>(lds + lay.ids);
     t.frank = reinterpret_cast<unsigned short*>(lds + lay.frank);
     t.bins = reinterpret_cast<unsigned short*>(lds + lay.bins);
     t.adj = reinterpret_cast<unsigned short*>(lds + lay.adj);
     t.adjU = reinterpret_cast<unsigned*>(lds + lay.adjU);
-    t.owner = reinterpret_cast<unsigned short*>(lds + lay.owner);
     t.keys = reinterpret_cast<unsigned long long*>(lds + lay.keys);
     t.cand = reinterpret_cast<unsigned short*>(lds + lay.cand);
     t.best = reinterpret_cast<unsigned short*>(lds + lay.best);
     t.newidx = reinterpret_cast<unsigned short*>(lds + lay.newidx);
-    t.c0 = reinterpret_cast<unsigned short*>(lds + lay.c0);
-    t.c1 = reinterpret_cast<unsigned short*>(lds + lay.c1);
+    t.c01 = reinterpret_cast<unsigned short*>(lds + lay.c01);
     t.cmin = reinterpret_cast<int*>(lds + lay.cmin);
     t.ctrl = reinterpret_cast<int*>(lds + lay.ctrl);
     t.red = reinterpret_cast<unsigned long long*>(lds + lay.red);
@@ -479,26 +480,26 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
         if (a == c || t.nfr[a] == 0 || t.nfr[c] == 0) return;
         const int ea = t.start[a] + atomicAdd(&t.fill[a], 1), ec = t.start[c] + atomicAdd(&t.fill[c], 1);
         t.adjU[ea] = ((unsigned)t.deg[c] << ID_BITS) | (unsigned)c;
-        t.owner[ea] = (unsigned short)a;
         t.adjU[ec] = ((unsigned)t.deg[a] << ID_BITS) | (unsigned)a;
-        t.owner[ec] = (unsigned short)c;
     });
     __syncthreads();
     // neighbour lists by ascending (degree, id): rank of an entry inside its list (equal keys = parallel
     // members: interchangeable, ordered by position)
-    const int nadj = t.start[nj];
-    for (int e = tid; e < nadj; e += NT) {
-        const int a = t.owner[e], s = t.start[a], d = t.deg[a];
-        const unsigned key = t.adjU[e];
-        int rank = 0;
-        for (int i = 0; i < d; i += 4) {  // four independent reads per step (the list area has four entries of slack)
-            const unsigned k0 = t.adjU[s + i], k1 = t.adjU[s + i + 1], k2 = t.adjU[s + i + 2], k3 = t.adjU[s + i + 3];
-            rank += (k0 < key || (k0 == key && s + i < e)) ? 1 : 0;
-            rank += (i + 1 < d && (k1 < key || (k1 == key && s + i + 1 < e))) ? 1 : 0;
-            rank += (i + 2 < d && (k2 < key || (k2 == key && s + i + 2 < e))) ? 1 : 0;
-            rank += (i + 3 < d && (k3 < key || (k3 == key && s + i + 3 < e))) ? 1 : 0;
+    // (four lanes share a joint's list: lane `sub` ranks the entries sub, sub + 4, ... - no table of an entry's owner)
+    for (int a = tid >> 2; a < nj; a += NT / 4) {
+        const int s = t.start[a], d = t.deg[a];
+        for (int e = s + (tid & 3); e < s + d; e += 4) {
+            const unsigned key = t.adjU[e];
+            int rank = 0;
+            for (int i = 0; i < d; i += 4) {  // four independent reads per step (the list area has four entries of slack)
+                const unsigned k0 = t.adjU[s + i], k1 = t.adjU[s + i + 1], k2 = t.adjU[s + i + 2], k3 = t.adjU[s + i + 3];
+                rank += (k0 < key || (k0 == key && s + i < e)) ? 1 : 0;
+                rank += (i + 1 < d && (k1 < key || (k1 == key && s + i + 1 < e))) ? 1 : 0;
+                rank += (i + 2 < d && (k2 < key || (k2 == key && s + i + 2 < e))) ? 1 : 0;
+                rank += (i + 3 < d && (k3 < key || (k3 == key && s + i + 3 < e))) ? 1 : 0;
+            }
+            t.adj[s + rank] = (unsigned short)(key & ((1u << ID_BITS) - 1));
         }
-        t.adj[s + rank] = (unsigned short)(key & ((1u << ID_BITS) - 1));
     }
     __syncthreads();
 
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
         __syncthreads();
         for (int i = tid; i < count; i += NT) {
             const int v = t.queue[i];
-            t.order[n_order + i] = v;
+            t.order[n_order + i] = (unsigned short)v;
             t.lvl[v] = PERMANENT;
         }
         n_order += count;
@@ -558,10 +559,12 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     unsigned short* cand = t.cand + (size_t)wave * nJ_max;
     unsigned short* wbest = t.best + (size_t)wave * nJ_max;
     unsigned short* newidx = t.newidx + (size_t)wave * nJ_max;
-    unsigned short* c0 = t.c0 + (size_t)wave * nJ_max;
-    unsigned short* c1 = t.c1 + (size_t)wave * nJ_max;
+    unsigned short* c01 = t.c01 + (size_t)wave * nJ_max;
     int* cmin = t.cmin + (size_t)wave * lay.nch_max;
-    unsigned long long* keys = t.keys + (size_t)wave * nJ_max;
+    // this wave's slice of the key area: n4 32-bit keys; a 64-bit sort (key fields that do not fit 32 bits: huge
+    // coordinate ranges) takes the slices of waves w and w + 1 for an even w, and only the even waves sweep then
+    unsigned* k32 = reinterpret_cast<unsigned*>(t.keys) + (size_t)wave * lay.n4;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(k32);
     unsigned long long my_cost = NO_COST;
     int my_rank = 0x7fffffff, my_choice = 0, ndof = 0;
     auto consider = [&](unsigned long long cost, int eval_rank, int choice, auto ord) {
@@ -576,21 +579,21 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     if (nf > 0) {
         if (wave == (n_sweep > 1 ? 2 : 0)) {  // reverse Cuthill-McKee
             auto ord = [&](int k) { return t.order[nf - 1 - k]; };
-            consider(price_order(t, nf, ord, newidx, c0, c1, cmin, lane, &ndof), 0, 0, ord);
+            consider(price_order(t, nf, ord, newidx, c01, cmin, lane, &ndof), 0, 0, ord);
         }
         if (wave == (n_sweep > 1 ? 3 : 1)) {  // plain Cuthill-McKee
             auto ord = [&](int k) { return t.order[k]; };
-            consider(price_order(t, nf, ord, newidx, c0, c1, cmin, lane, &ndof), 1, 1, ord);
+            consider(price_order(t, nf, ord, newidx, c01, cmin, lane, &ndof), 1, 1, ord);
         }
-        for (int i = wave; i < n_sweep; i += NWAVE) {
+        const bool wide_keys = key_bits > 32;
+        for (int i = wide_keys ? ((wave & 1) ? n_sweep : wave / 2) : wave; i < n_sweep; i += wide_keys ? NWAVE / 2 : NWAVE) {
             const int ax = i == 0 ? first_ax : (i <= first_ax ? i - 1 : i);
             const int a0 = axis_of(ax, 0), a1 = axis_of(ax, 1), a2 = axis_of(ax, 2);
             // lexicographic by (bin a0, bin a1, bin a2, id): ONE rank sort.  x = position in the ascending id
             // list, so (bins, x) orders like (bins, id).  32-bit keys when the three bin fields and x fit (any
             // lattice-like truss: a few dozen bins per axis) - four keys per LDS read, one compare each -,
             // 64-bit keys otherwise.
-            if (key_bits <= 32) {
-                unsigned* k32 = reinterpret_cast<unsigned*>(keys);
+            if (!wide_keys) {
                 for (int x = lane; x < nf; x += 64) {
                     const int j = t.ids[x];
                     k32[x] = ((((unsigned)t.bins[3 * j + a0] << bits_of(a1) | (unsigned)t.bins[3 * j + a1]) << bits_of(a2) |
@@ -650,8 +653,8 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
             st.mark(3);
             auto fwd = [&](int k) { return (int)cand[k]; };
             auto rev = [&](int k) { return (int)cand[nf - 1 - k]; };
-            consider(price_order(t, nf, fwd, newidx, c0, c1, cmin, lane, &ndof), 2 + 2 * i, 2 + 2 * ax, fwd);
-            consider(price_order(t, nf, rev, newidx, c0, c1, cmin, lane, &ndof), 3 + 2 * i, 3 + 2 * ax, rev);
+            consider(price_order(t, nf, fwd, newidx, c01, cmin, lane, &ndof), 2 + 2 * i, 2 + 2 * ax, fwd);
+            consider(price_order(t, nf, rev, newidx, c01, cmin, lane, &ndof), 3 + 2 * i, 3 + 2 * ax, rev);
             st.mark(4);
         }
     }
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
         if (t.red[w] < t.red[win] || (t.red[w] == t.red[win] && t.ctrl[4 + w] < t.ctrl[4 + win])) win = w;
     const unsigned short* wperm = t.best + (size_t)win * nJ_max;
     int* inverse = t.fill;
-    int* fullperm = t.queue;  // [nJ_max] the whole permutation (the sweeps' queue is dead)
+    int* fullperm = t.ppos;   // [nJ_max] the whole permutation (the sweeps' parent positions are dead)
     for (int k = tid; k < nJ_max; k += NT) {
         if (k < nf) {
             const int old = wperm[k];
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
         if (nf > 0) {
             auto ord = [&](int k) { return (int)wperm[k]; };
             int n = 0;
-            price_order(t, nf, ord, newidx, c0, c1, cmin, lane, &n);
+            price_order(t, nf, ord, newidx, c01, cmin, lane, &n);
             const int nch = (n + 15) >> 4, nchp = (n + 63) / 64 * 4;
             int* ft = cmin;  // cmin -> ft: running minimum from the end (padding chunks couple to themselves)
             for (int q = nch + lane; q < nchp; q += 64) ft[q] = q;
