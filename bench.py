@@ -404,7 +404,7 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
         # informational: the same batch from page-locked HOST arrays to page-locked host results, one call
         # (set-up, bucket pulls, device order + solves, pushes: `batch.solve_batch_streamed`)
         try:
-            pinned, pool = packed.to_packed(tensors).pinned(), batch.ResultPool()
+            pinned, pool = packed.to_packed(tensors).pinned(), batch.ResultPool(tracked=True)   # (results are only read)
             for _ in range(2):
                 batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
             t0 = time.perf_counter()

@@ -1553,11 +1553,19 @@ def _solve_small_host(packed: PackedBatch, torch, dev, variants, on_device=False
 class ResultPool:
     """Page-locked host buffers for the results of `solve_batch(..., pool=...)`, reused from call to call:
     the download is one DMA per array instead of a copy into freshly page-faulted memory.  The arrays of a
-    returned `BatchResult` are views of the pool and stay valid until the pool serves another call."""
+    returned `BatchResult` are views of the pool and stay valid until the pool serves another call.
 
-    def __init__(self):
+    `tracked=True` (opt-in): the host-fed pipeline (`solve_batch_streamed`) keeps LIVE EXTENTS of the result arrays
+    (`take_tracked`) and pushes only live bytes - the zero padding crosses the link once, when the arrays are made.
+    The contract that comes with it: the returned arrays are READ-ONLY views; a caller who writes into them (say
+    `res.displace += x`) must call `invalidate()` before the pool's next use, or later results carry stale bytes in
+    their padding.  Without it every push zero-fills its rows to their full width (more bytes over PCIe, no
+    contract)."""
+
+    def __init__(self, tracked=False):
         self._bufs = {}
         self._live = {}
+        self.tracked = bool(tracked)
 
     def take(self, torch, key, shape, dtype):
         self._live.pop(key, None)   # whoever takes the plain buffer may write anything anywhere in it
@@ -1596,7 +1604,10 @@ def host_result_arrays(torch, pool, B, nJ_max, nM_max, device):
     `ResultPool`, with their live extents."""
     out, live = {}, {}
     for name, shape in (("u", [B, nJ_max, 3]), ("f_ext", [B, nJ_max, 3]), ("N", [B, nM_max])):
-        out[name], live[name] = pool.take_tracked(torch, (0, name), shape, torch.float64, device)
+        if pool.tracked:   # (the caller opted into the read-only contract of tracked extents)
+            out[name], live[name] = pool.take_tracked(torch, (0, name), shape, torch.float64, device)
+        else:
+            out[name] = pool.take(torch, (0, name), shape, torch.float64)
     out["info"] = pool.take(torch, (0, "info"), [B], torch.int32)
     out["live"] = live
     return out

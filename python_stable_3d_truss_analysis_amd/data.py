@@ -379,6 +379,12 @@ def _dense_from_truss(truss):
 
 
 _SIZE_BLOCK = 4096   # polycube sizes are drawn in fixed blocks of global sample indices
+#: Definition of "the dataset of (seed, n_samples)".  2 (since round 3): sizes keyed by (seed, global index // 4096),
+#: default chunk 32 768 - independent of how the dataset is cut into chunks and ranks.  1 (round 2): sizes keyed by
+#: (seed, chunk index) with a default chunk of 16 384 - the same (seed, n_samples) gave OTHER samples.  Pinned by
+#: tests/test_data_graph.py::test_dataset_definition_is_pinned; the generators' per-truss streams (keyed by the
+#: global index) did not change.
+DATASET_VERSION = 2
 
 
 def dataset_sizes(seed, first, count, numCubeRange):

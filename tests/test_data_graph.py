@@ -198,6 +198,19 @@ def test_bar25_through_the_device_feature_path_matches_the_reference_capture(gol
         assert float(t["weight"][0]) == pytest.approx(float(z[f"{tag}_noimp/originWeight"]), rel=1e-12)
 
 
+def test_dataset_definition_is_pinned():
+    """DATASET VERSION 2 (`data.DATASET_VERSION`): sample i of a dataset draws its polycube size from
+    numpy's `default_rng([seed, i // 4096])` at position i % 4096.  These values pin that definition - a change here
+    changes every dataset a user regenerates from (seed, n_samples) and needs a version bump and a note in
+    INTEGRATION.md (version 1, before round 3, keyed the stream by the CHUNK index and depended on the chunk size)."""
+    assert data.DATASET_VERSION == 2
+    assert data.dataset_sizes(7, 0, 8, (8, 190)).tolist() == [180, 122, 133, 172, 113, 149, 160, 49]
+    assert data.dataset_sizes(7, 65530, 8, (8, 190)).tolist() == [98, 40, 148, 98, 59, 144, 112, 122]
+    assert data.dataset_sizes(11, 4094, 6, (8, 190)).tolist() == [121, 144, 67, 45, 50, 176]     # across a block
+    assert data.dataset_sizes(0, 999999, 3, (5, 5)).tolist() == [5, 5, 5]
+    assert data.dataset_sizes(0, 123456, 4, (1, 3)).tolist() == [1, 2, 2, 1]
+
+
 def test_dataset_sizes_depend_on_the_global_index_only():
     whole = data.dataset_sizes(3, 0, 10000, (8, 190))
     assert whole.min() >= 8 and whole.max() <= 190 and len(np.unique(whole)) > 150

@@ -341,8 +341,11 @@ def test_masked_streams_run_kernels_and_refuse_bad_masks(gpu):
         gpu._MaskedStreams(torch, torch.device("cuda:0"), lib, 0, 8)
 
 
-def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
-    """`solve_batch_streamed` / `RaggedSolver(host_io=...)`: the batch stays in page-locked host memory, every
+@pytest.mark.parametrize("tracked", [False, True], ids=["zero-filled rows", "tracked live extents"])
+def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu, tracked):
+    """`ResultPool(tracked=True)` is the opt-in, read-only-results form (only live bytes are pushed; junk written by
+    hand needs `invalidate()`); the default pool zero-fills every pushed row to its full width and needs no contract.
+    `solve_batch_streamed` / `RaggedSolver(host_io=...)`: the batch stays in page-locked host memory, every
     bucket is pulled over PCIe by the gather kernel, solved, and pushed into the page-locked result arrays (full
     rows, zero padding) on three streams - bit for bit the results of the one-piece `solve_batch`, also when the
     result pool held other data before, and `solve_batch(pool=...)` routes big pinned batches there by itself."""
@@ -350,7 +353,7 @@ def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
     rng = np.random.default_rng(8)
     packed = gen.generate_cube_batch(rng.integers(1, 191, size=1500), gridRange=(6, 6, 6), seed=13)
     want = gpu.solve_batch(packed, reorder=True)
-    pinned, pool = packed.pinned(), gpu.ResultPool()
+    pinned, pool = packed.pinned(), gpu.ResultPool(tracked=tracked)
     assert gpu._is_pinned(pinned) and not gpu._is_pinned(packed)
     for reorder in (True, False, "rcm"):                # device plan, no order, a plan carried out on the host
         ref = want if reorder is True else gpu.solve_batch(packed, reorder=reorder)
@@ -358,7 +361,8 @@ def test_host_fed_pipeline_gives_the_bits_of_the_one_piece_solve(gpu):
             if attempt == 1:                              # content written by hand must not survive either
                 for k in ("u", "f_ext", "N"):
                     pool._bufs[(0, k)].fill_(float("nan"))
-                pool.invalidate()
+                if tracked:                               # (the default pool needs no such call)
+                    pool.invalidate()
             got = gpu.solve_batch_streamed(pinned, reorder=reorder, pool=pool)
             for k in ("displace", "external", "internal", "info"):
                 np.testing.assert_array_equal(getattr(got, k), getattr(ref, k), err_msg=f"{k} reorder={reorder}")

@@ -18,7 +18,7 @@ for reorder in (False, True):
         dt = time.perf_counter() - t0
         print(f"reorder={reorder}, {attempt}: {dt:.3f} s end to end = {B / dt:.0f} solves/s, "
               f"info_nonzero={int((res.info != 0).sum())}")
-pinned, pool = packed.pinned(), batch.ResultPool()
+pinned, pool = packed.pinned(), batch.ResultPool(tracked=True)
 for reorder in (True, "fast", "rcm"):
     for attempt in ("first call (pool allocation)", "second call", "third call"):
         t0 = time.perf_counter()
