@@ -662,7 +662,8 @@ def dataset_stream(n_samples, rank=0, world=1, chunk=32768, seed=0, numCubeRange
     of padded rows) into a device staging buffer and copied by DMA into page-locked host memory on a second
     stream WHILE the device works on the next chunk.  Yields `PackedGraphs` whose tensors are views of the
     page-locked ring: `graphs[i]` is sample `graphs.first + i` as a `HeteroData` (torch_geometric present) or
-    `GraphStores`.  A yielded chunk stays valid until the generator has been advanced `slots - 1` more times -
+    `GraphStores`.  A yielded chunk stays valid until the generator has been advanced `slots - 1` more times (and, after
+    the generator has ended, until the next stream on this device starts: the rings are reused) -
     a consumer that keeps samples longer copies them (`torch.save`, a collate into its own batch, ...).
     `record` (a list): (name, start event, end event) of every chunk's device work and copy are appended.
     The dataset is defined by (seed, global sample index) exactly as in `dataset_chunks`."""
@@ -673,8 +674,11 @@ def dataset_stream(n_samples, rank=0, world=1, chunk=32768, seed=0, numCubeRange
     slots = max(2, int(slots))
     n_chunks = (int(n_samples) + chunk - 1) // chunk
     mine = list(range(rank, n_chunks, world))
-    # (the ring lives as long as the process: page-locking a few GB costs as much as solving a chunk)
-    ring = _RINGS.setdefault((str(dev), slots), _PackedRing(torch, dev, slots))
+    # (rings outlive the call: page-locking a few GB costs as much as solving a chunk.  A running stream OWNS its ring -
+    # it is taken out of the cache here and put back when the generator ends or is closed -, so two streams on one
+    # device never share buffers)
+    ring_key = (str(dev), slots)
+    ring = _RINGS.pop(ring_key, None) or _PackedRing(torch, dev, slots)
     main = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev)
     regression = taskType == TaskType.REGRESSION
@@ -740,21 +744,27 @@ def dataset_stream(n_samples, rank=0, world=1, chunk=32768, seed=0, numCubeRange
     #   -> queue chunk k's large copy -> launch chunk k + 1 (kernels only) -> hand over chunk k - 1
     # so that no small copy is ever submitted while a large one is in flight, and the device always has the next
     # chunk's kernels queued while the host is with the consumer.
-    if not mine:
-        return
-    running = launch(0, *prepare(mine[0]))
-    pending = None
-    for i in range(len(mine)):
-        nxt = prepare(mine[i + 1]) if i + 1 < len(mine) else None
-        copied = copy_out(i, *running)
-        if nxt is not None:
-            running = launch(i + 1, *nxt)
-        if pending is not None:
-            pending[1].synchronize()
-            yield pending[0]
-        pending = copied
-    pending[1].synchronize()
-    yield pending[0]
+    try:
+        if not mine:
+            return
+        running = launch(0, *prepare(mine[0]))
+        pending = None
+        for i in range(len(mine)):
+            nxt = prepare(mine[i + 1]) if i + 1 < len(mine) else None
+            copied = copy_out(i, *running)
+            if nxt is not None:
+                running = launch(i + 1, *nxt)
+            if pending is not None:
+                pending[1].synchronize()
+                yield pending[0]
+            pending = copied
+        pending[1].synchronize()
+        yield pending[0]
+    finally:
+        for ev in ring.done:          # nothing of this stream is in flight when the ring changes hands
+            if ev is not None:
+                ev.synchronize()
+        _RINGS.setdefault(ring_key, ring)
 
 
 class TrussHeteroDataCreator:
