@@ -466,8 +466,9 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
             "rank_ms_per_step": {"min": elapsed_min / args.cube_steps * 1e3, "max": step_s * 1e3},
             "steps": args.cube_steps, "batch_per_gpu": packed.B, "buckets": len(solver.buckets),
             "buckets_with_launch_hints": hinted, "info_nonzero": info_bad, "wide_envelopes": n_wide,
-            "joint_order": "trs_joint_order on the device, INSIDE the timed step (every candidate); results in the "
-                           "generator's numbering",
+            "joint_order": "trs_joint_order on the device, INSIDE the timed step (effort 3: every coordinate sweep; reverse "
+                           "Cuthill-McKee and its reverse for trusses below 128 free joints); results in the generator's "
+                           "numbering",
             "stages_ms": stage_ms,
             "roofline": {"bound": bound, "intensity_flop_per_byte": intensity,
                          "mfma": {"achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_TFLOPS,
@@ -833,13 +834,13 @@ def main():
     if world == 1 and order == "profile" and not args.no_dense_ref and dev.joint_out is not None:
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         raw = {f: up(getattr(packed, f)) for f in batch.DeviceBatch.INPUT_FIELDS}
-        ordered = batch.joint_order_device(torch, raw, effort=2)
+        ordered = batch.joint_order_device(torch, raw, effort=3)   # (what `reorder=True` does: every sweep; RCM only for small trusses)
         tens = dict(raw)
         tens.update({k: ordered[k] for k in ("xyz", "conn", "cbits", "loads")})
         inner = batch.DeviceBatch.from_device(tens, packed.n_max, joint_out=ordered["perm"], all_narrow=dev.all_narrow)
 
         def ordered_step():   # the order is found and applied again every step, into the solver's input tensors
-            batch.joint_order_device(torch, raw, effort=2, out=ordered)
+            batch.joint_order_device(torch, raw, effort=3, out=ordered)
             inner.solve()
         for _ in range(args.warmup):
             ordered_step()

@@ -66,7 +66,8 @@ int trs_rcm_order(int B, int nJ_max, int nM_max, const int32_t *conn, const uint
 int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
                       const uint8_t *cbits, const int32_t *nJ, const int32_t *nM, int32_t *perm /* [B][nJ_max] */,
                       int32_t *choice /* [B] or NULL */,
-                      int effort /* 0: RCM and its reverse, 1: + the sweep along the longest extent, 2: all sweeps */);
+                      int effort /* 0: RCM and its reverse, 1: + the sweep along the longest extent, 2: all sweeps,
+                                    3: all sweeps, RCM and its reverse only below 128 free joints or without a sweep */);
 
 /* Reach of the row envelope below the 64 x 64 diagonal blocks of K_ff, in 16-row chunks, per truss, for the
  * numbering given or after a renumbering (what trs_assemble derives on the device).  A batch that stays at or below 24 everywhere holds

@@ -268,7 +268,10 @@ int trs_graph_features_packed(int B, int nJ_max, int nM_max, const double *xyz, 
  *   xyz_out, conn_out, cbits_out, loads_out (all four or all NULL; not the input arrays): the renumbered trusses,
  *                       joint k := old joint perm[k]; members keep their order (N needs no mapping), their end
  *                       joints are renumbered, padding members stay (0, 0)
- *   effort              0: RCM and its reverse, 1: + the sweep along the longest extent, 2: all sweeps
+ *   effort              0: RCM and its reverse, 1: + the sweep along the longest extent, 2: all sweeps, 3: all sweeps,
+ *                       RCM and its reverse only for trusses with fewer than 128 free joints or without a usable
+ *                       sweep (on larger lattice-like trusses a sweep wins and Cuthill-McKee is 40 % of the kernel's
+ *                       time; +0.2 % stored tiles over 2048 mixed cube trusses)
  * trs_joint_order_fits says whether a batch shape can be ordered on the device (tables within a CU's LDS,
  * nJ_max < 8192); trs_joint_order returns hipErrorInvalidValue for a shape that cannot (callers then use the host
  * version). */

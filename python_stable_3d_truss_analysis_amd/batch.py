@@ -301,26 +301,29 @@ def order_plan(reorder, nJ_max, nM_max):
     """How a `reorder=` argument is carried out: None (no renumbering), ("given", perm array), ("device", effort)
     - `trs_joint_order` on the GPU, no host pass - or ("host", name) - `joint_order` on the host.
 
-    True / "profile" = every candidate, "fast" = RCM, its reverse and one sweep: on the device whenever the
-    batch shape fits its kernel (`trs_joint_order_fits`), else on the host.  "rcm" = plain reverse Cuthill-McKee
-    (host).  "host-profile" / "host-fast" force the host versions (comparisons, tests); "device" insists on the
-    device version and raises when the shape does not fit."""
+    True / "auto" = every coordinate sweep, plus reverse Cuthill-McKee and its reverse for small trusses (fewer than
+    128 free joints) or where no sweep is possible - effort 3: on larger lattice-like trusses a sweep wins, and
+    Cuthill-McKee is 40 % of the device kernel's time; "profile" = every candidate for every truss (effort 2);
+    "fast" = RCM, its reverse and one sweep: on the device whenever the batch shape fits its kernel
+    (`trs_joint_order_fits`), else on the host.  "rcm" = plain reverse Cuthill-McKee (host).  "host-auto" /
+    "host-profile" / "host-fast" force the host versions (comparisons, tests); "device" insists on the device
+    version (effort 3) and raises when the shape does not fit."""
     if reorder is False or reorder is None:
         return None
     if isinstance(reorder, np.ndarray):
         return ("given", reorder)
-    if reorder in ("host-profile", "host-fast", "rcm"):
-        return ("host", {"host-profile": "profile", "host-fast": "fast"}.get(reorder, reorder))
-    if reorder is True or reorder in ("profile", "fast", "device"):
+    if reorder in ("host-auto", "host-profile", "host-fast", "rcm"):
+        return ("host", {"host-auto": "auto", "host-profile": "profile", "host-fast": "fast"}.get(reorder, reorder))
+    if reorder is True or reorder in ("auto", "profile", "fast", "device"):
         fits = bool(_capi.load().trs_joint_order_fits(int(nJ_max), int(nM_max)))
         if fits:
-            return ("device", 1 if reorder == "fast" else 2)
+            return ("device", {"fast": 1, "profile": 2}.get(reorder, 3))
         if reorder == "device":
             raise ValueError(f"joint order on the device: batch shape ({nJ_max} joints, {nM_max} members) does not "
                              "fit trs_joint_order (see trs_joint_order_fits)")
-        return ("host", "fast" if reorder == "fast" else "profile")
-    raise ValueError(f"unknown joint order {reorder!r} (True, 'profile', 'fast', 'rcm', 'device', 'host-profile', "
-                     "'host-fast' or a permutation array)")
+        return ("host", reorder if reorder in ("fast", "profile") else "auto")
+    raise ValueError(f"unknown joint order {reorder!r} (True, 'auto', 'profile', 'fast', 'rcm', 'device', 'host-auto', "
+                     "'host-profile', 'host-fast' or a permutation array)")
 
 
 def joint_order_device(torch, tensors, effort=2, apply=True, want_choice=False, out=None):
@@ -805,9 +808,10 @@ def rcm_permutation(packed: PackedBatch):
 def profile_permutation(packed: PackedBatch, return_choice=False, effort=2):
     """The cheapest of several candidate joint orders per truss (native, `csrc/reorder.c`
     `trs_profile_order`): reverse Cuthill-McKee, its reverse and twelve binned coordinate sweeps, priced
-    by the 16x16-tile envelope the factorisation works in.  Never worse than `rcm_permutation`; on the
-    reference's cube trusses 25-35 % less factorisation work.  perm[b, k] = old id of the joint that
-    becomes joint k; `return_choice` adds the winning candidate's id per truss (0 = RCM)."""
+    by the 16x16-tile envelope the factorisation works in.  Never worse than `rcm_permutation` (efforts 0-2); on
+    the reference's cube trusses 25-35 % less factorisation work.  perm[b, k] = old id of the joint that
+    becomes joint k; `return_choice` adds the winning candidate's id per truss (0 = RCM).  `effort`: 0 RCM and
+    its reverse, 1 + one sweep, 2 everything, 3 every sweep and the RCM pair only for trusses below 128 free joints."""
     import ctypes
     from .generate import _load
     lib = _load()
@@ -856,10 +860,11 @@ def envelope_reach(packed: PackedBatch, perm=None):
 
 def joint_order(packed: PackedBatch, reorder):
     """The HOST-side permutation for a `reorder=` argument, with the same meaning of the names as `order_plan`:
-    True / "profile" = `profile_permutation` with every candidate, "fast" = the same with one coordinate sweep
-    instead of six (80 % of the gain for half the host time: what a host-in / host-out call wants when the order
-    has to be found on the host, where it is the longest step), "rcm" = `rcm_permutation`; an int32 array
-    [B, nJ_max] found earlier (e.g. on another thread) passes through."""
+    True / "auto" = `profile_permutation(effort=3)` (every sweep; Cuthill-McKee for small trusses), "profile" = every
+    candidate for every truss, "fast" = one coordinate sweep instead of six (80 % of the gain for half the host
+    time: what a host-in / host-out call wants when the order has to be found on the host, where it is the longest
+    step), "rcm" = `rcm_permutation`; an int32 array [B, nJ_max] found earlier (e.g. on another thread) passes
+    through."""
     if isinstance(reorder, np.ndarray):
         if reorder.shape != (packed.B, packed.nJ_max):
             raise ValueError(f"joint order of shape {reorder.shape}, expected {(packed.B, packed.nJ_max)}")
@@ -868,9 +873,11 @@ def joint_order(packed: PackedBatch, reorder):
         return profile_permutation(packed, effort=1)
     if reorder == "rcm":
         return rcm_permutation(packed)
-    if reorder is True or reorder == "profile":
+    if reorder is True or reorder == "auto":
+        return profile_permutation(packed, effort=3)
+    if reorder == "profile":
         return profile_permutation(packed)
-    raise ValueError(f"unknown joint order {reorder!r} (True, 'profile', 'fast', 'rcm' or a permutation array)")
+    raise ValueError(f"unknown joint order {reorder!r} (True, 'auto', 'profile', 'fast', 'rcm' or a permutation array)")
 
 
 def permute_joints(packed: PackedBatch, perm):
@@ -1175,8 +1182,8 @@ class RaggedSolver:
         # one by one with tables sized by the bucket, so every bucket that fits is still ordered on the device
         # (unless the caller forced a host order or gave a permutation).
         self.device_effort = plan[1] if plan is not None and plan[0] == "device" else None
-        if plan is not None and plan[0] == "host" and (reorder is True or reorder in ("profile", "fast")):
-            self.device_effort = 1 if reorder == "fast" else 2
+        if plan is not None and plan[0] == "host" and (reorder is True or reorder in ("auto", "profile", "fast")):
+            self.device_effort = {"fast": 1, "profile": 2}.get(reorder, 3)
         self.ordered = None        # host plan: renumbered xyz / conn / cbits / loads + perm of the FULL batch
         if plan is not None and plan[0] != "device":
             # (found for the whole batch: the buckets that do not fit the device kernel take their rows from it)

@@ -36,6 +36,8 @@ constexpr int NWAVE = NT / 64;
 constexpr int ID_BITS = 13;                 // joint ids in the sort keys: nJ_max < 8192
 constexpr int PERMANENT = 0x40000000;       // visit stamp of a joint that has its final Cuthill-McKee number
 constexpr unsigned long long NO_COST = ~0ull;
+constexpr int RCM_BELOW = 128;              // effort 3: free joints below which the Cuthill-McKee candidates are still
+                                            // priced (= TRS_ORDER_RCM_BELOW of csrc/reorder.c)
 
 // LDS carve-up shared by host and device (byte offsets, 16-byte aligned parts)
 struct OrdLds {
@@ -434,6 +436,11 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     // the host's, and the bins must not depend on its last bits
     const double h = nlen ? (double)(float)(0.25 * sqrt(len2 / (double)nlen)) : 0.0;
     const bool sweeps = h > 0.0 && h < 1e300 && nf > 1 && effort >= 1;
+    // effort 3: on a larger lattice-like truss a coordinate sweep wins (bar-942; every cube truss from 140 cubes up),
+    // and Cuthill-McKee - three breadth-first sweeps with a barrier or four per level, plus the (degree, id) sort of
+    // the neighbour lists it needs - is 40 % of this kernel's time: its two candidates are priced for small trusses
+    // only, or where no sweep is possible.  Same rule as trs_profile_order (csrc/reorder.c).
+    const bool use_rcm = effort < 3 || nf < RCM_BELOW || !sweeps;
     const int bin_cap = 4 * nJ_max + 64;
     int nb[3] = {1, 1, 1};
     if (sweeps) {
@@ -479,14 +486,19 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     for_members([&](int a, int c) {
         if (a == c || t.nfr[a] == 0 || t.nfr[c] == 0) return;
         const int ea = t.start[a] + atomicAdd(&t.fill[a], 1), ec = t.start[c] + atomicAdd(&t.fill[c], 1);
-        t.adjU[ea] = ((unsigned)t.deg[c] << ID_BITS) | (unsigned)c;
-        t.adjU[ec] = ((unsigned)t.deg[a] << ID_BITS) | (unsigned)a;
+        if (use_rcm) {
+            t.adjU[ea] = ((unsigned)t.deg[c] << ID_BITS) | (unsigned)c;
+            t.adjU[ec] = ((unsigned)t.deg[a] << ID_BITS) | (unsigned)a;
+        } else {  // pricing needs the neighbours of a joint, in any order
+            t.adj[ea] = (unsigned short)c;
+            t.adj[ec] = (unsigned short)a;
+        }
     });
     __syncthreads();
     // neighbour lists by ascending (degree, id): rank of an entry inside its list (equal keys = parallel
     // members: interchangeable, ordered by position)
     // (four lanes share a joint's list: lane `sub` ranks the entries sub, sub + 4, ... - no table of an entry's owner)
-    for (int a = tid >> 2; a < nj; a += NT / 4) {
+    for (int a = tid >> 2; a < (use_rcm ? nj : 0); a += NT / 4) {
         const int s = t.start[a], d = t.deg[a];
         for (int e = s + (tid & 3); e < s + d; e += 4) {
             const unsigned key = t.adjU[e];
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     st.mark(0);
     // ---- phase A.1: Cuthill-McKee, component by component ---------------------------------------------------
     int n_order = 0, stamp = 1;
-    for (;;) {
+    while (use_rcm) {
         unsigned best = 0xffffffffu;  // minimum-degree unvisited free joint, smallest id first
         for (int j = tid; j < nj; j += NT)
             if (t.nfr[j] != 0 && t.lvl[j] == 0) best = min(best, ((unsigned)t.deg[j] << ID_BITS) | (unsigned)j);
@@ -577,11 +589,11 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
         }
     };
     if (nf > 0) {
-        if (wave == (n_sweep > 1 ? 2 : 0)) {  // reverse Cuthill-McKee
+        if (use_rcm && wave == (n_sweep > 1 ? 2 : 0)) {  // reverse Cuthill-McKee
             auto ord = [&](int k) { return t.order[nf - 1 - k]; };
             consider(price_order(t, nf, ord, newidx, c01, cmin, lane, &ndof), 0, 0, ord);
         }
-        if (wave == (n_sweep > 1 ? 3 : 1)) {  // plain Cuthill-McKee
+        if (use_rcm && wave == (n_sweep > 1 ? 3 : 1)) {  // plain Cuthill-McKee
             auto ord = [&](int k) { return t.order[k]; };
             consider(price_order(t, nf, ord, newidx, c01, cmin, lane, &ndof), 1, 1, ord);
         }

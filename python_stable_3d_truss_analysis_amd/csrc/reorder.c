@@ -236,6 +236,7 @@ static void counting_pass(const int *ids, int *out, int n, const int *key, int s
 
 /* perm: [B][nJ_max] as trs_rcm_order; choice (may be NULL): [B] winning candidate - 0 RCM, 1 its reverse,
  * 2 + 2 p + r the sweep with axis order p (0..5: xyz xzy yxz yzx zxy zyx, first axis slowest), r = 1 backwards */
+#define TRS_ORDER_RCM_BELOW 128   /* effort 3: free joints below which the Cuthill-McKee candidates are still priced */
 int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const int32_t *conn,
                       const uint8_t *cbits, const int32_t *nJ, const int32_t *nM, int32_t *perm,
                       int32_t *choice, int effort) {
@@ -273,16 +274,6 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
             int nf = 0; /* joints with a free DOF: they come first in every candidate, the others keep RCM's tail */
             for (int j = 0; j < nj; ++j) nf += (cb[j] & 7) != 7;
             for (int k = 0; k < nj; ++k) p[k] = rcm[k];
-            for (int k = 0; k < nf; ++k) cand[k] = rcm[k];
-            double best = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin, 1e300);
-            int best_id = 0;
-            /* candidate 1: plain Cuthill-McKee (RCM backwards) */
-            for (int k = 0; k < nf; ++k) cand[k] = rcm[nf - 1 - k];
-            double c = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin, best);
-            if (c < best) {
-                best = c; best_id = 1;
-                for (int k = 0; k < nf; ++k) p[k] = cand[k];
-            }
             /* coordinate bins: a quarter of the mean member length */
             double len2 = 0.0; /* root mean square member length (one square root per truss) */
             int nlen = 0;
@@ -295,7 +286,26 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
             /* rounded to single precision: the device version (order.hip) sums the squares in another order,
              * and the bins - hence the permutation - must not depend on the last bits of that sum */
             const double h = nlen ? (double)(float)(0.25 * __builtin_sqrt(len2 / nlen)) : 0.0;
-            if (h > 0.0 && h < 1e300 && nf > 1) {
+            const int sweeps = h > 0.0 && h < 1e300 && nf > 1 && effort >= 1;
+            /* effort 3: the Cuthill-McKee candidates are priced for SMALL trusses only (fewer than
+             * TRS_ORDER_RCM_BELOW free joints) or where no sweep is possible: on larger lattice-like trusses a sweep
+             * wins (bar-942; every cube truss from 140 cubes up, 97 % of those from 80) and Cuthill-McKee - three
+             * breadth-first sweeps - is 40 % of the device kernel's time.  The same rule in csrc/order.hip. */
+            const int use_rcm = effort < 3 || nf < TRS_ORDER_RCM_BELOW || !sweeps;
+            double best = 1e300, c;
+            int best_id = 0;
+            if (use_rcm) {
+                for (int k = 0; k < nf; ++k) cand[k] = rcm[k];
+                best = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin, 1e300);
+                /* candidate 1: plain Cuthill-McKee (RCM backwards) */
+                for (int k = 0; k < nf; ++k) cand[k] = rcm[nf - 1 - k];
+                c = envelope_cost(&sc, nf, cb, cand, newidx, c0, c1, cmin, best);
+                if (c < best) {
+                    best = c; best_id = 1;
+                    for (int k = 0; k < nf; ++k) p[k] = cand[k];
+                }
+            }
+            if (sweeps) {
                 int nb[3];
                 for (int a = 0; a < 3; ++a) {
                     double lo = X[a], hi = X[a];

@@ -53,7 +53,7 @@ def _stored_tiles(gpu, packed):
     return np.array([int((cend[b, :nch[b]] - np.arange(nch[b])).sum()) for b in range(packed.B)])
 
 
-@pytest.mark.parametrize("effort", [2, 1, 0])
+@pytest.mark.parametrize("effort", [3, 2, 1, 0])
 def test_device_order_reproduces_the_host_profile_order(gpu, effort):
     for name, packed in _fixture_batches(gpu).items():
         got = _device_order(gpu, packed, effort)
@@ -91,7 +91,8 @@ def test_solves_under_the_device_order_match_goldens_in_the_callers_numbering(gp
     z = H.dense_golden()
     golds = [{k: z[f"{nm}/{k}"] for k in ("u", "f_ext", "N")} for nm in names] + [g for _, _, g in H.ragged_cube_cases()]
     packed = gpu.pack_json(datas)
-    assert gpu.order_plan(True, packed.nJ_max, packed.nM_max) == ("device", 2)
+    assert gpu.order_plan(True, packed.nJ_max, packed.nM_max) == ("device", 3)
+    assert gpu.order_plan("profile", packed.nJ_max, packed.nM_max) == ("device", 2)
     plain = gpu.solve_batch(packed)
     for how in ("solve_batch", "resident"):
         if how == "solve_batch":
@@ -142,7 +143,7 @@ def test_device_order_edge_cases(gpu):
     lib = gpu._capi.load()
     assert lib.trs_joint_order_fits(343, 2100) == 1 and lib.trs_joint_order_fits(8192, 100) == 0
     assert lib.trs_joint_order_fits(4000, 60000) == 0
-    assert gpu.order_plan(True, 9000, 100) == ("host", "profile")
+    assert gpu.order_plan(True, 9000, 100) == ("host", "auto") and gpu.order_plan("profile", 9000, 100) == ("host", "profile")
     with pytest.raises(ValueError):
         gpu.order_plan("device", 9000, 100)
 
@@ -191,7 +192,7 @@ def test_ragged_solver_matches_solve_batch_bitwise(gpu):
             np.testing.assert_array_equal(np.nan_to_num(got.displace, nan=0.0), want.displace)
             if attempt == 0:
                 solver.adopt_launch_hints()
-        host = gpu.RaggedSolver(packed, reorder="host-profile")
+        host = gpu.RaggedSolver(packed, reorder="host-auto")     # the same plan (effort 3) carried out on the host
         host.step()
         np.testing.assert_array_equal(host.result().displace, want.displace)
         plain = gpu.RaggedSolver(packed, reorder=False)
@@ -420,7 +421,7 @@ def _random_trusses(rng, count):
 def test_device_order_on_irregular_trusses_with_every_support_kind(gpu):
     rng = np.random.default_rng(42)
     packed = gpu.pack_json(_random_trusses(rng, 400))
-    for effort in (2, 1, 0):
+    for effort in (3, 2, 1, 0):
         got = _device_order(gpu, packed, effort)
         perm, choice = gpu.profile_permutation(packed, return_choice=True, effort=effort)
         np.testing.assert_array_equal(got["choice"], choice)

@@ -325,7 +325,13 @@ def test_profile_order_is_valid_never_worse_than_rcm_and_cheaper_on_cube_trusses
     costs = [sum(_envelope_cost(p, b, batch.profile_permutation(p, effort=e)[b])[0] for b in range(12)) for e in (0, 1, 2)]
     assert costs[2] <= costs[1] <= costs[0]
     np.testing.assert_array_equal(batch.joint_order(p, "fast"), batch.profile_permutation(p, effort=1))
-    np.testing.assert_array_equal(batch.joint_order(p, True), perm)   # True = every candidate, as order_plan(True)
+    # True = "auto" (effort 3), as order_plan(True): every sweep, the Cuthill-McKee pair only below 128 free joints -
+    # never cheaper than all candidates, within a few per cent of them on cube trusses
+    auto = batch.profile_permutation(p, effort=3)
+    np.testing.assert_array_equal(batch.joint_order(p, True), auto)
+    np.testing.assert_array_equal(batch.joint_order(p, "auto"), auto)
+    cost3 = sum(_envelope_cost(p, b, auto[b])[0] for b in range(12))
+    assert costs[2] <= cost3 <= 1.05 * costs[2]
     np.testing.assert_array_equal(batch.joint_order(p, "profile"), perm)
     np.testing.assert_array_equal(batch.joint_order(p, perm), perm)
     with pytest.raises(ValueError):
