@@ -272,6 +272,8 @@ int trs_graph_features_packed(int B, int nJ_max, int nM_max, const double *xyz, 
  *                       RCM and its reverse only for trusses with fewer than 128 free joints or without a usable
  *                       sweep (on larger lattice-like trusses a sweep wins and Cuthill-McKee is 40 % of the kernel's
  *                       time; +0.2 % stored tiles over 2048 mixed cube trusses)
+ *                       At effort 3 a truss of 128 or more free joints WITHOUT a usable sweep (all members of length
+ *                       zero, coordinates that are not numbers) keeps its free joints in the given order (choice 14).
  * trs_joint_order_fits says whether a batch shape can be ordered on the device (tables within a CU's LDS,
  * nJ_max < 8192); trs_joint_order returns hipErrorInvalidValue for a shape that cannot (callers then use the host
  * version). */

@@ -834,6 +834,7 @@ NARROW_MAX_BELOW = 24   # csrc/trs_common.h TRS_NARROW_MAX_BELOW: reach up to wh
 # include/trs_solver.h
 HINT_NO_WIDE, HINT_SUBSTITUTED, HINT_COMPACT, HINT_SEPARATE_STAGES, HINT_NO_SMALL, HINT_RECOVER_UNSTAGED = 1, 2, 4, 8, 16, 32
 HINT_ALL_TILES = 64
+ORDER_RCM_BELOW = 128           # csrc/order.hip RCM_BELOW: effort 3 prices Cuthill-McKee below this many free joints
 ASM_FULL_SYMMETRIC, ASM_COMPACT, ASM_ALL_NARROW, ASM_ALL_TILES = 1, 2, 4, 8
 
 
@@ -1386,8 +1387,8 @@ class RaggedSolver:
                             inp["cbits"].data_ptr(), inp["loads"].data_ptr(), inp["E"].data_ptr(), inp["A"].data_ptr(),
                             inp["nJ"].data_ptr(), inp["nM"].data_ptr(), ordr["perm"].data_ptr(), ordr["reach"].data_ptr(),
                             db.xyz.data_ptr(), db.conn.data_ptr(), db.cbits.data_ptr(), db.loads.data_ptr(),
-                            db.E.data_ptr(), db.A.data_ptr(), db.nJ.data_ptr(), db.nM.data_ptr(), int(self.device_effort),
-                            stream), "trs_joint_order_rows"))
+                            db.E.data_ptr(), db.A.data_ptr(), db.nJ.data_ptr(), db.nM.data_ptr(),
+                            int(self.device_effort), stream), "trs_joint_order_rows"))
                         for slot in slots:
                             if sections[slot] is not None:
                                 db.A.fill_(float(sections[slot][0]))

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     // Every global READ of the search happens here, coalesced and issued together: the coordinates go to an LDS
     // stage (in the space the adjacency fill will take over later), the members' end joints are kept in
     // registers for the two passes that need them.
-    double* Xs = reinterpret_cast<double*>(lds + lay.adjU);  // [3 nJ_max] staged coordinates (dead before the fill)
+    double* Xs = reinterpret_cast<double*>(lds + lay.keys);  // [3 nJ_max] staged coordinates, in the shared region (dead before the fill)
     constexpr int MR = 8;
     int2 cr[MR];
     const int2* CNI = reinterpret_cast<const int2*>(CN);
@@ -440,7 +440,9 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     // and Cuthill-McKee - three breadth-first sweeps with a barrier or four per level, plus the (degree, id) sort of
     // the neighbour lists it needs - is 40 % of this kernel's time: its two candidates are priced for small trusses
     // only, or where no sweep is possible.  Same rule as trs_profile_order (csrc/reorder.c).
-    const bool use_rcm = effort < 3 || nf < RCM_BELOW || !sweeps;
+    // A truss the rule keeps away from Cuthill-McKee that has no usable sweep either (all members of length zero,
+    // coordinates that are not numbers) keeps its free joints in the given order.
+    const bool use_rcm = effort < 3 || nf < RCM_BELOW;
     const int bin_cap = 4 * nJ_max + 64;
     int nb[3] = {1, 1, 1};
     if (sweeps) {
@@ -589,6 +591,10 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
         }
     };
     if (nf > 0) {
+        if (!use_rcm && !sweeps && wave == 0) {  // nothing to choose from: the free joints by ascending id
+            auto ord = [&](int k) { return (int)t.ids[k]; };
+            consider(price_order(t, nf, ord, newidx, c01, cmin, lane, &ndof), 0, 14, ord);
+        }
         if (use_rcm && wave == (n_sweep > 1 ? 2 : 0)) {  // reverse Cuthill-McKee
             auto ord = [&](int k) { return t.order[nf - 1 - k]; };
             consider(price_order(t, nf, ord, newidx, c01, cmin, lane, &ndof), 0, 0, ord);
@@ -814,14 +820,19 @@ extern "C" int trs_joint_order_launch(int B, int nJ_max, int nM_max, const doubl
                                       const double* A_in, double* E_out, double* A_out, int* nJ_out, int* nM_out) {
     if (B <= 0) return 0;
     if (!trs_joint_order_fits(nJ_max, nM_max)) return (int)hipErrorInvalidValue;
-    static const int lds_limit_set = (int)hipFuncSetAttribute(   // once per process, not per launch
-        reinterpret_cast<const void*>(trs_joint_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)lds_limit_set;
+    const size_t lds = ord_layout(nJ_max, nM_max).total
 #ifdef TRS_EXP_ORDER_IDLE_LDS   // occupancy experiment: LDS nobody uses, fewer work-groups per CU
-    const size_t lds = ord_layout(nJ_max, nM_max).total + TRS_EXP_ORDER_IDLE_LDS;
-#else
-    const size_t lds = ord_layout(nJ_max, nM_max).total;
+                       + TRS_EXP_ORDER_IDLE_LDS
 #endif
+        ;
+    // The dynamic-LDS ceiling of the kernel is raised only when a launch needs more than the default 64 KB, once per
+    // process (cube trusses: 25-39 KB; only shapes beyond ~500 joints get here).  Raising it for every kernel of the
+    // library up front made the host-fed pipeline's CU-masked streams fault on this runtime (EXPERIMENTS R4.7).
+    if (lds > 64 * 1024) {
+        static const int raised = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_joint_order_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)raised;
+    }
     hipLaunchKernelGGL(trs_joint_order_kernel, dim3(B), dim3(NT), lds, stream, xyz, conn, cbits, loads, nJ, nM, nJ_max,
                        nM_max, perm, choice, reach, xyz_out, conn_out, cbits_out, loads_out, effort, rows, nJ_in, nM_in,
                        E_in, A_in, E_out, A_out, nJ_out, nM_out);

@@ -288,10 +288,10 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
             const double h = nlen ? (double)(float)(0.25 * __builtin_sqrt(len2 / nlen)) : 0.0;
             const int sweeps = h > 0.0 && h < 1e300 && nf > 1 && effort >= 1;
             /* effort 3: the Cuthill-McKee candidates are priced for SMALL trusses only (fewer than
-             * TRS_ORDER_RCM_BELOW free joints) or where no sweep is possible: on larger lattice-like trusses a sweep
+             * TRS_ORDER_RCM_BELOW free joints): on larger lattice-like trusses a sweep
              * wins (bar-942; every cube truss from 140 cubes up, 97 % of those from 80) and Cuthill-McKee - three
              * breadth-first sweeps - is 40 % of the device kernel's time.  The same rule in csrc/order.hip. */
-            const int use_rcm = effort < 3 || nf < TRS_ORDER_RCM_BELOW || !sweeps;
+            const int use_rcm = effort < 3 || nf < TRS_ORDER_RCM_BELOW;
             double best = 1e300, c;
             int best_id = 0;
             if (use_rcm) {
@@ -304,6 +304,12 @@ int trs_profile_order(int B, int nJ_max, int nM_max, const double *xyz, const in
                     best = c; best_id = 1;
                     for (int k = 0; k < nf; ++k) p[k] = cand[k];
                 }
+            }
+            if (!use_rcm && !sweeps) { /* nothing to choose from: the free joints in the given order (choice 14) */
+                int nk = 0;
+                for (int j = 0; j < nj; ++j)
+                    if ((cb[j] & 7) != 7) p[nk++] = j;
+                best_id = 14;
             }
             if (sweeps) {
                 int nb[3];

@@ -430,3 +430,27 @@ def test_device_order_on_irregular_trusses_with_every_support_kind(gpu):
         want = gpu.permute_joints(packed, perm)
         for field in ("xyz", "conn", "cbits", "loads"):
             np.testing.assert_array_equal(got[field], getattr(want, field), err_msg=field)
+
+
+def test_effort_3_on_large_and_degenerate_trusses(gpu):
+    """Effort 3 on trusses that all have at least 128 free joints (no Cuthill-McKee candidate is priced): the
+    permutations, choices, reaches and renumbered arrays of the host's effort 3; a truss without a usable sweep
+    (coordinates that are not numbers, every member of length zero) keeps its free joints in the given order on both
+    sides (choice 14)."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    rng = np.random.default_rng(4)
+    packed = gen.generate_cube_batch(rng.integers(120, 191, size=96), gridRange=(6, 6, 6), seed=31)
+    assert int(packed.n_free.min()) >= 3 * gpu.ORDER_RCM_BELOW
+    broken = packed.take(np.arange(4))
+    broken.xyz[1] = np.nan                          # no bin width: no sweep
+    broken.xyz[2, :, :] = broken.xyz[2, 0, :]       # every member of length zero
+    for batch_ in (packed, broken):
+        got = _device_order(gpu, batch_, 3)
+        perm, choice = gpu.profile_permutation(batch_, return_choice=True, effort=3)
+        np.testing.assert_array_equal(got["perm"], perm)
+        np.testing.assert_array_equal(got["choice"], choice)
+        np.testing.assert_array_equal(got["reach"], gpu.envelope_reach(batch_, perm))
+        assert (choice >= 2).all()                  # never the Cuthill-McKee pair
+    assert choice[1] == 14 and choice[2] == 14 and choice[0] < 14
+    free = [j for j in range(int(broken.nJ[1])) if broken.cbits[1, j] & 7 != 7]
+    assert perm[1, :len(free)].tolist() == free
