@@ -10,7 +10,7 @@ set -u
 TAG=${1:-r04}
 export TMPDIR=/tmp
 OUT=gpurun_out
-tools/profile_pmc.sh ${TAG}_pmc > $OUT/${TAG}_pmc_files.log 2>&1
+timeout 900 tools/profile_pmc.sh ${TAG}_pmc > $OUT/${TAG}_pmc_files.log 2>&1
 python3 tools/summarize_pmc.py $OUT/${TAG}_pmc $OUT/${TAG}_pmc_summary.json > $OUT/${TAG}_sum.log 2>&1
 find $OUT/${TAG}_pmc/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
 python3 - "$OUT/${TAG}_pmc_summary.json" "$OUT/${TAG}_potrf_traffic.json" <<'PY' > $OUT/${TAG}_traffic.log 2>&1
@@ -21,9 +21,9 @@ os.makedirs("profiles", exist_ok=True)
 m.main(sys.argv[1], "trs_potrf_narrow_kernel<false, 2>", 4096, "profile")
 shutil.copy("profiles/potrf_traffic.json", sys.argv[2])
 PY
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cube_stats -- python3 tools/cube_step.py > $OUT/${TAG}_cube_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cube_stats -- python3 tools/cube_step.py > $OUT/${TAG}_cube_stats.log 2>&1
 find $OUT/${TAG}_cube_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_cube_kernel_stats.csv
-tools/cube_pmc.sh ${TAG}_cubepmc > /dev/null 2>&1
+timeout 600 tools/cube_pmc.sh ${TAG}_cubepmc > /dev/null 2>&1
 cp $OUT/${TAG}_cubepmc/cube_pmc.txt $OUT/${TAG}_cube_pmc.txt
-python3 bench.py > $OUT/${TAG}_bench.json.log 2> $OUT/${TAG}_bench.err
+timeout 900 python3 bench.py > $OUT/${TAG}_bench.json.log 2> $OUT/${TAG}_bench.err
 ls -la $OUT/${TAG}_*.csv $OUT/${TAG}_*.json $OUT/${TAG}_*.txt $OUT/${TAG}_*.log 2>/dev/null | awk '{print $5, $9}'
