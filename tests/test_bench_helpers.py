@@ -83,3 +83,19 @@ def test_available_cpus_respects_affinity_and_is_positive():
     if hasattr(os, "sched_getaffinity"):
         assert n <= len(os.sched_getaffinity(0))
     assert generate._load().trs_host_threads(0) >= 1
+
+
+def test_cube_cpu_baseline_runs_on_a_fixed_sample_of_the_legs_batch():
+    """`bench.cube_cpu_baseline` (north-star: the CPU baseline beside the cube-truss line): a fixed sample of the leg's own
+    batch from the native host generator, solved by the oracle; the record and the checker's vectors."""
+    import numpy as np
+    idx = bench.cube_sample_indices(65536)
+    assert len(idx) == 64 and idx[0] == 0 and idx[-1] == 65535 and (np.diff(idx) > 0).all()
+    assert bench.cube_sample_indices(10).tolist() == list(range(10))
+    rec, refs = bench.cube_cpu_baseline(48, seconds=0.2, pool_too=False)
+    assert rec["kind"] == "port" and rec["cores"] == 1 and rec["unit"] == "solves/s" and rec["value"] > 0
+    assert sorted(refs) == bench.cube_sample_indices(48).tolist()
+    ratio = rec["reference_speed_ratio"]
+    assert ratio is not None and 0.8 < ratio["ratio"] < 1.25      # the committed calibration against the real reference
+    one = refs[0]
+    assert one["u"].ndim == 2 and one["u"].shape[1] == 3 and np.isfinite(one["u"]).all() and np.abs(one["N"]).max() > 0
