@@ -376,7 +376,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 wgflag[2] = (narrow && uf_all != nullptr && widest <= TRS_NARROW_MAX_BELOW && !full && (flags & TRS_ASM_ALL_TILES) == 0) ? 1 : 0;
 #endif
             }
-            int empty = 0, stored_tiles = 0;
+            int empty = 0, stored_tiles = 0, front = 0;
             for (int t = tid; t < nch; t += 64) {  // t | 3 lies in the same step: reads precede the writes
                 const int e = narrow ? max(cendl[t] + 1, (t | 3) + 1) : cendl[t | 3] + 1 + (TRS_WIDE_ITEM - 1);
                 __builtin_amdgcn_wave_barrier();
@@ -384,13 +384,24 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 cend[t] = min(nch, e);
                 const int w = min(nch, e) - t;
                 stored_tiles += w;
+                front = max(front, w);   // (read by experiment builds only: TRS_EXP_WINDOW)
                 empty += w - __popc(kmask[t] & (w >= 32 ? 0xffffffffu : ((1u << w) - 1u)));
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 empty += __shfl_xor(empty, off);
                 stored_tiles += __shfl_xor(stored_tiles, off);
+                front = max(front, __shfl_xor(front, off));
             }
+#ifdef TRS_EXP_WINDOW
+            // the work-group kernel with the window in LDS takes the matrix (trs_common.h, TRS_ENV_WINDOW)
+            if (tid == 0 && narrow && !compact && uf_all != nullptr && widest <= TRS_NARROW_MAX_BELOW && !full &&
+                front <= TRS_WINDOW_MAX_FRONT && front > TRS_EXP_WINDOW_ABOVE && 16 * nch <= 1024) {
+                int* meta = env + n_pad_max / 16 + n_pad_max / 64;
+                meta[0] |= TRS_ENV_WINDOW;
+                meta[5] = front;
+            }
+#endif
             // skipping pays only when enough tiles are skipped (the row loop tests a bit per 16 bytes stored):
             // a tower-like truss (bar-942: 6 of 158 tiles without an entry) keeps every tile
             const bool worth = 8 * empty >= stored_tiles;

@@ -781,6 +781,9 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
     const TrsEnv env = trs_env_of(env_all, b, n_pad_max);
     if (!trs_env_is_narrow(env) || trs_env_is_compact(env) != FUSED) return;  // another kernel's matrix
     if (!FUSED && trs_env_is_rs4(env) != (RSV > 2)) return;                   // the other item size's matrix
+#ifdef TRS_EXP_WINDOW
+    if (trs_env_is_window(env)) return;                                      // trs_potrf_window_kernel's matrix
+#endif
     Slab S;
     S.rs = __builtin_amdgcn_make_buffer_rsrc(S_all + (size_t)b * slab_stride, 0,
                                              (int)(slab_stride * sizeof(double)), 0x00020000);
@@ -1053,6 +1056,10 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
     st.flush();
 }
 
+#ifdef TRS_EXP_WINDOW   // (experiment builds only - EXPERIMENTS R4.8: measured slower, not part of the product)
+#include "trs_window.h"
+#endif
+
 }  // namespace
 
 #ifdef TRS_POTRF_STAMPS
@@ -1089,6 +1096,22 @@ extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_st
         hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 2>), grid, block, 0, stream, S, n_free, ld, slab_stride,
                            info, env, n_pad_max, B, wk, uf, ld_uf, fused_substitution);
         if ((rc = (int)hipGetLastError())) return rc;
+#ifdef TRS_EXP_WINDOW
+        if (n_pad_max <= 1024) {
+            const int M = TRS_WINDOW_MAX_FRONT;
+            const size_t lds = trs_window_lds_bytes(M, n_pad_max);
+            static int raised = 0;
+            if (!raised) {
+                if ((rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrf_window_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024)))
+                    return rc;
+                raised = 1;
+            }
+            hipLaunchKernelGGL(trs_potrf_window_kernel, dim3(B), dim3(64 * WINW), lds, stream, S, n_free, ld, slab_stride,
+                               info, env, n_pad_max, B, uf, ld_uf, M, 0);
+            if ((rc = (int)hipGetLastError())) return rc;
+        }
+#endif
         if (TRS_NARROW_RS4_ABOVE <= TRS_NARROW_MAX_BELOW) {  // (compile-time: see trs_common.h)
             hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 4>), grid, block, 0, stream, S, n_free, ld, slab_stride,
                                info, env, n_pad_max, B, wk, uf, ld_uf, fused_substitution);

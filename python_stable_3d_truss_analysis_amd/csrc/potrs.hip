@@ -242,8 +242,10 @@ extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_st
     // (and the slab fits the 31-bit offsets of a buffer descriptor, as in trs_potrf_batched)
     const size_t lds_narrow = (size_t)PMW * n_pad_max * sizeof(double);
     const int narrow = env != nullptr && lds_narrow <= 64 * 1024 && slab_stride * sizeof(double) < ((size_t)1 << 31);
+#ifndef TRS_EXP_WINDOW   // (the window kernel leaves the substitution to this launch)
     if (narrow && (hints & TRS_HINT_SUBSTITUTED) != 0 && (hints & TRS_HINT_NO_WIDE) != 0 && n_pad_max <= 1024)
         return 0;  // every matrix was substituted by the wave that factored it
+#endif
     if (narrow) {
         hipLaunchKernelGGL(trs_potrs_narrow_kernel, dim3((B + PMW - 1) / PMW), dim3(64 * PMW), lds_narrow, stream, S,
                            n_free, ld, slab_stride, uf, ld_uf, env, n_pad_max, B);
