@@ -581,7 +581,7 @@ def ga_leg(device, torch):
             state = random.getstate()
             random.seed(1)
             run = GA(truss, types, nIteration=gens, nPatience=10 ** 6, nPop=1024, nElite=256)
-            run._device, run._typeTable = ga._device, ga._typeTable    # (the resident population batch, built above)
+            run._adopt_population(ga)    # (the resident population batch, built above)
             t0 = time.perf_counter()
             _, info, _, history = run.Evolve(isPrintMessage=False, native=native)
             wall = time.perf_counter() - t0

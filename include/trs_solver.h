@@ -188,6 +188,15 @@ int trs_recover_rows(int B, int nJ_max, int nM_max, const double *xyz, const int
                      const int32_t *info, const int64_t *out_rows, int nJ_out_max, int nM_out_max, double *u,
                      double *f_ext, double *N, int32_t *info_out, int hints, void *stream);
 
+/* Member sections of a GA population from its gene matrix (ABI 9; ga.py:125-137 `TranslateGene` /
+ * `SetMemberTypesByGene`: locus i of a gene selects the type of member i): for individual b < count and member
+ * m < n_member   (A, E, rho)[b][m] = type_table[genes[b][m]]   (type_table [n_type][3] = a, e, density, device;
+ * genes uint8 [count][n_member], device); rows b >= count and members m >= n_member of the padded arrays get type 0
+ * (solved and ignored); a locus >= n_type gives NaN sections, which the solve reports in info.  One launch in
+ * place of the gather + three strided copies of a tensor library. */
+int trs_ga_sections(int B, int nM_max, int count, int n_member, int n_type /* 1..256 */, const uint8_t *genes,
+                    const double *type_table, double *A /* [B][nM_max] */, double *E, double *rho, void *stream);
+
 /* Constraint reductions of the GA fitness (truss.py:166-168,429-462; ga.py:139-149):
  *   weight[b]   = sum_m A*L*rho
  *   stress_vio[b] = sum_m max(|N|/A - allow_stress, 0) over members with |N| >= 1e-10

@@ -27,6 +27,7 @@ SIGNATURES = {
     "trs_potrf_batched": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "trs_potrs_batched": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _I, _P]),
     "trs_recover": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "trs_ga_sections": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "trs_fitness": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _D, _D, _P, _P, _P, _P]),
     "trs_solve_small_fits": (_I, [_I, _I, _I]),
     "trs_solve_small": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,

@@ -563,12 +563,14 @@ class DeviceBatch:
                 (HINT_ALL_TILES if self.all_tiles and self.env is not None else 0),
                 self._stream()), "trs_solve_rows")
 
-    def _solve_small(self, fitness=None):
+    def _solve_small(self, fitness=None, out=None):
         """`trs_solve_small`: the whole of `Truss.Solve()` in one kernel (optionally with the GA
-        reductions); returns the three reduction tensors or None."""
+        reductions); returns the three reduction tensors (`out`, three float64 [B] device tensors, or new ones) or
+        None."""
         t = self.torch
-        out = [None, None, None]
-        if fitness is not None:
+        if fitness is None:
+            out = [None, None, None]
+        elif out is None:
             out = [t.empty([self.B], dtype=t.float64, device=self.device) for _ in range(3)]
         ptr = lambda x: None if x is None else x.data_ptr()
         with t.cuda.device(self.device):
@@ -582,13 +584,21 @@ class DeviceBatch:
                 ptr(out[0]), ptr(out[1]), ptr(out[2]), self._stream()), "trs_solve_small")
         return out if fitness is not None else None
 
-    def solve_fitness(self, allow_stress, allow_displace):
+    def solve_fitness(self, allow_stress, allow_displace, out=None):
         """Solve and reduce to (weight, stress_violation, displacement_violation) per truss - one kernel
-        on the fused small path, `solve()` + `fitness()` otherwise (GA generation, ga.py:139-160)."""
+        on the fused small path, `solve()` + `fitness()` otherwise (GA generation, ga.py:139-160).  `out`: three
+        float64 [B] device tensors to write into (e.g. the rows of one [3, B] tensor: one download)."""
         if self.small:
-            return self._solve_small((allow_stress, allow_displace))
+            return self._solve_small((allow_stress, allow_displace), out)
         self.solve()
-        return self.fitness(allow_stress, allow_displace)
+        return self.fitness(allow_stress, allow_displace, out)
+
+    def set_sections_from_genes(self, genes, count, n_member, type_table):
+        """`trs_ga_sections`: A, E, rho of the resident batch from a GA population's gene matrix (uint8 device tensor
+        [count, n_member]) and its type table (float64 device tensor [n_type, 3] = a, e, density)."""
+        _capi.check(self.lib.trs_ga_sections(self.B, self.nM_max, int(count), int(n_member), int(type_table.shape[0]),
+                                             genes.data_ptr(), type_table.data_ptr(), self.A.data_ptr(),
+                                             self.E.data_ptr(), self.rho.data_ptr(), self._stream()), "trs_ga_sections")
 
     def solve(self):
         """The whole pipeline, asynchronous on the current stream: one kernel for a batch of small
@@ -610,10 +620,11 @@ class DeviceBatch:
                 (HINT_ALL_TILES if self.all_tiles and self.env is not None else 0),
                 self._stream()), "trs_solve")
 
-    def fitness(self, allow_stress, allow_displace):
+    def fitness(self, allow_stress, allow_displace, out=None):
         """(weight, stress_violation, displacement_violation) per truss, on device."""
         t = self.torch
-        out = [t.empty([self.B], dtype=t.float64, device=self.device) for _ in range(3)]
+        if out is None:
+            out = [t.empty([self.B], dtype=t.float64, device=self.device) for _ in range(3)]
         _capi.check(self.lib.trs_fitness(
             self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
             self.A.data_ptr(), self.rho.data_ptr(), self.nJ.data_ptr(), self.nM.data_ptr(),

@@ -30,6 +30,8 @@ int trs_solve_small_launch(int, int, int, int, const double*, const int*, const 
                            const uint8_t*, const double*, const int*, const int*, double*, double*, double*,
                            int*, int*, int*, const double*, double, double, double*, double*, double*,
                            hipStream_t);
+int trs_ga_sections_launch(int, int, int, int, int, const unsigned char*, const double*, double*, double*, double*,
+                           hipStream_t);
 int trs_fitness_launch(int, int, int, const double*, const int*, const double*, const double*,
                        const int*, const int*, const double*, const double*, double, double, double*,
                        double*, double*, hipStream_t);
@@ -130,6 +132,13 @@ int trs_fitness(int B, int nJ_max, int nM_max, const double* xyz, const int32_t*
     if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
     return trs_fitness_launch(B, nJ_max, nM_max, xyz, conn, A, rho, nJ, nM, u, N, allow_stress,
                               allow_displace, weight, stress_vio, disp_vio, (hipStream_t)stream);
+}
+
+int trs_ga_sections(int B, int nM_max, int count, int n_member, int n_type, const uint8_t* genes,
+                    const double* type_table, double* A, double* E, double* rho, void* stream) {
+    if (B < 0 || nM_max < 0 || count < 0 || count > B || n_member < 0 || n_member > nM_max || n_type < 1 || n_type > 256)
+        return (int)hipErrorInvalidValue;
+    return trs_ga_sections_launch(B, nM_max, count, n_member, n_type, genes, type_table, A, E, rho, (hipStream_t)stream);
 }
 
 int trs_cubegen_dev(int B, uint64_t seed, int gx, int gy, int gz, const int32_t* num_cubes, int method, int link_type,

@@ -257,6 +257,33 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
     return (int)hipGetLastError();
 }
 
+// Member sections of a GA population from its gene matrix (ga.py:125-137: locus i of a gene is the type of member i):
+// one thread per (individual, member) of the padded arrays; rows past `count` and members past `n_member` get type 0
+// (they are solved and ignored), a locus outside the table NaN sections (the solve then reports the individual).
+__global__ __launch_bounds__(256) void trs_ga_sections_kernel(
+    const unsigned char* __restrict__ genes, const double* __restrict__ table, const int count, const int n_member,
+    const int n_type, const int nM_max, const long long total, double* __restrict__ A, double* __restrict__ E,
+    double* __restrict__ rho) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / nM_max), m = (int)(i - (long long)b * nM_max);
+    const int type = (b < count && m < n_member) ? (int)genes[(size_t)b * n_member + m] : 0;
+    const bool ok = type < n_type;
+    const double nan = __builtin_nan("");
+    A[i] = ok ? table[3 * type] : nan;
+    E[i] = ok ? table[3 * type + 1] : nan;
+    rho[i] = ok ? table[3 * type + 2] : nan;
+}
+
+extern "C" int trs_ga_sections_launch(int B, int nM_max, int count, int n_member, int n_type, const unsigned char* genes,
+                                      const double* table, double* A, double* E, double* rho, hipStream_t stream) {
+    const long long total = (long long)B * nM_max;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(trs_ga_sections_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, genes, table,
+                       count, n_member, n_type, nM_max, total, A, E, rho);
+    return (int)hipGetLastError();
+}
+
 extern "C" int trs_fitness_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
                                   const double* A, const double* rho, const int* nJ, const int* nM,
                                   const double* u, const double* N, double allow_stress,

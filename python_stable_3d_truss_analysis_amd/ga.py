@@ -125,32 +125,65 @@ class GA:
         if self._device is None or self._device.B < count:
             import torch
             base = pack_trusses([self.truss])
-            self._device = DeviceBatch(base.replicate(max(count, self.nPop)))
+            dev = self._device = DeviceBatch(base.replicate(max(count, self.nPop)))
             table = np.array([[t.a, t.e, t.density] for t in self.typeList], dtype=np.float64)
-            self._typeTable = torch.from_numpy(table).to(self._device.device)
+            self._typeTable = torch.from_numpy(table).to(dev.device)
+            # a generation's traffic: the gene matrix up, three reductions + the status down - page-locked staging
+            # on both sides, so that the call is two kernels between two asynchronous copies and ONE wait
+            self._genesHost = torch.empty([dev.B, self.nMember], dtype=torch.uint8).pin_memory()
+            self._genesDev = torch.empty([dev.B, self.nMember], dtype=torch.uint8, device=dev.device)
+            self._fitDev = torch.empty([3, dev.B], dtype=torch.float64, device=dev.device)
+            self._fitHost = torch.empty([3, dev.B], dtype=torch.float64).pin_memory()
+            self._infoHost = torch.empty([dev.B], dtype=torch.int32).pin_memory()
         return self._device
 
-    def GetFitnessBatch(self, genes):
-        """[(fitness, isInternalAllowed, isDisplaceAllowed)] for a list of genes: one batched solve.
-        Member sections are gathered on the device from the type table by the gene matrix."""
+    _POPULATION_STATE = ("_device", "_typeTable", "_genesHost", "_genesDev", "_fitDev", "_fitHost", "_infoHost")
+
+    def _adopt_population(self, other):
+        """Share `other`'s resident population batch and staging buffers (same truss, member types and nPop: a
+        second GA over the same problem, e.g. another seed) instead of building them again."""
+        for name in self._POPULATION_STATE:
+            setattr(self, name, getattr(other, name))
+
+    def _fitness_arrays(self, genes):
+        """(fitness, isInternalAllowed, isDisplaceAllowed) as arrays for a population (list of genes or a gene
+        matrix): gene matrix -> member sections (`trs_ga_sections`) -> solve + reductions (`trs_solve_small` with the
+        GA terms on the fused path) on the resident population, one wait for the four result rows."""
         import torch
         if not self.truss.isStable:   # what Truss.Solve() raises per individual in the reference
             from .utils import TrussNotStableError
             raise TrussNotStableError("The truss is not stable !")
+        count = len(genes)
         if self._devices is not None and len(self._devices) > 1:
             return self._fitness_sharded(genes)
-        dev = self._population_device(len(genes))
-        count = len(genes)
-        loci = torch.zeros([dev.B, dev.nM_max], dtype=torch.int64, device=dev.device)
-        loci[:count, :self.nMember] = torch.from_numpy(self._gene_matrix(genes)).to(dev.device)   # (uint8 -> int64 on the device)
-        sections = self._typeTable[loci]                    # [B, nM, 3] = (a, e, density)
-        dev.A.copy_(sections[..., 0]); dev.E.copy_(sections[..., 1]); dev.rho.copy_(sections[..., 2])
-        # one kernel for solve + reductions on the fused small path; one download for everything
-        terms = torch.stack(dev.solve_fitness(self.allowStress, self.allowDisplace) +
-                            [dev.info.to(torch.float64)])[:, :count].cpu().numpy()
-        if terms[3].any():
+        matrix = self._gene_matrix(genes)
+        if matrix.size and (matrix.min() < 0 or matrix.max() >= self.nType):
+            raise IndexError("a gene holds a locus outside the member type list")
+        dev = self._population_device(count)
+        with torch.cuda.device(dev.device):
+            if self.nType <= 256:
+                self._genesHost.numpy()[:count] = matrix
+                self._genesDev.copy_(self._genesHost, non_blocking=True)
+                dev.set_sections_from_genes(self._genesDev, count, self.nMember, self._typeTable)
+            else:   # more types than a byte holds: gather with the tensor library
+                loci = torch.zeros([dev.B, dev.nM_max], dtype=torch.int64, device=dev.device)
+                loci[:count, :self.nMember] = torch.from_numpy(np.ascontiguousarray(matrix, dtype=np.int64)).to(dev.device)
+                sections = self._typeTable[loci]                    # [B, nM, 3] = (a, e, density)
+                dev.A.copy_(sections[..., 0]); dev.E.copy_(sections[..., 1]); dev.rho.copy_(sections[..., 2])
+            dev.solve_fitness(self.allowStress, self.allowDisplace, out=list(self._fitDev.unbind(0)))
+            self._fitHost.copy_(self._fitDev, non_blocking=True)
+            self._infoHost.copy_(dev.info, non_blocking=True)
+            torch.cuda.current_stream(dev.device).synchronize()
+        if self._infoHost.numpy()[:count].any():
             raise np.linalg.LinAlgError("Singular matrix")
-        return self._compose_many(terms[0], terms[1], terms[2])
+        terms = self._fitHost.numpy()
+        return self._compose_arrays(terms[0, :count], terms[1, :count], terms[2, :count])
+
+    def GetFitnessBatch(self, genes):
+        """[(fitness, isInternalAllowed, isDisplaceAllowed)] for a list of genes: one batched solve.
+        Member sections are gathered on the device from the type table by the gene matrix."""
+        fitness, okStress, okDisplace = self._fitness_arrays(genes)
+        return list(zip(fitness.tolist(), okStress.tolist(), okDisplace.tolist()))
 
     def _gene_matrix(self, genes):
         """The population (list of lists of type indices, the reference's representation) as an int64
@@ -168,13 +201,14 @@ class GA:
                 pass
         return np.asarray(genes, dtype=np.int64)
 
-    def _compose_many(self, weight, stressViolation, displaceViolation):
-        """`_compose` over arrays (same arithmetic, element by element)."""
+    def _compose_arrays(self, weight, stressViolation, displaceViolation):
+        """`_compose` over arrays (same arithmetic, element by element): fitness, isInternalAllowed,
+        isDisplaceAllowed."""
         okStress = np.abs(stressViolation) < ZERO_EPS
         okDisplace = np.abs(displaceViolation) < ZERO_EPS
         fitness = weight + np.where(okStress, 0.0, stressViolation / self.allowStress * PENALTY)
         fitness = fitness + np.where(okDisplace, 0.0, displaceViolation / self.allowDisplace * PENALTY)
-        return list(zip(fitness.tolist(), okStress.tolist(), okDisplace.tolist()))
+        return fitness, okStress, okDisplace
 
     def _fitness_sharded(self, genes):
         """The population split over the GPUs of `devices` (`shard.ShardedSolver.fitness`)."""
@@ -192,7 +226,7 @@ class GA:
         fit, info = self._pool.fitness(pop, self.allowStress, self.allowDisplace, geometry_key=id(self))
         if info.any():
             raise np.linalg.LinAlgError("Singular matrix")
-        return self._compose_many(fit[:, 0], fit[:, 1], fit[:, 2])
+        return self._compose_arrays(fit[:, 0], fit[:, 1], fit[:, 2])
 
     def close(self):
         """Stop the per-GPU worker processes of a multi-device GA (no-op otherwise)."""
@@ -265,7 +299,7 @@ class GA:
     #: the methods whose reference behaviour `_EvolveNative` reproduces; a subclass that overrides any of them
     #: (the reference's documented extension point is GetFitness) gets the plain Python loop
     _NATIVE_METHODS = ("GetFitness", "Select", "Crossover", "Mutate", "UpdatePop", "GetRandomGene",
-                       "GetBestFeasibleGene", "_RecordFeasible", "_evaluate", "_compose_many")
+                       "GetBestFeasibleGene", "_RecordFeasible", "_evaluate", "_compose_arrays", "_fitness_arrays")
 
     def _native_loop_ok(self):
         """The whole generation loop can run on gene MATRICES with the native population update (`csrc/gaops.c`):
@@ -319,21 +353,24 @@ class GA:
         stock_batch = type(self).GetFitnessBatch is GA.GetFitnessBatch
 
         def evaluate(matrix):
+            if stock_batch:
+                return self._fitness_arrays(matrix)
             # (a user's own batch evaluator gets the reference's list-of-lists population)
-            info = self.GetFitnessBatch(matrix if stock_batch else matrix.tolist())   # [(fitness, okStress, okDisplace)]
-            fit = np.fromiter((t[0] for t in info), dtype=np.float64, count=len(info))
-            ok = np.fromiter((t[1] and t[2] for t in info), dtype=bool, count=len(info))
-            return info, fit, ok
+            info = self.GetFitnessBatch(matrix.tolist())   # [(fitness, okStress, okDisplace)]
+            return (np.fromiter((t[0] for t in info), dtype=np.float64, count=len(info)),
+                    np.fromiter((t[1] for t in info), dtype=bool, count=len(info)),
+                    np.fromiter((t[2] for t in info), dtype=bool, count=len(info)))
 
         while self.nIteration is None or iteration < self.nIteration:
-            info, fit, ok = evaluate(pop)
+            fit, okS, okD = evaluate(pop)
             order = np.argsort(fit, kind="stable")
-            feasible = np.flatnonzero(ok[order])
+            feasible = np.flatnonzero((okS & okD)[order])
             if feasible.size:                         # the best feasible gene of this generation (ranked order)
                 b = int(order[feasible[0]])
-                if self._feasibleFitness is None or info[b][0] < self._feasibleFitness:
-                    self._feasibleGene[:], self._feasibleFitness = pop[b].tolist(), info[b][0]
-            minFitness, okStress, okDisplace = info[int(order[0])]
+                if self._feasibleFitness is None or float(fit[b]) < self._feasibleFitness:
+                    self._feasibleGene[:], self._feasibleFitness = pop[b].tolist(), float(fit[b])
+            first = int(order[0])
+            minFitness, okStress, okDisplace = float(fit[first]), bool(okS[first]), bool(okD[first])
             if minFitness < bestFitness:
                 bestFitness, nWait = minFitness, 0
             else:

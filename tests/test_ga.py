@@ -155,3 +155,41 @@ def test_ga_population_1024_fitness_matches_oracle_sample():
         assert f == pytest.approx(rf, rel=1e-9) and (a, b) == (ra, rb)
     _, info, finalPop, history = ga.Evolve(isPrintMessage=False)
     assert len(history) == 2 and history[1] <= history[0] and len(finalPop) == 1024
+
+
+@pytest.mark.gpu
+def test_ga_sections_kernel_and_fitness_edge_cases():
+    """`trs_ga_sections` against a plain gather (padding rows / members get type 0), a population smaller than the
+    resident one, the list and the matrix form of the same population, and a locus outside the type list."""
+    import numpy as np
+    import torch
+    truss = Truss(3).LoadFromJSON(data=H.load_json("bar-120_input_0"))   # (the truss OracleGA evaluates)
+    random.seed(11)
+    types = [MemberType(0.5 + i, random.uniform(1e7, 3e7), random.uniform(0.1, 1.0)) for i in range(7)]
+    ga = GA(truss, types, nIteration=1, nPop=48, nElite=8)
+    pop = ga.Initialize()
+    full = ga.GetFitnessBatch(pop)
+    dev = ga._device
+    table = np.array([[t.a, t.e, t.density] for t in types])
+    genes = np.array(pop)
+    for name, col in (("A", 0), ("E", 1), ("rho", 2)):
+        got = getattr(dev, name).cpu().numpy()
+        want = np.full(got.shape, table[0, col])
+        want[:len(pop), :ga.nMember] = table[genes, col]
+        assert np.array_equal(got, want), name
+    # fewer genes than the resident population; list form == matrix form; every entry against the oracle evaluator
+    part = ga.GetFitnessBatch(pop[:5])
+    assert part == full[:5]
+    assert ga.GetFitnessBatch(np.array(pop[:5], dtype=np.uint8)) == part
+    ref = OracleGA.GetFitnessBatch(ga, pop[:5])
+    for (f, a, b), (rf, ra, rb) in zip(part, ref):
+        assert f == pytest.approx(rf, rel=1e-9) and (a, b) == (ra, rb)
+    bad = [list(g) for g in pop[:3]]
+    bad[1][2] = len(types)
+    with pytest.raises(IndexError):
+        ga.GetFitnessBatch(bad)
+    # the kernel itself marks a locus outside the table (no host check on this path): NaN sections
+    g = torch.full([dev.B, ga.nMember], 200, dtype=torch.uint8, device=dev.device)
+    dev.set_sections_from_genes(g, 2, ga.nMember, ga._typeTable)
+    torch.cuda.synchronize()
+    assert torch.isnan(dev.A[:2, :ga.nMember]).all() and not torch.isnan(dev.A[2:]).any()
