@@ -21,7 +21,7 @@ small = gen.generate_cube_batch(rng.integers(8, 40, size=16384), gridRange=(6, 6
 for label, packed in (("16384 cubes", cubes), ("8192 cubes of 150..190", big), ("16384 cubes of 8..39", small), ("bar-942 x 4096", bar)):
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     tensors = {f: up(getattr(packed, f)) for f in ("xyz", "conn", "cbits", "loads", "nJ", "nM")}
-    for effort in (2, 0):
+    for effort in (3, 2, 0):
         batch.joint_order_device(torch, tensors, effort=effort); torch.cuda.synchronize()
         buf = (ctypes.c_ulonglong * 16)()
         lib.trs_order_debug_stamps(buf, 1)
