@@ -264,6 +264,94 @@ __device__ unsigned long long price_order(const Tables& t, int nf, Ord ord, unsi
     return cost;
 }
 
+// price_order for an order AND its reverse in one walk over the neighbour lists (the walk - dependent LDS look-ups -
+// is most of a pricing): in the reversed order a joint's first coupled position is its neighbours' LAST position of
+// the forward order, and its rows start at n - (rows before it) - (its own rows).  fwd(k) = old id of the joint at
+// position k; c01r / cminr: a second scratch pair (the wave's slice of the sort keys, dead once the sort is done).
+// Same two values as price_order(fwd) and price_order(reversed).
+template <typename Fwd>
+__device__ void price_order_pair(const Tables& t, int nf, Fwd fwd, unsigned short* newidx, unsigned short* c01,
+                                 int* cmin, unsigned short* c01r, int* cminr, int lane, int* n_out,
+                                 unsigned long long* cost_fwd, unsigned long long* cost_rev) {
+    auto pack = [](int ds, int v) { return (unsigned short)(((ds >> 4) << 1) | ((((ds + v - 1) >> 4) != (ds >> 4)) ? 1 : 0)); };
+    int carry = 0;
+    for (int base = 0; base < nf; base += 64) {
+        const int k = base + lane;
+        const int old = k < nf ? fwd(k) : 0;
+        const int v = k < nf ? (int)t.nfr[old] : 0;
+        const int incl = wave_incl_scan(v, lane);
+        const int ds = carry + incl - v;
+        if (k < nf) {
+            newidx[old] = (unsigned short)k;
+            c01[k] = pack(ds, v);
+            c01r[k] = (unsigned short)(ds + v);   // rows up to and including this joint; turned into the reversed start below
+        }
+        carry += __shfl(incl, 63);
+    }
+    const int n = carry, nch = (n + 15) >> 4;
+    for (int q = lane; q < nch; q += 64) {
+        cmin[q] = q;
+        cminr[q] = q;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < nf; k += 64) {
+        const int end = c01r[k];
+        c01r[k] = pack(n - end, (int)t.nfr[fwd(k)]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < nf; k += 64) {
+        const int old = fwd(k);
+        int lo = k, hi = k;  // a joint's own rows may straddle two chunks
+        const int e1 = t.start[old + 1];
+        for (int e = t.start[old]; e < e1; e += 4) {  // four independent look-ups per step (slack behind the lists;
+            const int w0 = t.adj[e], w1 = t.adj[e + 1], w2 = t.adj[e + 2], w3 = t.adj[e + 3];   // ids stay < nJ_max)
+            const int i0 = newidx[w0], i1 = e + 1 < e1 ? (int)newidx[w1] : k, i2 = e + 2 < e1 ? (int)newidx[w2] : k,
+                      i3 = e + 3 < e1 ? (int)newidx[w3] : k;
+            lo = min(min(lo, i0), min(min(i1, i2), i3));
+            hi = max(max(hi, i0), max(max(i1, i2), i3));
+        }
+        const int col = c01[lo] >> 1, mine = c01[k];
+        atomicMin(&cmin[mine >> 1], col);
+        if (mine & 1) atomicMin(&cmin[(mine >> 1) + 1], col);
+        const int colr = c01r[hi] >> 1, miner = c01r[k];
+        atomicMin(&cminr[miner >> 1], colr);
+        if (miner & 1) atomicMin(&cminr[(miner >> 1) + 1], colr);
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long cf = 0, cr = 0;
+    int runf = nch, runr = nch;
+    for (int base = (nch - 1) / 64 * 64; base >= 0; base -= 64) {
+        const int q = base + lane;
+        int vf = q < nch ? cmin[q] : 0x7fffffff, vr = q < nch ? cminr[q] : 0x7fffffff;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int of = __shfl_down(vf, off), orv = __shfl_down(vr, off);
+            if (lane + off < 64) {
+                vf = min(vf, of);
+                vr = min(vr, orv);
+            }
+        }
+        vf = min(vf, runf);
+        vr = min(vr, runr);
+        if (q < nch) {
+            const unsigned long long wf = (unsigned long long)(q - vf + 1), wr = (unsigned long long)(q - vr + 1);
+            cf += wf * (wf + 12ull);
+            cr += wr * (wr + 12ull);
+        }
+        runf = __shfl(vf, 0);
+        runr = __shfl(vr, 0);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cf += __shfl_xor(cf, off);
+        cr += __shfl_xor(cr, off);
+    }
+    __builtin_amdgcn_wave_barrier();
+    *n_out = n;
+    *cost_fwd = cf;
+    *cost_rev = cr;
+}
+
 __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     const double* __restrict__ xyz, const int* __restrict__ conn, const unsigned char* __restrict__ cbits,
     const double* __restrict__ loads, const int* __restrict__ nJ_arr, const int* __restrict__ nM_arr,
@@ -671,8 +759,13 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
             st.mark(3);
             auto fwd = [&](int k) { return (int)cand[k]; };
             auto rev = [&](int k) { return (int)cand[nf - 1 - k]; };
-            consider(price_order(t, nf, fwd, newidx, c01, cmin, lane, &ndof), 2 + 2 * i, 2 + 2 * ax, fwd);
-            consider(price_order(t, nf, rev, newidx, c01, cmin, lane, &ndof), 3 + 2 * i, 3 + 2 * ax, rev);
+            // (second scratch pair: this wave's key slice, dead now - 2 nf + 4 nch <= 4 nf bytes)
+            unsigned short* c01r = reinterpret_cast<unsigned short*>(k32);
+            int* cminr = reinterpret_cast<int*>(k32 + ((nf + 3) >> 2 << 1));
+            unsigned long long cost_fwd, cost_rev;
+            price_order_pair(t, nf, fwd, newidx, c01, cmin, c01r, cminr, lane, &ndof, &cost_fwd, &cost_rev);
+            consider(cost_fwd, 2 + 2 * i, 2 + 2 * ax, fwd);
+            consider(cost_rev, 3 + 2 * i, 3 + 2 * ax, rev);
             st.mark(4);
         }
     }
