@@ -469,7 +469,9 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
             "joint_order": "trs_joint_order on the device, INSIDE the timed step (effort 3: every coordinate sweep; reverse "
                            "Cuthill-McKee and its reverse for trusses below 128 free joints); results in the generator's "
                            "numbering",
-            "stages_ms": stage_ms,
+            "stages_ms": stage_ms, "lanes": solver.lanes,
+            "stages_ms_note": "event pairs per bucket, summed; the buckets run on `lanes` streams at the same time, so the "
+                              "sums exceed the step",
             "roofline": {"bound": bound, "intensity_flop_per_byte": intensity,
                          "mfma": {"achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_TFLOPS,
                                   "flop_model": "MFMA work of the factorisation inside the 16x16-tile envelopes, "

@@ -11,16 +11,18 @@ from python_stable_3d_truss_analysis_amd import batch
 ap = argparse.ArgumentParser()
 ap.add_argument("--cubes", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--slab-gb", type=int, default=48, help="max_slab_bytes of the solver, GiB (all lanes together)")
+ap.add_argument("--lanes", type=int, default=None, help="streams the buckets are dealt onto (default: the solver's)")
 args = ap.parse_args()
 sizes, tensors = bench.cube_workload(args.cubes, 0, device="cuda:0")
-solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors)
+solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors, lanes=args.lanes, max_slab_bytes=args.slab_gb << 30)
 solver.step(); torch.cuda.synchronize()
 solver.adopt_launch_hints()
 for _ in range(args.steps):
     solver.step()
 torch.cuda.synchronize()
 print("info_nonzero", int((solver.info != 0).sum().item()))
-# per-stage times of one step (events on the stream), summed over the buckets
+# per-stage times of one step (events on the buckets' streams), summed over the buckets (lanes overlap: the sums exceed the step)
 import time
 rec = []
 solver.step(record=rec); torch.cuda.synchronize()
@@ -32,5 +34,5 @@ for _ in range(args.steps):
     solver.step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
-print(f"options {solver.buckets[-1]['dev'].options}: step {dt * 1e3:.2f} ms = {args.cubes / dt / 1e6:.3f} M solves/s; "
+print(f"options {solver.buckets[-1]['dev'].options}, {solver.lanes} lanes, {len(solver.buckets)} buckets: step {dt * 1e3:.2f} ms = {args.cubes / dt / 1e6:.3f} M solves/s; "
       + ", ".join(f"{k} {v:.2f}" for k, v in tot.items()))
