@@ -419,8 +419,9 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
                         "info_nonzero": int((got.info != 0).sum()),
                         "note": "host arrays in -> host results out per CALL of batch.solve_batch_streamed (set-up "
                                 "included): buckets pulled over PCIe by the gather kernel (live bytes only), ordered "
-                                "and solved on the device, results pushed into page-locked arrays; copy kernels on "
-                                "compute units of their own; never the leg's value"}
+                                "and solved on the device, results pushed into page-locked arrays; three ordinary "
+                                "streams (TRS_PCIE_CUS=16,8 gives the copy kernels compute units of their own: opt-in); "
+                                "never the leg's value"}
             del pinned, pool, got
         except Exception as exc:   # (an informational leg must not take the line down)
             host_fed = {"error": repr(exc)}

@@ -1134,11 +1134,14 @@ def _flow_shop_order(groups, packed, n_pad_of, rule="johnson"):
 
 
 def _pipeline_streams(torch, dev, lib):
-    """(pull, run, push) streams of `RaggedSolver`'s host-fed pipeline.  `TRS_PCIE_CUS="pull,push"` compute units
-    are set apart for the copy kernels (default 16 + 8 = two per XCD for the pull, one for the push: the row copies reach the
-    link's rate on those, `tools/masked_pipeline_check.py`); 0 = three ordinary streams (the copies then compete
-    with the factorisation for registers on every CU)."""
-    spec = os.environ.get("TRS_PCIE_CUS", "16,8")
+    """(pull, run, push) streams of `RaggedSolver`'s host-fed pipeline: three ordinary streams by default.
+    `TRS_PCIE_CUS="pull,push"` (e.g. "16,8" = two CUs per XCD for the pull, one for the push: the row copies reach the
+    link's rate on those, `tools/masked_pipeline_check.py`) sets compute units apart for the copy kernels through
+    CU-masked streams - 73 instead of 91 ms per host-fed call of the 65 536-truss cube batch, because the copies no
+    longer compete with the factorisation for registers on every CU - but OPT-IN: on this runtime processes that
+    use CU-masked streams die of memory access faults or hang once in five runs of the host-fed tests (ordinary
+    streams: once in twenty-six; EXPERIMENTS R4.9)."""
+    spec = os.environ.get("TRS_PCIE_CUS", "0")
     key = (str(dev), spec)
     if key not in _PIPELINE_STREAMS:   # (a queue with a CU mask takes ~20 ms to create: once per process and device)
         pull_cus, push_cus = int(spec.split(",")[0]), int(spec.split(",")[-1])
@@ -1183,12 +1186,14 @@ class RaggedSolver:
         (e.g. from `generate.generate_cube_batch_device`), just its `BatchSizes`.  `workspace`: a
         `SolverWorkspace` shared with other solvers that run on the same stream one after the other.
 
-        `lanes` (default 3, `TRS_RAGGED_LANES`; resident batches only): the buckets are dealt onto that many streams
-        - lane 0 is the caller's stream, the others fork from it at the start of `step()` and join it at the end -,
-        each lane with a workspace of its own, so that one bucket's kernels fill the tails (and the store-free table
-        set-up) of another's: 48.6 -> 45.3 ms per step of the 65 536-truss cube batch at the same memory.
-        `max_slab_bytes` bounds the slabs of ALL lanes together: a bucket gets at most `max_slab_bytes / lanes`.
-        Results are bit for bit those of one lane.
+        `lanes` (default 1, `TRS_RAGGED_LANES`; resident batches only; OPT-IN): the buckets are dealt onto that many
+        streams - lane 0 is the caller's stream, the others fork from it at the start of `step()` and join it at the
+        end -, each lane with a workspace of its own, so that one bucket's kernels fill the tails (and the store-free
+        table set-up) of another's: 48.6 -> 45.3 ms per step of the 65 536-truss cube batch at the same memory
+        (`max_slab_bytes` bounds the slabs of ALL lanes together: a bucket gets at most `max_slab_bytes / lanes`).
+        Results are bit for bit those of one lane.  Not the default: with per-chunk solvers (`data.dataset_chunks`)
+        one run in ten stopped making progress on the device on this runtime (EXPERIMENTS R4.9, not understood);
+        a long-lived solver stepped repeatedly never did.
 
         `host_io=(inputs, outputs)`: the batch STAYS in page-locked host memory - `inputs` / `outputs` are dicts of
         pinned CPU tensors (the padded arrays of a `PackedBatch.pinned()`; `u`, `f_ext`, `N`, `info` of a
@@ -1253,7 +1258,7 @@ class RaggedSolver:
                          for _ in range(max(1, int(n_variants)))]
             first = self.outs[0]
             self.u, self.f_ext, self.N, self.info = first["u"], first["f_ext"], first["N"], first["info"]
-        n_lanes = 1 if self.host_io else max(1, int(lanes if lanes is not None else os.environ.get("TRS_RAGGED_LANES", "3")))
+        n_lanes = 1 if self.host_io else max(1, int(lanes if lanes is not None else os.environ.get("TRS_RAGGED_LANES", "1")))
         groups = size_buckets(packed, max_slab_bytes // n_lanes, granularity) if B else []
         n_pad_of = lambda idx: (int(packed.n_free[idx].max()) + 63) // 64 * 64
         slab_of = lambda idx: len(idx) * n_pad_of(idx) * (n_pad_of(idx) + 16)
@@ -1428,9 +1433,11 @@ class RaggedSolver:
             if not self.host_io:
                 caller = torch.cuda.current_stream(self.device)
                 lanes = [caller] + list(self._side_streams)
+                self._lane_events = []   # (kept until the next step: none is destroyed while a stream may still wait on it)
                 if len(lanes) > 1:   # fork: the side lanes start behind everything queued on the caller's stream
                     fork = torch.cuda.Event()
                     fork.record(caller)
+                    self._lane_events.append(fork)
                     for side in lanes[1:]:
                         side.wait_event(fork)
                 try:
@@ -1440,6 +1447,7 @@ class RaggedSolver:
                         done = torch.cuda.Event()
                         done.record(side)
                         caller.wait_event(done)
+                        self._lane_events.append(done)
                 return
             if sections[0] is not None:
                 raise ValueError("the host-fed pipeline solves the members' own sections")

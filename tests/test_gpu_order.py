@@ -6,6 +6,8 @@ host's `trs_apply_joint_order`; the reach it reports must equal the host's envel
 batch (= what `trs_assemble` derives); stored tiles never exceed the host profile order's; and the solve under
 the device order must match the goldens / the oracle in the caller's numbering.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -200,39 +202,15 @@ def test_ragged_solver_matches_solve_batch_bitwise(gpu):
         np.testing.assert_array_equal(plain.result().displace, gpu.solve_batch(packed).displace)
 
 
-def test_ragged_solver_lanes_give_the_same_bits(gpu):
-    """The buckets of a resident ragged batch dealt onto 1, 2, 3 and 5 streams (`RaggedSolver(lanes=)`: every lane its
-    own workspace, fork from / join to the caller's stream): the same bits, step after step, also on a side stream
-    of the caller's and with two section variants; a second solver that shares the workspace runs right behind."""
-    import torch
-    from python_stable_3d_truss_analysis_amd import generate as gen
-    rng = np.random.default_rng(8)
-    packed = gen.generate_cube_batch(rng.integers(1, 191, size=400), gridRange=(6, 6, 6), seed=4)
-    one = gpu.RaggedSolver(packed, reorder=True, lanes=1, n_variants=2)
-    fixed = (2.5, 1.0e7, 0.3)
-    one.step(sections=[None, fixed])
-    want = [{k: o[k].clone() for k in ("u", "f_ext", "N", "info")} for o in one.outs]
-    assert one.lanes == 1 and not any(w["info"].any() for w in want)
-    ws = gpu.SolverWorkspace(torch, one.device)
-    for lanes in (2, 3, 5):
-        solver = gpu.RaggedSolver(packed, reorder=True, lanes=lanes, n_variants=2, workspace=ws)
-        assert solver.lanes == min(lanes, len(solver.buckets)) and {bk["lane"] for bk in solver.buckets} == set(range(solver.lanes))
-        other = gpu.RaggedSolver(packed, reorder=True, lanes=lanes, n_variants=2, workspace=ws)   # same buffers, same lanes
-        side = torch.cuda.Stream()
-        for attempt, stream in enumerate((torch.cuda.current_stream(), side, side)):
-            for o in solver.outs + other.outs:
-                o["u"].fill_(float("nan")); o["N"].fill_(float("nan"))
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):
-                solver.step(sections=[None, fixed])
-                other.step(sections=[None, fixed])
-            stream.synchronize()
-            for s in (solver, other):
-                for got, ref in zip(s.outs, want):
-                    for k in ("u", "f_ext", "N", "info"):
-                        assert torch.equal(torch.nan_to_num(got[k], nan=0.0), ref[k]), (lanes, attempt, k)
-            if attempt == 0:
-                solver.adopt_launch_hints()
+def test_ragged_solver_lanes_give_the_same_bits():
+    """`RaggedSolver(lanes=)` (opt-in: the buckets of a resident ragged batch dealt onto several streams) gives the
+    bits of one lane - checked in a process of its own (`tests/lanes_check.py`), so that its side streams never
+    share this process with the CU-masked streams of the host-fed tests below (EXPERIMENTS R4.9)."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lanes_check.py")
+    run = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "lanes ok" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
 
 
 def test_copy_rows_gathers_and_scatters_prefixes(gpu):
@@ -347,34 +325,18 @@ def test_ragged_solver_section_variants_equal_solve_batch_sections(gpu):
         np.testing.assert_array_equal(got.internal.cpu().numpy(), ref.internal)
 
 
-def test_masked_streams_run_kernels_and_refuse_bad_masks(gpu):
-    """`trs_stream_create_masked` (ABI 8): kernels queued on a CU-masked stream run (on whichever CUs the mask
-    names) and give the same results; masks that leave a role without CUs are refused."""
-    import ctypes
-    import torch
-    lib = gpu._capi.load()
-    try:
-        streams = gpu._MaskedStreams(torch, torch.device("cuda:0"), lib, 8, 4)
-    except gpu.HipExtensionError as exc:       # (the pipeline then runs on ordinary streams, `_pipeline_streams`)
-        pytest.skip(f"this runtime refuses CU-masked streams: {exc}")
-    P, Z = ctypes.c_void_p, ctypes.c_size_t
-    src = torch.arange(64 * 100, dtype=torch.float64, device="cuda").reshape(64, 100)
-    rows = torch.arange(63, -1, -1, dtype=torch.int64, device="cuda")
-    torch.cuda.synchronize()
-    outs = []
-    for st in streams:
-        dst = torch.zeros_like(src)
-        assert lib.trs_copy_rows(1, (P * 1)(src.data_ptr()), (Z * 1)(800), (P * 1)(dst.data_ptr()), (Z * 1)(800), (Z * 1)(800),
-                                 None, None, None, None, 64, rows.data_ptr(), 0, 2, st.cuda_stream) == 0
-        outs.append(dst)
-    torch.cuda.synchronize()
-    assert all(torch.equal(dst, src.flip(0)) for dst in outs)
-    streams.close()
-    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
-    with pytest.raises(ValueError):
-        gpu._MaskedStreams(torch, torch.device("cuda:0"), lib, n_cu, 8)
-    with pytest.raises(ValueError):
-        gpu._MaskedStreams(torch, torch.device("cuda:0"), lib, 0, 8)
+def test_masked_streams_run_kernels_and_refuse_bad_masks():
+    """`trs_stream_create_masked` (ABI 8; the host-fed pipeline's opt-in `TRS_PCIE_CUS`): kernels queued on a CU-masked
+    stream run (on whichever CUs the mask names) and give the same results; masks that leave a role without CUs are
+    refused.  In a process of its own (`tests/masked_streams_check.py`): on this runtime a process that has created
+    CU-masked streams may fault later (EXPERIMENTS R4.9), and this one has eighty tests still to run."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "masked_streams_check.py")
+    run = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+    if "refused:" in run.stdout:
+        pytest.skip(run.stdout.strip().splitlines()[-1])
+    assert run.returncode == 0 and "masked streams ok" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
 
 
 @pytest.mark.parametrize("tracked", [False, True], ids=["zero-filled rows", "tracked live extents"])
