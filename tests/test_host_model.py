@@ -215,6 +215,32 @@ def test_size_buckets_and_trimmed_cover_a_ragged_batch():
     assert sub.n_free.tolist() == p.n_free[groups[0]].tolist()
 
 
+def test_size_buckets_cut_at_whole_rounds():
+    """`size_buckets(quantum=)` (resident solvers): the trusses in descending size, groups of whole multiples of the
+    quantum where a group's span of size classes holds that many, never more slab than allowed, every truss once."""
+    rng = np.random.default_rng(4)
+    B = 5000
+    sizes = batch.BatchSizes(nJ=np.full(B, 50, dtype=np.int32), nM=np.full(B, 200, dtype=np.int32),
+                             n_free=rng.integers(140, 900, size=B).astype(np.int32), nJ_max=50, nM_max=200)
+    quantum, span, cap = 256, 2, 4 << 30
+    groups = batch.size_buckets(sizes, max_slab_bytes=cap, quantum=quantum, span=span)
+    assert sorted(np.concatenate(groups).tolist()) == list(range(B))
+    pads = (sizes.n_free.astype(np.int64) + 63) // 64 * 64
+    whole = 0
+    for idx in groups:
+        top, low = int(pads[idx].max()), int(pads[idx].min())
+        assert top - low <= 64 * span
+        assert len(idx) * top * (top + 16) * 8 <= cap or len(idx) == 1
+        whole += int(len(idx) % quantum == 0)
+        assert len(idx) < quantum or len(idx) % quantum == 0
+    assert whole >= len(groups) // 2
+    # descending: no truss of a later group is larger than the largest of an earlier one
+    tops = [int(pads[idx].max()) for idx in groups]
+    assert tops == sorted(tops, reverse=True)
+    # quantum 0 = one padded size per group, as before
+    assert all(len(set(pads[idx].tolist())) == 1 for idx in batch.size_buckets(sizes, max_slab_bytes=cap))
+
+
 def test_rcm_permutation_is_valid_and_shrinks_the_cube_envelope():
     """Native RCM (csrc/reorder.c): a permutation per truss; the joint bandwidth of generated cube
     trusses drops well below the generator order; bar-942 (already banded) stays solvable either way."""
