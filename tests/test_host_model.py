@@ -237,6 +237,8 @@ def test_size_buckets_cut_at_whole_rounds():
     # descending: no truss of a later group is larger than the largest of an earlier one
     tops = [int(pads[idx].max()) for idx in groups]
     assert tops == sorted(tops, reverse=True)
+    # inside a group: ascending size (the factorisation walks a group from its end)
+    assert all((np.diff(sizes.n_free[idx]) >= 0).all() for idx in groups)
     # quantum 0 = one padded size per group, as before
     assert all(len(set(pads[idx].tolist())) == 1 for idx in batch.size_buckets(sizes, max_slab_bytes=cap))
 
