@@ -399,32 +399,6 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
             eu = max(eu, float(np.abs(got_u[k, :len(ru)] - ru).max() / np.abs(ru).max()))
             en = max(en, float(np.abs(got_N[k, :len(rn)] - rn).max() / np.abs(rn).max()))
         check = {"u": eu, "N": en, "trusses_checked": len(refs)}
-    host_fed = None
-    if world == 1 and not args.no_pcie:
-        # informational: the same batch from page-locked HOST arrays to page-locked host results, one call
-        # (set-up, bucket pulls, device order + solves, pushes: `batch.solve_batch_streamed`)
-        try:
-            pinned, pool = packed.to_packed(tensors).pinned(), batch.ResultPool(tracked=True)   # (results are only read)
-            for _ in range(2):
-                batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
-            t0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                got = batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
-            dt = (time.perf_counter() - t0) / reps
-            nJ64, nM64 = packed.nJ.astype(np.int64), packed.nM.astype(np.int64)
-            host_fed = {"solves_per_s": packed.B / dt, "ms_per_call": dt * 1e3,
-                        "h2d_live_bytes": int((nJ64 * 49 + nM64 * 24).sum()),
-                        "d2h_live_bytes": int((nJ64 * 48 + nM64 * 8).sum()) + 4 * packed.B,
-                        "info_nonzero": int((got.info != 0).sum()),
-                        "note": "host arrays in -> host results out per CALL of batch.solve_batch_streamed (set-up "
-                                "included): buckets pulled over PCIe by the gather kernel (live bytes only), ordered "
-                                "and solved on the device, results pushed into page-locked arrays; three ordinary "
-                                "streams (TRS_PCIE_CUS=16,8 gives the copy kernels compute units of their own: opt-in); "
-                                "never the leg's value"}
-            del pinned, pool, got
-        except Exception as exc:   # (an informational leg must not take the line down)
-            host_fed = {"error": repr(exc)}
     # executed matrix-core work and algorithmic bytes of this rank's batch, from the envelope metadata of every
     # bucket (the buckets share one workspace: re-assemble bucket by bucket to read it)
     flops = bytes_alg = tiles = ktiles = 0.0
@@ -486,11 +460,37 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
                                  "bytes_per_step": bytes_alg, "by_stage": per_stage},
                          "stored_tiles_per_truss": tiles / max(1, packed.B),
                          "stiffness_tiles_per_truss": ktiles / max(1, packed.B)},
-            "device_generate_s": t_gen, "host_fed": host_fed,
+            "device_generate_s": t_gen,
             "cpu_baseline": cpu[0] if cpu is not None else None,
             "max_rel_err_vs_oracle": check,
             "note": "generated on the device, resident in generator order; one launch pipeline per size bucket on a "
                     "shared workspace"}
+
+
+def host_fed_leg(args, device, torch, batch):
+    """Informational, rank 0 at N = 1, one of the legs that drive SEVERAL streams (they run last, under the watchdog): the
+    cube batch from page-locked HOST arrays to page-locked host results, one call (set-up, bucket pulls, device order +
+    solves, pushes: `batch.solve_batch_streamed`)."""
+    import numpy as np
+    packed, tensors = cube_workload(args.cube_batch, 0, device=device)
+    pinned, pool = packed.to_packed(tensors).pinned(), batch.ResultPool(tracked=True)   # (results are only read)
+    for _ in range(2):
+        batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        got = batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
+    dt = (time.perf_counter() - t0) / reps
+    nJ64, nM64 = packed.nJ.astype(np.int64), packed.nM.astype(np.int64)
+    return {"solves_per_s": packed.B / dt, "ms_per_call": dt * 1e3,
+            "h2d_live_bytes": int((nJ64 * 49 + nM64 * 24).sum()),
+            "d2h_live_bytes": int((nJ64 * 48 + nM64 * 8).sum()) + 4 * packed.B,
+            "info_nonzero": int((got.info != 0).sum()),
+            "note": "host arrays in -> host results out per CALL of batch.solve_batch_streamed (set-up "
+                    "included): buckets pulled over PCIe by the gather kernel (live bytes only), ordered "
+                    "and solved on the device, results pushed into page-locked arrays; three ordinary "
+                    "streams (TRS_PCIE_CUS=16,8 gives the copy kernels compute units of their own: opt-in); "
+                    "never the leg's value"}
 
 
 def dataset_leg(args, device, torch, barrier, reduce_max, rank, world):
@@ -504,7 +504,11 @@ def dataset_leg(args, device, torch, barrier, reduce_max, rank, world):
     total = args.dataset_samples * world
     kw = dict(seed=11, numCubeRange=(8, 190), gridRange=(6, 6, 6), fixedMemberType=MemberType(1., 1e7, 0.1),
               taskType=TaskType.REGRESSION, device=device, forceScale=1e3, displaceScale=0.1, positionScale=100.)
-    for _ in gdata.dataset_chunks(min(chunk, 2048), rank=0, world=1, chunk=min(chunk, 2048), **kw):   # warm
+    # warm: kernels and launch tables with a small chunk, then one chunk of the timed size, so that the timed chunks find
+    # their workspaces and tensor shapes in the allocator's cache (the first 16 GB hipMalloc costs a fifth of a second)
+    for _ in gdata.dataset_chunks(min(chunk, 2048), rank=0, world=1, chunk=min(chunk, 2048), **kw):
+        pass
+    for _ in gdata.dataset_chunks(chunk, rank=0, world=1, chunk=chunk, **kw):
         pass
     barrier()
     t0 = time.perf_counter()
@@ -514,44 +518,45 @@ def dataset_leg(args, device, torch, barrier, reduce_max, rank, world):
         bad += int(tensors["info"].ne(0).sum().item())
     barrier()
     elapsed = reduce_max(time.perf_counter() - t0)
-    # the same dataset DELIVERED: packed feature rows + edge indices in page-locked host memory (data.dataset_stream,
-    # the sink of config 5: "results streamed to PyG HeteroData"), the copies overlapped with the next chunk
-    streamed = None
-    try:
-        for _ in gdata.dataset_stream(2 * chunk, rank=0, world=1, chunk=chunk, **kw):   # warm: page-locks both slots of the ring
-            pass
-        barrier()
-        t0 = time.perf_counter()
-        got = nbytes = sbad = 0
-        for graphs in gdata.dataset_stream(total, rank=rank, world=world, chunk=chunk, **kw):
-            got += len(graphs)
-            nbytes += graphs.nbytes
-            sbad += int(graphs.tensors["info"].ne(0).sum().item())
-            g = graphs[len(graphs) // 2]     # a consumer's view: one sample of the chunk as a graph object
-            assert g["joint"].x.shape[0] == int(graphs.nJ[len(graphs) // 2])
-        barrier()
-        s_elapsed = reduce_max(time.perf_counter() - t0)
-        streamed = {"value": total / s_elapsed, "unit": "samples/s", "seconds": s_elapsed,
-                    "bytes_per_sample": nbytes / max(1, got), "d2h_GBps_rank0": nbytes / s_elapsed / 1e9,
-                    "info_nonzero_rank0": sbad, "rank0_samples": got, "vs_resident": (total / s_elapsed) / (total / elapsed),
-                    "note": "data.dataset_stream: as above, then the un-padded float32 feature rows, targets and the "
-                            "members' end joints (row 0 of every sample's j2m edge index; int32) of every chunk copied "
-                            "by DMA into page-locked host memory on a second stream while the device works on the "
-                            "next chunk; per chunk one sample materialised as a graph object (HeteroData where "
-                            "torch_geometric is installed, else the dict-of-stores stand-in)"}
-    except Exception as exc:
-        streamed = {"error": repr(exc)}
-        if world > 1:
-            raise
     if rank != 0:
         return None
     return {"value": total / elapsed, "unit": "samples/s", "samples_per_gpu": args.dataset_samples, "chunk": chunk,
             "seconds": elapsed, "solves_per_sample": 2, "info_nonzero_rank0": bad, "rank0_samples": seen,
-            "streamed": streamed,
             "note": "`value` = the compute side of config 5 (data.dataset_chunks: generation, joint order, two solves "
                     "and graph features per sample, all on the device, padded tensors left resident per chunk); "
-                    "`streamed` = config 5 end to end, the samples delivered in host memory; mixed cube trusses of "
-                    "8..190 cubes"}
+                    "`streamed` (N = 1) = config 5 end to end, the samples delivered in host memory; mixed cube "
+                    "trusses of 8..190 cubes"}
+
+
+def dataset_streamed_leg(args, device, resident_rate):
+    """Informational, rank 0 at N = 1, a leg that drives two streams (it runs last, under the watchdog): the dataset of
+    `dataset_leg` DELIVERED - packed feature rows + edge indices in page-locked host memory (data.dataset_stream, the sink
+    of config 5: "results streamed to PyG HeteroData"), the copies overlapped with the next chunk."""
+    from python_stable_3d_truss_analysis_amd import MemberType, TaskType
+    from python_stable_3d_truss_analysis_amd import data as gdata
+    chunk = min(32768, args.dataset_samples)
+    total = args.dataset_samples
+    kw = dict(seed=11, numCubeRange=(8, 190), gridRange=(6, 6, 6), fixedMemberType=MemberType(1., 1e7, 0.1),
+              taskType=TaskType.REGRESSION, device=device, forceScale=1e3, displaceScale=0.1, positionScale=100.)
+    for _ in gdata.dataset_stream(2 * chunk, rank=0, world=1, chunk=chunk, **kw):   # warm: page-locks both slots of the ring
+        pass
+    t0 = time.perf_counter()
+    got = nbytes = sbad = 0
+    for graphs in gdata.dataset_stream(total, rank=0, world=1, chunk=chunk, **kw):
+        got += len(graphs)
+        nbytes += graphs.nbytes
+        sbad += int(graphs.tensors["info"].ne(0).sum().item())
+        g = graphs[len(graphs) // 2]     # a consumer's view: one sample of the chunk as a graph object
+        assert g["joint"].x.shape[0] == int(graphs.nJ[len(graphs) // 2])
+    s_elapsed = time.perf_counter() - t0
+    return {"value": total / s_elapsed, "unit": "samples/s", "seconds": s_elapsed,
+            "bytes_per_sample": nbytes / max(1, got), "d2h_GBps_rank0": nbytes / s_elapsed / 1e9,
+            "info_nonzero_rank0": sbad, "rank0_samples": got, "vs_resident": (total / s_elapsed) / resident_rate,
+            "note": "data.dataset_stream: as `value`, then the un-padded float32 feature rows, targets and the "
+                    "members' end joints (row 0 of every sample's j2m edge index; int32) of every chunk copied "
+                    "by DMA into page-locked host memory on a second stream while the device works on the "
+                    "next chunk; per chunk one sample materialised as a graph object (HeteroData where "
+                    "torch_geometric is installed, else the dict-of-stores stand-in)"}
 
 
 def ga_leg(device, torch):
@@ -626,6 +631,30 @@ def reference_protocol_leg():
     return out
 
 
+class LateLegWatchdog:
+    """Armed around one late (multi-stream, informational) leg: if the leg has not finished after `seconds`, the line
+    assembled so far is printed - with a note naming the leg - and the process exits with status 0.  A stalled
+    device call never returns to Python, so nothing softer than `os._exit` can end it; everything the contract asks
+    for is in the line by then."""
+
+    def __init__(self, line, name, seconds):
+        import threading
+        self._finished = threading.Event()
+        self._thread = threading.Thread(target=self._watch, args=(line, name, float(seconds)), daemon=True)
+        self._thread.start()
+
+    def _watch(self, line, name, seconds):
+        if self._finished.wait(seconds):
+            return
+        line["watchdog"] = (f"the informational leg `{name}` did not finish within {seconds:.0f} s (multi-stream work "
+                            "stalled on the device); the line was printed without it and the process ended")
+        print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    def done(self):
+        self._finished.set()
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) with
     torch.distributed.run as a CHILD process and pass its output and exit code through.  This process
@@ -675,6 +704,9 @@ def main():
                          "topology, outside the timed region like the upload - the line also carries the rate with "
                          "the order INSIDE the step, `order_in_step`); results are delivered in the GIVEN numbering "
                          "either way (trs_recover's joint_out) and checked against the oracle in it")
+    ap.add_argument("--late-leg-seconds", type=float, default=180.0,
+                    help="watchdog of each informational multi-stream leg (dataset.streamed, cube_batch.host_fed): after "
+                         "this long the line is printed without the leg")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than visible GPUs (ranks share devices round-robin; for testing "
                          "the multi-rank path on a 1-GPU box - the line then reports the devices really used)")
@@ -863,8 +895,7 @@ def main():
 
     # informational: the same step fed from / drained to page-locked host memory over PCIe, upload of the
     # next batch, solve and download of the previous one overlapped on three streams (batch.StreamedSolver)
-    pcie = None
-    if world == 1 and not args.no_pcie:
+    def pcie_leg():
         pipe = batch.StreamedSolver(packed, device, slots=3, use_envelope=not args.dense, same_topology=True)
         src = pipe.host_in[0]
         for _ in range(3):          # warm-up: first use of the page-locked buffers, allocator, clocks
@@ -880,14 +911,21 @@ def main():
         dt = (time.perf_counter() - t0) / reps
         in_bytes = sum(v.numel() * v.element_size() for v in src.values())
         out_bytes = sum(v.numel() * v.element_size() for v in pipe.host_out[0].values())
-        pcie = {"solves_per_s": args.batch / dt, "ms_per_step": dt * 1e3,
+        return {"solves_per_s": args.batch / dt, "ms_per_step": dt * 1e3,
                 "h2d_bytes_per_truss": in_bytes // args.batch, "d2h_bytes_per_truss": out_bytes // args.batch,
                 "h2d_plus_d2h_GBps": (in_bytes + out_bytes) / dt / 1e9,
                 "info_nonzero": int((last.info != 0).sum()),
                 "note": "steady state of batch.StreamedSolver: upload of all inputs, solve and download of u, "
                         "f_ext, N, info through page-locked host buffers on three streams (one DMA per direction "
                         "and batch), three resident batches; never the headline value"}
-        del pipe
+
+
+    pcie = None
+    if world == 1 and not args.no_pcie:
+        try:
+            pcie = pcie_leg()
+        except Exception as exc:
+            pcie = {"error": repr(exc)}
 
     # the ragged workload of north_star (BASELINE config 3), on EVERY rank, with its own barrier-bracketed region
     cube = None
@@ -1070,6 +1108,24 @@ def main():
                 "u": float(np.abs(res.displace[:, :nJ] - ref["u"][None]).max() / np.abs(ref["u"]).max()),
                 "N": float(np.abs(res.internal[:, :nM] - ref["N"][None]).max() / np.abs(ref["N"]).max()),
                 "trusses_checked": int(res.displace.shape[0])}
+        # The legs that drive SEVERAL streams (informational, N = 1) run last, each under a watchdog: this runtime has
+        # stopped multi-stream work on the device without an error (EXPERIMENTS R4.9) - if one of them does not come
+        # back, the line is printed without it and the process ends instead of hanging the caller.
+        if world == 1 and not args.no_pcie:
+            late = []
+            if isinstance(dataset, dict) and "value" in dataset:
+                late.append(("dataset.streamed", lambda: dataset_streamed_leg(args, device, dataset["value"]),
+                             lambda v: dataset.__setitem__("streamed", v)))
+            if isinstance(cube, dict) and "value" in cube:
+                late.append(("cube_batch.host_fed", lambda: host_fed_leg(args, device, torch, batch),
+                             lambda v: cube.__setitem__("host_fed", v)))
+            for name, run, put in late:
+                guard = LateLegWatchdog(line, name, args.late_leg_seconds)
+                try:
+                    put(run())
+                except Exception as exc:   # (an informational leg must not take the line down)
+                    put({"error": repr(exc)})
+                guard.done()
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
