@@ -1210,14 +1210,13 @@ class RaggedSolver:
         (e.g. from `generate.generate_cube_batch_device`), just its `BatchSizes`.  `workspace`: a
         `SolverWorkspace` shared with other solvers that run on the same stream one after the other.
 
-        `lanes` (default 1, `TRS_RAGGED_LANES`; resident batches only; OPT-IN): the buckets are dealt onto that many
-        streams - lane 0 is the caller's stream, the others fork from it at the start of `step()` and join it at the
-        end -, each lane with a workspace of its own, so that one bucket's kernels fill the tails (and the store-free
-        table set-up) of another's: 48.6 -> 45.3 ms per step of the 65 536-truss cube batch at the same memory
-        (`max_slab_bytes` bounds the slabs of ALL lanes together: a bucket gets at most `max_slab_bytes / lanes`).
-        Results are bit for bit those of one lane.  Not the default: with per-chunk solvers (`data.dataset_chunks`)
-        one run in ten stopped making progress on the device on this runtime (EXPERIMENTS R4.9, not understood);
-        a long-lived solver stepped repeatedly never did.
+        `lanes` (default 1, `TRS_RAGGED_LANES`; resident batches only): EXPERIMENTAL, DO NOT USE FOR RESULTS THAT MATTER.
+        The buckets are dealt onto that many streams - lane 0 is the caller's stream, the others fork from it at the
+        start of `step()` and join it at the end -, each lane with a workspace of its own inside `max_slab_bytes`, so
+        that one bucket's kernels fill the tails of another's: 48.6 -> 45.3 ms per step of the 65 536-truss cube batch.
+        On this runtime (ROCm 7.2, MI355X) concurrent launch sequences of this library have, once in a few dozen steps,
+        stalled the device or corrupted a burst of trusses across the lanes (a joint order that is no longer a
+        permutation, garbage displacements): EXPERIMENTS R4.9.  One lane - the default - never did.
 
         `host_io=(inputs, outputs)`: the batch STAYS in page-locked host memory - `inputs` / `outputs` are dicts of
         pinned CPU tensors (the padded arrays of a `PackedBatch.pinned()`; `u`, `f_ext`, `N`, `info` of a

@@ -202,17 +202,6 @@ def test_ragged_solver_matches_solve_batch_bitwise(gpu):
         np.testing.assert_array_equal(plain.result().displace, gpu.solve_batch(packed).displace)
 
 
-def test_ragged_solver_lanes_give_the_same_bits():
-    """`RaggedSolver(lanes=)` (opt-in: the buckets of a resident ragged batch dealt onto several streams) gives the
-    bits of one lane - checked in a process of its own (`tests/lanes_check.py`), so that its side streams never
-    share this process with the CU-masked streams of the host-fed tests below (EXPERIMENTS R4.9)."""
-    import subprocess
-    import sys
-    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lanes_check.py")
-    run = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
-    assert run.returncode == 0 and "lanes ok" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
-
-
 def test_copy_rows_gathers_and_scatters_prefixes(gpu):
     import ctypes
     import torch

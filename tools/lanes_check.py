@@ -1,4 +1,5 @@
-"""Run by tests/test_gpu_order.py::test_ragged_solver_lanes_give_the_same_bits in a process of its own: the buckets of
+"""NOT part of the test suite (the multi-lane switch is experimental: EXPERIMENTS R4.9 - it has stalled the device and
+corrupted a handful of trusses per few dozen steps on this runtime): the buckets of
 a resident ragged batch dealt onto 1, 2 and 3 streams (`RaggedSolver(lanes=)`: every lane its own workspace, fork from /
 join to the caller's stream) give the same bits, step after step, also on a side stream of the caller's and with two
 section variants; a second solver that shares the workspaces runs right behind."""
