@@ -475,17 +475,20 @@ def host_fed_leg(args, device, torch, batch):
     packed, tensors = cube_workload(args.cube_batch, 0, device=device)
     pinned, pool = packed.to_packed(tensors).pinned(), batch.ResultPool(tracked=True)   # (results are only read)
     for _ in range(2):
-        batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
+        first = batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
+    first_u, first_N = np.array(first.displace), np.array(first.internal)   # (the pool's arrays are re-used by the next call)
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
         got = batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
     dt = (time.perf_counter() - t0) / reps
+    # copy kernels and solver kernels share the device in this pipeline: the calls must still repeat each other bit for bit
+    repeat = bool(np.array_equal(first_u, got.displace, equal_nan=True) and np.array_equal(first_N, got.internal, equal_nan=True))
     nJ64, nM64 = packed.nJ.astype(np.int64), packed.nM.astype(np.int64)
     return {"solves_per_s": packed.B / dt, "ms_per_call": dt * 1e3,
             "h2d_live_bytes": int((nJ64 * 49 + nM64 * 24).sum()),
             "d2h_live_bytes": int((nJ64 * 48 + nM64 * 8).sum()) + 4 * packed.B,
-            "info_nonzero": int((got.info != 0).sum()),
+            "info_nonzero": int((got.info != 0).sum()), "calls_repeat_bitwise": repeat,
             "note": "host arrays in -> host results out per CALL of batch.solve_batch_streamed (set-up "
                     "included): buckets pulled over PCIe by the gather kernel (live bytes only), ordered "
                     "and solved on the device, results pushed into page-locked arrays; three ordinary "
