@@ -99,3 +99,25 @@ def test_cube_cpu_baseline_runs_on_a_fixed_sample_of_the_legs_batch():
     assert ratio is not None and 0.8 < ratio["ratio"] < 1.25      # the committed calibration against the real reference
     one = refs[0]
     assert one["u"].ndim == 2 and one["u"].shape[1] == 3 and np.isfinite(one["u"]).all() and np.abs(one["N"]).max() > 0
+
+
+def test_late_leg_watchdog_prints_the_line_and_ends_the_process():
+    """`bench.LateLegWatchdog`: a leg that never returns (a stalled device call does not come back to Python) must not
+    take the finished line down - the watchdog prints it with a note and ends the process with status 0; a leg that
+    returns in time leaves no trace."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import json, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "line = {'metric': 'm', 'value': 1.0}\n"
+        "g = bench.LateLegWatchdog(line, 'quick', 5.0); line['quick'] = 1; g.done()\n"
+        "g = bench.LateLegWatchdog(line, 'stuck', 0.3)\n"
+        "time.sleep(30)\n"
+        "print(json.dumps({'unreachable': True}))\n")
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=25)
+    assert run.returncode == 0
+    out = json.loads(run.stdout.strip().splitlines()[-1])
+    assert out["value"] == 1.0 and out["quick"] == 1 and "stuck" in out["watchdog"] and "unreachable" not in out
