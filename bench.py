@@ -634,28 +634,101 @@ def reference_protocol_leg():
     return out
 
 
+def repeat_stats(seconds, potrf_ms, steps, trusses_per_step):
+    """min / median / max over the repeats of the timed K-step region (each repeat bracketed like the contract's
+    region: barrier + synchronise on both sides, max over the ranks): ms per step, the whole-job rate, and the
+    dominant kernel's average launch of each repeat (events on the launch stream)."""
+    if not seconds:
+        return {"count": 0}
+    ms = sorted(s / steps * 1e3 for s in seconds)
+    med = lambda v: float(v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]))
+    pk = sorted(potrf_ms)
+    return {"count": len(ms), "steps_per_repeat": steps,
+            "ms_per_step": {"min": ms[0], "median": med(ms), "max": ms[-1]},
+            "value": {"min": trusses_per_step / (ms[-1] * 1e-3), "median": trusses_per_step / (med(ms) * 1e-3),
+                      "max": trusses_per_step / (ms[0] * 1e-3), "unit": "solves/s"},
+            "roofline_avg_launch_ms": {"min": pk[0], "median": med(pk), "max": pk[-1]},
+            "note": "further repeats of the same timed region right behind the first one (`value` / `ms_per_step` of "
+                    "the line are the FIRST region, as the contract asks)"}
+
+
 class LateLegWatchdog:
     """Armed around one late (multi-stream, informational) leg: if the leg has not finished after `seconds`, the line
-    assembled so far is printed - with a note naming the leg - and the process exits with status 0.  A stalled
-    device call never returns to Python, so nothing softer than `os._exit` can end it; everything the contract asks
-    for is in the line by then."""
+    assembled so far is printed - with a note naming the leg - and the process exits with status
+    `LateLegWatchdog.EXIT_STATUS` (3): a device call that never returns is a fault of the run, whatever the line
+    holds, and the caller must see it in the exit code.  A stalled device call never returns to Python, so nothing
+    softer than `os._exit` can end it; everything the contract asks for is in the line by then.
+    `put(key_setter)` is how the main thread stores the leg's result: it takes the same lock as the watchdog's dump,
+    so the line is never serialised while it is being changed, and never printed twice."""
+
+    EXIT_STATUS = 3
 
     def __init__(self, line, name, seconds):
         import threading
-        self._finished = threading.Event()
+        self._lock = threading.Lock()
+        self._finished = False
+        self._wake = threading.Event()
         self._thread = threading.Thread(target=self._watch, args=(line, name, float(seconds)), daemon=True)
         self._thread.start()
 
     def _watch(self, line, name, seconds):
-        if self._finished.wait(seconds):
+        if self._wake.wait(seconds):
             return
-        line["watchdog"] = (f"the informational leg `{name}` did not finish within {seconds:.0f} s (multi-stream work "
-                            "stalled on the device); the line was printed without it and the process ended")
-        print(json.dumps(line), flush=True)
-        os._exit(0)
+        with self._lock:
+            if self._finished:      # the leg came back at the deadline: the main thread prints the line
+                return
+            out = json.loads(json.dumps(line))   # (a copy: nothing below touches the caller's dict)
+            out["watchdog"] = (f"the informational leg `{name}` did not finish within {seconds:.0f} s (multi-stream "
+                               f"work stalled on the device); the line was printed without it and the process ended "
+                               f"with status {self.EXIT_STATUS}")
+            print(json.dumps(out), flush=True)
+            os._exit(self.EXIT_STATUS)
+
+    def put(self, store):
+        """Run `store()` (which writes the leg's result into the line) and disarm the watchdog, atomically with
+        respect to its dump."""
+        with self._lock:
+            store()
+            self._finished = True
+        self._wake.set()
 
     def done(self):
-        self._finished.set()
+        with self._lock:
+            self._finished = True
+        self._wake.set()
+
+
+def choose_timing_group(dist, torch, device, rank, world, ndev):
+    """The process group that carries the barrier around the timed region and the max-over-ranks of the elapsed time
+    (there is no collective on the data path), chosen COLLECTIVELY: gloo comes up first and is the control plane;
+    RCCL (backend "nccl") is tried only when every rank says over gloo that it is willing - it owns a GPU of its own
+    (RCCL refuses duplicate devices) and `TRS_BENCH_NO_RCCL_RANK` does not name it (the test hook that makes one rank
+    decline) -, and is used only when every rank says over gloo that its probe all-reduce went through.  Every rank
+    therefore takes the same branch: a rank whose RCCL set-up fails can no longer leave the others waiting in a
+    collective it never joins.  Returns (name, group or None = the default gloo group)."""
+    def agree(flag):   # minimum over the ranks, on the gloo control plane
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    declines = os.environ.get("TRS_BENCH_NO_RCCL_RANK", "")
+    willing = world <= ndev and str(rank) not in [r for r in declines.split(",") if r]
+    if not agree(willing):
+        return "gloo", None
+    ok, group = True, None
+    try:
+        group = dist.new_group(backend="nccl")
+        probe = torch.zeros([1], device=device)
+        dist.all_reduce(probe, group=group)
+        torch.cuda.synchronize(device)
+    except Exception as exc:  # pragma: no cover - needs a broken RCCL set-up
+        print(f"[bench rank {rank}] RCCL group failed ({exc!r})", file=sys.stderr)
+        ok = False
+    if agree(ok):
+        return "nccl", group
+    if rank == 0:
+        print("[bench] RCCL did not come up on every rank; timing over gloo", file=sys.stderr)
+    return "gloo", None
 
 
 def launch_ranks(n):
@@ -710,6 +783,9 @@ def main():
     ap.add_argument("--late-leg-seconds", type=float, default=180.0,
                     help="watchdog of each informational multi-stream leg (dataset.streamed, cube_batch.host_fed): after "
                          "this long the line is printed without the leg")
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="further repeats of the timed K-step region, right behind it, for the spread of the headline "
+                         "(`repeats`: min / median / max; the contract's `value` stays the FIRST region)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than visible GPUs (ranks share devices round-robin; for testing "
                          "the multi-rank path on a 1-GPU box - the line then reports the devices really used)")
@@ -752,39 +828,26 @@ def main():
     n_devices_used = min(world, ndev)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    timing_group = None
+    timing_group, tgroup = None, None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # The group carries ONLY the barrier around the timed region and the max-over-ranks of the
-        # elapsed time (no collective on the data path).  RCCL (backend "nccl") when every rank owns its
-        # GPU; gloo when ranks share a device (RCCL refuses duplicate devices) or RCCL cannot come up -
-        # a failure of the timing plumbing must not lose the measurement.
-        timing_group = "nccl" if world <= ndev else "gloo"
-        if timing_group == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=device)
-                probe = torch.zeros([1], device=device)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize(device)
-            except Exception as exc:  # pragma: no cover - needs a broken RCCL set-up
-                print(f"[bench rank {rank}] RCCL group failed ({exc!r}); timing over gloo", file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                timing_group = "gloo"
-        if timing_group == "gloo":
-            dist.init_process_group("gloo")
+        dist.init_process_group("gloo")
+        timing_group, tgroup = choose_timing_group(dist, torch, device, rank, world, ndev)
 
     def barrier():
         if distributed:
-            dist.barrier()
+            if timing_group == "nccl":
+                dist.barrier(group=tgroup, device_ids=[dev_index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(device)
 
     def reduce_max(seconds, op="max"):
         if not distributed:
             return seconds
         tmax = torch.tensor([seconds], dtype=torch.float64, device=device if timing_group == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN, group=tgroup)
         return float(tmax.item())
 
     packed = batch.pack_json([data]).replicate(args.batch)
@@ -824,6 +887,18 @@ def main():
         step(potrf_events=potrf_events[k])
     barrier()
     elapsed = time.perf_counter() - t0
+    potrf_ms_timed = float(np.mean([e0.elapsed_time(e1) for e0, e1 in potrf_events]))
+    # the spread of the headline: the same K-step region again and again (same calls, same brackets; the events of
+    # the first region are recorded over - their times are taken already), max over the ranks per repeat
+    repeat_s, repeat_potrf_ms = [], []
+    for _ in range(max(0, args.repeats)):
+        barrier()
+        t0r = time.perf_counter()
+        for k in range(args.steps):
+            step(potrf_events=potrf_events[k])
+        barrier()
+        repeat_s.append(reduce_max(time.perf_counter() - t0r))
+        repeat_potrf_ms.append(float(np.mean([e0.elapsed_time(e1) for e0, e1 in potrf_events])))
     all_events = [[(new_event(), new_event()) for _ in STAGES] for _ in range(args.steps)]
     for k in range(args.steps):
         step(all_events[k])
@@ -834,7 +909,6 @@ def main():
 
     stage_ms = {s: float(np.mean([all_events[k][i][0].elapsed_time(all_events[k][i][1])
                                   for k in range(args.steps)])) for i, s in enumerate(STAGES)}
-    potrf_ms_timed = float(np.mean([e0.elapsed_time(e1) for e0, e1 in potrf_events]))
     res = dev.result()
 
     # reference point outside the timed region (rank 0): the same kernels with the envelope switched
@@ -1042,6 +1116,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "rank_ms_per_step": {"min": elapsed_min / args.steps * 1e3, "max": elapsed / args.steps * 1e3},
+            "repeats": repeat_stats(repeat_s, repeat_potrf_ms, args.steps, world * args.batch),
             "host_threads_per_rank": host_threads,
             "higher_is_better": True,
             "scaling": "weak",
@@ -1125,10 +1200,10 @@ def main():
             for name, run, put in late:
                 guard = LateLegWatchdog(line, name, args.late_leg_seconds)
                 try:
-                    put(run())
+                    value = run()
                 except Exception as exc:   # (an informational leg must not take the line down)
-                    put({"error": repr(exc)})
-                guard.done()
+                    value = {"error": repr(exc)}
+                guard.put(lambda: put(value))
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

@@ -1080,15 +1080,29 @@ def shared_workspace(torch, device):
     one call's factorisation from the next call's assembly -, hence one workspace per stream: calls issued on
     different streams of a device (or from threads with different current streams) get different buffers.  Two
     threads that drive the SAME stream must serialise their calls themselves, as for any other stream-ordered
-    resource."""
+    resource.
+
+    The cache is BOUNDED: at most `MAX_SHARED_WORKSPACES` (4; a workspace is up to tens of GB) live at a time, the
+    least recently used one is dropped when a further stream asks (its buffers go back to the caching allocator once
+    the solvers built on it are gone; kernels still queued on them keep them alive through the allocator's
+    stream-ordered reuse, as for any freed tensor).  A stream handle value that comes back after its stream was
+    destroyed inherits the old entry - harmless: a destroyed stream has no work left, and the buffers carry no state
+    between calls."""
     key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
-    if key not in _SHARED_WORKSPACES:
-        _SHARED_WORKSPACES[key] = SolverWorkspace(torch, device)
-    return _SHARED_WORKSPACES[key]
+    ws = _SHARED_WORKSPACES.pop(key, None)
+    if ws is None:
+        ws = SolverWorkspace(torch, device)
+        while len(_SHARED_WORKSPACES) >= MAX_SHARED_WORKSPACES:
+            _SHARED_WORKSPACES.pop(next(iter(_SHARED_WORKSPACES)))     # (dicts keep insertion order: the oldest use)
+    _SHARED_WORKSPACES[key] = ws                                       # most recently used last
+    return ws
+
+
+MAX_SHARED_WORKSPACES = 4
 
 
 def release_workspaces():
-    """Drop the shared workspaces of every device (they hold the largest slab a call on that device needed, up to
+    """Drop the shared workspaces of every device and stream (they hold the largest slab a call needed, up to
     48 GB, for the life of the process) and hand the cached blocks back to the driver."""
     import torch
     _SHARED_WORKSPACES.clear()

@@ -149,33 +149,55 @@ struct Tables {
 template <bool SORTED>
 __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last_begin) {
     const int tid = threadIdx.x;
-    int* tail_next = t.ctrl;  // [0]
+    // Joints discovered per level: THREE counters taken in turn (level d adds to found_cnt[d % 3]).  The unsorted
+    // sweeps have one barrier per level, so a thread may read its level's count while faster waves are already
+    // adding to the next level's: with a single running counter such a thread saw a tail that included joints of
+    // the level after - its loop bounds then differed from its work-group's, it walked queue entries nobody had
+    // written yet and the barriers fell out of step (a joint order that is no permutation, stores through garbage
+    // indices: what concurrent kernels on other streams, which pull the waves of a work-group apart, brought out -
+    // EXPERIMENTS R5.1).  Counter (d + 1) % 3 is cleared during level d: its last readers read it behind the
+    // barrier of level d - 2 and have all passed the barrier of level d - 1 since.
+    // (-DTRS_EXP_ORDER_SINGLE_COUNTER, tools/repro_streams.cpp only: the ONE running counter of rounds 3-4, kept so
+    // that the reproducer can show the fault and its cure with the same sources)
+    int* found_cnt = t.ctrl;  // [0 .. 2]
     if constexpr (SORTED)
         for (int j = tid; j < nj; j += NT) t.ppos[j] = 0x7fffffff;
     if (tid == 0) {
         t.queue[0] = (unsigned short)root;
         t.lvl[root] = stamp;
-        *tail_next = 1;
+#ifdef TRS_EXP_ORDER_SINGLE_COUNTER
+        found_cnt[0] = 1;
+#else
+        found_cnt[0] = 0;
+#endif
     }
     __syncthreads();
     unsigned short* found = SORTED ? t.nextq : t.queue;  // a sorted level is copied into the queue by rank
-    int head = 0, tail = 1, depth = 0, begin = 0;
+    int head = 0, tail = 1, depth = 0, begin = 0, turn = 0;
     const int sub = tid & 3;
     while (head < tail) {
         begin = head;
         const int mark = stamp + depth + 1;
+#ifdef TRS_EXP_ORDER_SINGLE_COUNTER
+        int* my_cnt = found_cnt;
+        const int next_turn = 0, slot0 = 0;
+#else
+        int* my_cnt = found_cnt + turn;
+        const int next_turn = turn == 2 ? 0 : turn + 1, slot0 = tail;
+        if (tid == 0) found_cnt[next_turn] = 0;
+#endif
         for (int i = head + (tid >> 2); i < tail; i += NT / 4) {
             const int v = t.queue[i];
             const int e1 = t.start[v + 1];
             for (int e = t.start[v] + sub; e < e1; e += 4) {
                 const int w = t.adj[e];
                 const int old = atomicMax(&t.lvl[w], mark);
-                if (old < stamp) found[atomicAdd(tail_next, 1)] = (unsigned short)w;          // first to reach w
+                if (old < stamp) found[slot0 + atomicAdd(my_cnt, 1)] = (unsigned short)w;      // first to reach w
                 if (SORTED && (old < stamp || old == mark)) atomicMin(&t.ppos[w], i);          // w's earliest parent
             }
         }
         __syncthreads();
-        const int new_tail = *tail_next;
+        const int new_tail = slot0 + *my_cnt;
         if constexpr (SORTED) {
             const int m = new_tail - tail;
             if (m > 1) {
@@ -198,6 +220,7 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
         }
         head = tail;
         tail = new_tail;
+        turn = next_turn;
         ++depth;
     }
     *last_begin = begin;

@@ -51,17 +51,64 @@ def _same_host(group):
     return all(n == names[0] and n[1] != -1 for n in names)
 
 
+def _shm_files(shapes, headroom=64 << 20):
+    """Rank 0 of `gather_results`: four files of the full-batch shapes in /dev/shm with their pages allocated, or None
+    when /dev/shm has no room for them (a container's default tmpfs is 64 MB; 65 536 cube trusses are 2.2 GB) -
+    whatever was created is removed again."""
+    import tempfile
+    sizes = [int(np.prod([max(1, d) for d in shape])) * np.dtype(dt).itemsize for shape, dt in shapes]
+    paths = []
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize < sum(sizes) + headroom:
+            return None
+        for nbytes in sizes:
+            fd, path = tempfile.mkstemp(prefix="trs_gather_", dir="/dev/shm")
+            paths.append(path)
+            try:
+                # the pages are allocated (zeroed) HERE, in one call: ranks that fault fresh pages of one tmpfs
+                # file in at the same time serialise on it (measured: 1.8 s instead of 0.3 s for 0.55 GB)
+                os.posix_fallocate(fd, 0, nbytes)
+            finally:
+                os.close(fd)
+        return paths
+    except OSError:
+        for path in paths:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return None
+
+
+def _map_file(path, shape, dtype, private):
+    """The file as an array: shared (this rank's writes reach the file) or private (copy-on-write: the file's pages
+    are read as they are, a write touches a private copy of its page only)."""
+    import mmap
+    shape1 = tuple(max(1, d) for d in shape)
+    fd = os.open(path, os.O_RDWR)
+    try:
+        mm = mmap.mmap(fd, int(np.prod(shape1)) * np.dtype(dtype).itemsize,
+                       flags=mmap.MAP_PRIVATE if private else mmap.MAP_SHARED, prot=mmap.PROT_READ | mmap.PROT_WRITE)
+    finally:
+        os.close(fd)
+    return np.frombuffer(mm, dtype=dtype).reshape(shape1)[tuple(slice(0, d) for d in shape)]
+
+
 def gather_results(local: BatchResult, idx, total, group=None, widths=None):
     """Reassemble the full-batch dense results on every rank.  `widths` = (nJ_max, nM_max) of the full batch
     (every rank holds the same `packed`, so `solve_batch_distributed` passes them; else they are agreed on first).
 
-    Ranks of ONE host (the case this package is built for: the GPUs of one node): rank 0 creates four files of
-    the full-batch shapes in /dev/shm (fresh pages are zero = the result padding), every rank maps them
-    (`numpy.memmap`) and writes ITS rows, and every rank returns arrays that are views of the same memory - no
-    pickling, no copy of another rank's rows, nothing left in /dev/shm (the names are unlinked once every rank has
-    mapped them; the memory lives until the last array is dropped, the mapping being the array's base object).
-    65 536 cube trusses (2.2 GB of results): one memcpy of each rank's share.
-    Across hosts: one `all_gather` of a contiguous float64 buffer per rank (no Python objects)."""
+    Ranks of ONE host (the case this package is built for: the GPUs of one node) with room in /dev/shm: rank 0
+    creates four files of the full-batch shapes there (fresh pages are zero = the result padding), every rank maps
+    them shared and writes ITS rows, and every rank returns arrays mapped PRIVATELY (copy-on-write) from the same
+    files - no pickling, no copy of another rank's rows, an in-place edit on one rank stays on that rank, and nothing
+    is left in /dev/shm (the names are unlinked once every rank has its mapping; the memory lives until the last
+    array is dropped).  65 536 cube trusses (2.2 GB of results): one memcpy of each rank's share.
+    The choice is made COLLECTIVELY: rank 0 checks the room and allocates, and broadcasts the file names or None -
+    then every rank takes the path below.
+    Across hosts, or without room in /dev/shm: one `all_gather` of a contiguous float64 buffer per rank (no Python
+    objects)."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -73,54 +120,42 @@ def gather_results(local: BatchResult, idx, total, group=None, widths=None):
     shapes = (([total, nJ, 3], np.float64), ([total, nJ, 3], np.float64), ([total, nM], np.float64), ([total], np.int32))
     parts = (local.displace, local.external, local.internal, local.info)
     if _same_host(group):
-        import tempfile
-        paths = [None] * 4
-        if rank == 0:
-            for k in range(4):
-                fd, paths[k] = tempfile.mkstemp(prefix="trs_gather_", dir="/dev/shm")
-                os.close(fd)
-        dist.broadcast_object_list(paths, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        try:
-            if rank == 0:   # sizes the files; the others map what exists
-                views = []
-                for path, (shape, dt) in zip(paths, shapes):
-                    shape1 = tuple(max(1, d) for d in shape)
-                    # the pages are allocated (zeroed) HERE, in one call: ranks that fault fresh pages of one
-                    # tmpfs file in at the same time serialise on it (measured: 1.8 s instead of 0.3 s for 0.55 GB)
-                    with open(path, "r+b") as fh:
-                        os.posix_fallocate(fh.fileno(), 0, int(np.prod(shape1)) * np.dtype(dt).itemsize)
-                    views.append(np.memmap(path, dtype=dt, mode="r+", shape=shape1))
-            dist.barrier(group)
-            if rank != 0:
-                views = [np.memmap(path, dtype=dt, mode="r+", shape=tuple(max(1, d) for d in shape))
-                         for path, (shape, dt) in zip(paths, shapes)]
-            dist.barrier(group)               # every rank has mapped the files:
-        finally:
-            if rank == 0:
-                for path in paths:            # the names can go (nothing stays in /dev/shm whatever happens next)
-                    try:
-                        os.unlink(path)
-                    except OSError:
-                        pass
-        views = [np.asarray(v)[tuple(slice(0, d) for d in shape)] for v, (shape, _) in zip(views, shapes)]
-        for view, part in zip(views, parts):
-            if part.ndim == 1:
-                view[idx] = part
-            else:
-                view[idx, :part.shape[1]] = part
-        dist.barrier(group)               # every rank's rows are in place
-        return BatchResult(views[0], views[1], views[2], views[3])
-    # several hosts: one contiguous buffer per rank (rows padded to the largest shard), gathered as tensors
+        box = [_shm_files(shapes) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        paths = box[0]
+        if paths is not None:
+            try:
+                for path, (shape, dt), part in zip(paths, shapes, parts):
+                    view = _map_file(path, shape, dt, private=False)
+                    if part.ndim == 1:
+                        view[idx] = part
+                    else:
+                        view[idx, :part.shape[1]] = part
+                    del view
+                dist.barrier(group)               # every rank's rows are in the files
+                views = [_map_file(path, shape, dt, private=True) for path, (shape, dt) in zip(paths, shapes)]
+                dist.barrier(group)               # every rank has its mapping:
+            finally:
+                if rank == 0:
+                    for path in paths:            # the names can go (nothing stays in /dev/shm whatever happens next)
+                        try:
+                            os.unlink(path)
+                        except OSError:
+                            pass
+            return BatchResult(views[0], views[1], views[2], views[3])
+    # several hosts (or no room in /dev/shm): one contiguous buffer per rank (rows padded to the largest shard),
+    # gathered as tensors
     counts = [None] * world
     dist.all_gather_object(counts, len(idx), group=group)
     cmax, width = max(counts + [1]), 6 * nJ + nM + 2
     buf = np.zeros([cmax, width])
     k = len(idx)
+    wJ, wM = int(local.displace.shape[1]), int(local.internal.shape[1])
     buf[:k, 0] = idx
     buf[:k, 1] = local.info
-    buf[:k, 2:2 + 3 * local.displace.shape[1]] = local.displace.reshape(k, -1)
-    buf[:k, 2 + 3 * nJ:2 + 3 * nJ + 3 * local.external.shape[1]] = local.external.reshape(k, -1)
-    buf[:k, 2 + 6 * nJ:2 + 6 * nJ + local.internal.shape[1]] = local.internal
+    buf[:k, 2:2 + 3 * wJ] = local.displace.reshape(k, 3 * wJ)          # (k may be 0: an empty shard)
+    buf[:k, 2 + 3 * nJ:2 + 3 * nJ + 3 * wJ] = local.external.reshape(k, 3 * wJ)
+    buf[:k, 2 + 6 * nJ:2 + 6 * nJ + wM] = local.internal
     on_gpu = dist.get_backend(group) == "nccl"
     mine = torch.from_numpy(buf)
     if on_gpu:

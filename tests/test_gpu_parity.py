@@ -429,10 +429,12 @@ def test_property_checks_at_full_batch(gpu):
         <= 1e-9 * np.abs(res.displace).max()
 
 
-def _strip_truss_json(n_joints, seed, extra_pin=False, dim=2):
+def _strip_truss_json(n_joints, seed, extra_pin=False, dim=2, rollers=0):
     """A triangulated strip (Warren-like) of `n_joints` joints with a pin, a roller and random loads:
-    n_free = 2 n_joints - 3 (or - 4 with a second pin) in 2D, so every system size can be hit; in 3D
-    the strip is braced by two extra rows of joints."""
+    n_free = 2 n_joints - 3 (or - 4 with a second pin) in 2D, so every system size can be hit.
+    dim=3: a triangulated TOWER - the joints on a jittered helix, the first three pinned, every further joint tied
+    to the three before it (a Henneberg step: rigid), `rollers` (0..2) of the last joints on a one-axis roller:
+    n_free = 3 (n_joints - 3) - rollers, i.e. every size from 2 up (1 does not exist in 3D: a joint frees 3, 2 or 0)."""
     rng = np.random.default_rng(seed)
     if dim == 2:
         xy = [[50.0 * i + rng.uniform(-5, 5), (60.0 if i % 2 else 0.0) + rng.uniform(-5, 5)] for i in range(n_joints)]
@@ -444,7 +446,53 @@ def _strip_truss_json(n_joints, seed, extra_pin=False, dim=2):
         forces = [[j, [float(rng.uniform(-1e3, 1e3)), float(rng.uniform(-1e3, 1e3))]]
                   for j in range(1, n_joints - 1) if joints[j][1] == "NO" and rng.random() < 0.7]
         return {"joint": joints, "force": forces, "member": members}
-    raise NotImplementedError
+    assert dim == 3 and n_joints >= 4 and 0 <= rollers <= min(2, n_joints - 4 + 1) and (rollers < 2 or n_joints >= 5)
+    joints = [[[float(100.0 * np.cos(2.1 * i) + rng.uniform(-5, 5)), float(100.0 * np.sin(2.1 * i) + rng.uniform(-5, 5)),
+                float(25.0 * i + rng.uniform(-3, 3))], "NO"] for i in range(n_joints)]
+    for j in range(3):
+        joints[j][1] = "PIN"
+    for k in range(rollers):
+        joints[n_joints - 1 - k][1] = ("ROLLER_Z", "ROLLER_X")[k]
+    members = [[[i - d, i], [float(rng.uniform(0.5, 2.0)), 1e7, 0.1]]
+               for i in range(1, n_joints) for d in (1, 2, 3) if i - d >= 0]
+    forces = [[j, [float(rng.uniform(-1e3, 1e3)) for _ in range(3)]]
+              for j in range(3, n_joints) if joints[j][1] == "NO" and rng.random() < 0.7]
+    if not forces:   # (a load on a roller joint: its free axes carry it)
+        forces = [[n_joints - 1, [100.0, -50.0, 25.0]]]
+    return {"joint": joints, "force": forces, "member": members}
+
+
+def test_every_3d_system_size_through_the_small_and_the_staged_path(gpu):
+    """The 3D counterpart of the sweep below (the every-size sweeps were 2D only): tower trusses with
+    n_free = 2 ... 201 - every residue modulo 16 and 64, in particular 15 / 16 / 17, 63 / 64 / 65, 127 / 128 / 129 -
+    as one ragged batch through `solve_batch` (the sizes up to 128 take the fused small-system kernel, the others the
+    staged pipeline: natural order, device order, RCM) and once more with EVERY size forced through the staged
+    pipeline; each truss against the oracle."""
+    from python_stable_3d_truss_analysis_amd import batch
+    cases = [_strip_truss_json(nj, seed=3 * nj + r, dim=3, rollers=r)
+             for nj in range(4, 71) for r in (0, 1, 2) if not (nj == 4 and r == 2)]
+    packed = batch.pack_json(cases)
+    sizes = sorted(set(int(v) for v in packed.n_free))
+    assert sizes == list(range(2, 202))
+    refs = [orc.solve(data) for data in cases]
+
+    def check(res, tag):
+        assert not res.info.any(), tag
+        for b, (data, ref) in enumerate(zip(cases, refs)):
+            nJ, nM = len(data["joint"]), len(data["member"])
+            assert H.max_scaled_err(res.displace[b, :nJ], ref["u"]) <= 1e-8, (b, tag)
+            assert H.max_scaled_err(res.external[b, :nJ], ref["f_ext"]) <= 1e-8, (b, tag)
+            assert H.max_scaled_err(res.internal[b, :nM], ref["N"]) <= 1e-8, (b, tag)
+
+    for reorder in (False, True, "rcm"):
+        check(batch.solve_batch(packed, reorder=reorder), reorder)
+    staged = gpu.DeviceBatch(packed, use_small=False)      # one padded batch, every size on the staged kernels
+    assert not staged.small
+    staged.solve()
+    check(staged.result(), "staged")
+    ordered = gpu.DeviceBatch(packed, use_small=False, reorder=True)
+    ordered.solve()
+    check(ordered.result(), "staged, device order")
 
 
 def test_every_system_size_around_the_tile_and_panel_boundaries(gpu):

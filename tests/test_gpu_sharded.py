@@ -85,6 +85,7 @@ def test_spmd_two_ranks_real_solver(tmp_path):
         assert not z["info"].any()
 
 
+@pytest.mark.timeout(700)
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts two ranks itself and rank 0 prints
     the one JSON line (n_gpus = the devices really used: 2 on a multi-GPU box, 1 when shared)."""
@@ -112,8 +113,32 @@ def test_bench_launches_its_own_ranks():
     assert set(cube["stages_ms"]) >= {"order", "solve"}   # (gather / scatter launches only for the small-system bucket)
     assert line["dataset"]["value"] > 0 and line["dataset"]["info_nonzero_rank0"] == 0
     assert line["dataset"]["rank0_samples"] == 512
+    assert line["timing_group"] in ("nccl", "gloo")
 
 
+@pytest.mark.timeout(500)
+def test_bench_two_ranks_one_declines_rccl():
+    """The RCCL-failure branch of the timing group: rank 1 is made to decline RCCL
+    (`TRS_BENCH_NO_RCCL_RANK=1`); both ranks must end up on gloo - chosen collectively, nobody waits in an RCCL
+    collective - and the run must finish with its one line."""
+    import torch
+    ndev = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TRS_BENCH_NO_RCCL_RANK"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "128", "--no-cpu-baseline", "--no-pcie", "--cube-batch", "0", "--dataset-samples", "0",
+           "--no-dense-ref"]
+    if ndev < 2:
+        cmd.append("--oversubscribe")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["ranks"] == 2 and line["timing_group"] == "gloo" and line["value"] > 0 and line["info_nonzero"] == 0
+
+
+@pytest.mark.timeout(1000)
 def test_bench_eight_ranks_smoke():
     """What the driver's scaling run does at N = 8, made boring beforehand: `bench.py --gpus 8` (ranks sharing the
     box's GPU(s) where there are fewer than eight: --oversubscribe) with tiny workloads - eight processes come up,

@@ -120,9 +120,17 @@ def _gather_worker(rank, world, port, total, nJ, nM, same_host, out_dir):
     from python_stable_3d_truss_analysis_amd import batch, shard
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    if not same_host:
+    if same_host is False:
         shard._same_host = lambda group: False       # the several-hosts path: contiguous tensors, no objects
+    elif same_host == "full":
+        shard._shm_files = lambda shapes, headroom=0: None   # /dev/shm without room: rank 0 says so, ALL fall back
     idx = np.arange(rank, total, world)
+    if same_host == "empty" and rank == 1:
+        idx = idx[:0]                                # a rank with an empty shard (fewer trusses than ranks)
+        shard._same_host = lambda group: False
+    elif same_host == "empty":
+        idx = np.arange(total)
+        shard._same_host = lambda group: False
     rng = np.random.default_rng(rank)
     # ragged widths per rank, as the shards of a real batch have them
     local = batch.BatchResult(rng.random([len(idx), nJ - rank, 3]), rng.random([len(idx), nJ - rank, 3]),
@@ -134,11 +142,20 @@ def _gather_worker(rank, world, port, total, nJ, nM, same_host, out_dir):
     ok = True
     for r in range(world):                       # every rank sees every rank's rows, padding zero
         ridx = np.arange(r, total, world)
+        if same_host == "empty":
+            ridx = np.arange(total) if r == 0 else np.arange(0)
         g = np.random.default_rng(r)
         u, f, n = g.random([len(ridx), nJ - r, 3]), g.random([len(ridx), nJ - r, 3]), g.random([len(ridx), nM - 2 * r])
         ok &= np.array_equal(full.displace[ridx, :nJ - r], u) and not full.displace[ridx, nJ - r:].any()
         ok &= np.array_equal(full.external[ridx, :nJ - r], f) and np.array_equal(full.internal[ridx, :nM - 2 * r], n)
         ok &= not full.internal[ridx, nM - 2 * r:].any() and np.array_equal(full.info[ridx], (ridx % 7 == 0).astype(np.int32))
+    dist.barrier()
+    # an in-place edit on one rank stays on that rank (the shared-memory path maps the files copy-on-write)
+    if rank == 0 and total:
+        full.displace[0, 0, 0] = -123.0
+    dist.barrier()
+    if rank == 1 and total:
+        ok &= full.displace[0, 0, 0] != -123.0
     dist.barrier()
     with open(os.path.join(out_dir, f"g{rank}.txt"), "w") as fh:
         fh.write(f"{int(ok)} {dt}\n")
@@ -149,11 +166,43 @@ def test_gather_results_through_shared_memory_and_as_tensors(tmp_path):
     """`gather_results` ships no Python objects: ranks of one host write their rows into memory-mapped files
     that are unlinked before the call returns (a quarter of config 3's result set here: 0.55 GB, well under a
     second), ranks of several hosts gather one contiguous tensor each."""
-    for same_host, total in ((True, 16384), (False, 512)):
+    # (True: memory-mapped files; False: several hosts; "full": one host whose /dev/shm has no room - decided by rank 0
+    # for everybody; "empty": a rank without a single truss on the tensor path)
+    for same_host, total in ((True, 16384), (False, 512), ("full", 512), ("empty", 64)):
         mp.spawn(_gather_worker, args=(2, _free_port(), total, 343, 2100, same_host, str(tmp_path)), nprocs=2, join=True)
         for rank in range(2):
             ok, dt = open(tmp_path / f"g{rank}.txt").read().split()
             assert ok == "1"
-            if same_host:
+            if same_host is True:
                 assert float(dt) < 6.0, f"gather of 0.55 GB took {dt} s"   # (0.3 s on a quiet box; page reclaim of a busy container can cost seconds)
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("trs_gather_")]
+
+
+def _timing_group_worker(rank, world, port, out_dir, pretend_gpus):
+    import json
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["TRS_BENCH_NO_RCCL_RANK"] = "1"          # rank 1 declines RCCL; rank 0 would be willing
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    name, group = bench.choose_timing_group(dist, torch, torch.device("cpu"), rank, world, pretend_gpus)
+    # the chosen group works: barrier + the max of the elapsed times, as bench.py uses it
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    dist.barrier()
+    with open(os.path.join(out_dir, f"tg{rank}.json"), "w") as fh:
+        json.dump({"name": name, "default_group": group is None, "max": float(t.item())}, fh)
+    dist.destroy_process_group()
+
+
+def test_timing_group_is_chosen_collectively(tmp_path):
+    """`bench.choose_timing_group`: one rank that cannot / will not use RCCL takes EVERY rank to
+    gloo - decided over the gloo control plane before anybody enters an RCCL call, so no rank is left waiting in a
+    collective the other never joins.  Two ranks on CPU, both pretending to own a GPU; rank 1 declines."""
+    import json
+    mp.spawn(_timing_group_worker, args=(2, _free_port(), str(tmp_path), 2), nprocs=2, join=True)
+    for rank in range(2):
+        with open(tmp_path / f"tg{rank}.json") as fh:
+            rec = json.load(fh)
+        assert rec == {"name": "gloo", "default_group": True, "max": 2.0}
