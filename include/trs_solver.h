@@ -43,9 +43,20 @@
  *    never exists in dense form in HBM.  Without the flag every matrix goes through the slab (the default:
  *    measured faster end to end, EXPERIMENTS.md Part II section 3.3 and R4.1).
  *
- * Thread safety: the library keeps NO mutable process-wide state.  Everything that selects a kernel or a data
- * path is an argument of the call (flags / hints below), so concurrent calls on distinct streams with distinct
- * buffers do not interact.
+ * Streams and threads: the library keeps NO mutable process-wide state that a result depends on (the only static
+ * data are "dynamic-LDS ceiling raised" markers of kernels, set once).  Everything that selects a kernel or a data
+ * path is an argument of the call (flags / hints below), every kernel works on the buffers of its call only, and no
+ * kernel assumes anything about what else runs on the device: CONCURRENT CALLS ON DISTINCT STREAMS WITH DISTINCT
+ * BUFFERS DO NOT INTERACT, and their results are bit for bit those of the same calls issued one after the other.
+ * This clause is tested: tools/repro_streams.cpp (a plain HIP program: hipMalloc, hipStream_t and this header, no
+ * tensor library) runs the launch sequences of a ragged batch's size buckets on two to five streams, compares every
+ * step truss by truss with a one-stream step and checks every joint order for being a permutation
+ * (tests/test_gpu_streams.py; 200 steps per test).  Rounds 3-4 of this library violated it: a work-group race in
+ * trs_joint_order's kernel (a breadth-first level counter read while faster waves already advanced it) that only
+ * concurrent kernels on other streams, which pull the waves of a work-group apart, brought out - wrong joint orders,
+ * stores through garbage indices into other calls' buffers, device stalls (EXPERIMENTS.md R4.9, R5.1).
+ * Calls that share a buffer (one workspace used by several calls) are ordered by the stream they are issued on, as
+ * for any stream-ordered resource; two host threads may call concurrently as long as their buffers are distinct.
  */
 #ifndef TRS_SOLVER_H
 #define TRS_SOLVER_H

@@ -1061,6 +1061,9 @@ class SolverWorkspace:
 
 _SHARED_WORKSPACES = {}
 _LANE_STREAMS = {}
+#: streams a resident `RaggedSolver` deals its buckets onto unless told otherwise (`lanes=`), and the slab budget per lane
+DEFAULT_LANES = 3
+LANE_SLAB_BYTES = 32 << 30
 
 
 def lane_streams(torch, device, count):
@@ -1218,19 +1221,22 @@ class RaggedSolver:
     GATHER = ("xyz", "conn", "E", "A", "cbits", "loads", "nJ", "nM")
     JOINT_ORDERED = ("xyz", "conn", "cbits", "loads")
 
-    def __init__(self, packed, device=None, reorder=True, max_slab_bytes=48 << 30, granularity=64,
+    def __init__(self, packed, device=None, reorder=True, max_slab_bytes=None, granularity=64,
                  options=None, tensors=None, workspace=None, host_io=None, n_variants=1, lanes=None):
         """`packed`: a `PackedBatch` (uploaded here) or, with `tensors` = the batch's device tensors by field name
         (e.g. from `generate.generate_cube_batch_device`), just its `BatchSizes`.  `workspace`: a
         `SolverWorkspace` shared with other solvers that run on the same stream one after the other.
 
-        `lanes` (default 1, `TRS_RAGGED_LANES`; resident batches only): EXPERIMENTAL, DO NOT USE FOR RESULTS THAT MATTER.
-        The buckets are dealt onto that many streams - lane 0 is the caller's stream, the others fork from it at the
-        start of `step()` and join it at the end -, each lane with a workspace of its own inside `max_slab_bytes`, so
-        that one bucket's kernels fill the tails of another's: 48.6 -> 45.3 ms per step of the 65 536-truss cube batch.
-        On this runtime (ROCm 7.2, MI355X) concurrent launch sequences of this library have, once in a few dozen steps,
-        stalled the device or corrupted a burst of trusses across the lanes (a joint order that is no longer a
-        permutation, garbage displacements): EXPERIMENTS R4.9.  One lane - the default - never did.
+        `lanes` (default `DEFAULT_LANES` = 3; resident batches only): the buckets are dealt onto that many streams -
+        lane 0 is the caller's stream, the others fork from it at the start of `step()` and join it at the end, so
+        a step still is ONE stream-ordered operation for the caller -, each lane with a workspace of its own, so that
+        one bucket's kernels fill the emptying-chip tails and the latency-bound phases of another's: 47.2 -> 44-45 ms
+        per step of the 65 536-truss cube batch.  Results are bit for bit those of one lane (asserted step by step:
+        `tests/test_gpu_streams.py`).  Rounds 3-4 had to keep this switched off - stalls and bursts of corrupted
+        trusses once in a few dozen steps; the cause was a race in `trs_joint_order`'s kernel that only concurrent
+        kernels brought out, found with the torch-free reproducer `tools/repro_streams.cpp` (EXPERIMENTS R5.1).
+        `max_slab_bytes` (default `LANE_SLAB_BYTES` = 32 GiB per lane, at most 60 % of the device's memory) is the
+        budget of all lanes together.
 
         `host_io=(inputs, outputs)`: the batch STAYS in page-locked host memory - `inputs` / `outputs` are dicts of
         pinned CPU tensors (the padded arrays of a `PackedBatch.pinned()`; `u`, `f_ext`, `N`, `info` of a
@@ -1295,7 +1301,10 @@ class RaggedSolver:
                          for _ in range(max(1, int(n_variants)))]
             first = self.outs[0]
             self.u, self.f_ext, self.N, self.info = first["u"], first["f_ext"], first["N"], first["info"]
-        n_lanes = 1 if self.host_io else max(1, int(lanes if lanes is not None else os.environ.get("TRS_RAGGED_LANES", "1")))
+        n_lanes = 1 if self.host_io else max(1, int(lanes if lanes is not None else DEFAULT_LANES))
+        if max_slab_bytes is None:
+            max_slab_bytes = min(n_lanes * LANE_SLAB_BYTES,
+                                 int(0.6 * torch.cuda.get_device_properties(dev).total_memory))
         # resident batches: groups cut at whole rounds of the factorisation kernel (3 waves x 4 SIMDs per CU in flight)
         quantum = 0 if self.host_io else 12 * int(torch.cuda.get_device_properties(dev).multi_processor_count)
         groups = size_buckets(packed, max_slab_bytes // n_lanes, granularity, quantum=quantum) if B else []
@@ -1822,9 +1831,9 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
             # a ragged batch that is on the device already and stays there: the resident bucket pipeline
             # (one-launch gathers and scatters, joint order per bucket, one workspace shared by all buckets and by
             # all calls on this device), one result set per section variant
-            solver = RaggedSolver(packed, dev, reorder=reorder, max_slab_bytes=min(max_slab_bytes, 48 << 30),
-                                  tensors=device_inputs, workspace=shared_workspace(torch, dev),
-                                  n_variants=len(variants))
+            solver = RaggedSolver(packed, dev, reorder=reorder, tensors=device_inputs,
+                                  max_slab_bytes=None if max_slab_bytes >= 64 << 30 else max_slab_bytes,
+                                  workspace=shared_workspace(torch, dev), n_variants=len(variants))
             solver.step(sections=variants)
             inputs = {f: device_inputs[f] for f in DeviceBatch.INPUT_FIELDS if f in device_inputs}
             results = [DeviceResult(o["u"], o["f_ext"], o["N"], o["info"], inputs) for o in solver.outs]

@@ -128,6 +128,10 @@ struct OrdStamp {
 };
 #endif
 
+#ifdef TRS_EXP_ORDER_RACE_PROBE   // tools/repro_streams.cpp: how often a thread WOULD have read a wrong level end (see bfs_sweep)
+__device__ unsigned long long g_ord_race_hits[2];   // [0] threads that read a moving count, [1] sweeps that saw one
+#endif
+
 struct Tables {
     unsigned char* nfr;
     int *deg, *start, *fill, *lvl, *ppos;
@@ -170,6 +174,12 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
 #else
         found_cnt[0] = 0;
 #endif
+#ifdef TRS_EXP_ORDER_RACE_PROBE
+        // A SHADOW of the single running counter of rounds 3-4 (ctrl[3]; every discovery bumps it as well).  The
+        // control flow follows the three counters; a thread whose read of the shadow, at the point where the old code
+        // read its counter, differs from the true level end would have taken a wrong `tail` there.  Counted, not acted on.
+        t.ctrl[3] = 1;
+#endif
     }
     __syncthreads();
     unsigned short* found = SORTED ? t.nextq : t.queue;  // a sorted level is copied into the queue by rank
@@ -193,11 +203,17 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
                 const int w = t.adj[e];
                 const int old = atomicMax(&t.lvl[w], mark);
                 if (old < stamp) found[slot0 + atomicAdd(my_cnt, 1)] = (unsigned short)w;      // first to reach w
+#ifdef TRS_EXP_ORDER_RACE_PROBE
+                if (old < stamp) atomicAdd(&t.ctrl[3], 1);
+#endif
                 if (SORTED && (old < stamp || old == mark)) atomicMin(&t.ppos[w], i);          // w's earliest parent
             }
         }
         __syncthreads();
         const int new_tail = slot0 + *my_cnt;
+#ifdef TRS_EXP_ORDER_RACE_PROBE
+        if (t.ctrl[3] != new_tail) atomicAdd(&g_ord_race_hits[0], 1ull);
+#endif
         if constexpr (SORTED) {
             const int m = new_tail - tail;
             if (m > 1) {
@@ -911,6 +927,17 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
 }
 
 }  // namespace
+
+#ifdef TRS_EXP_ORDER_RACE_PROBE
+extern "C" int trs_order_race_probe(unsigned long long* host_out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ord_race_hits), sizeof(g_ord_race_hits));
+    if (reset) {
+        unsigned long long zero[2] = {0, 0};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ord_race_hits), zero, sizeof(zero));
+    }
+    return rc;
+}
+#endif
 
 #ifdef TRS_ORDER_STAMPS
 extern "C" int trs_order_debug_stamps(unsigned long long* host_out, int reset) {

@@ -74,9 +74,22 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     int* cnt = reinterpret_cast<int*>(sh + 2 * ndof_max);  // [nJ_max]   member ends at a constrained joint
     int* start = cnt + nJ_max;                             // [nJ_max+1] exclusive scan of cnt
     int* ends = start + nJ_max + 1;                        // [2 nM_max] (member << 1) | end, grouped by joint
+    unsigned char* held = reinterpret_cast<unsigned char*>(ends + 2 * nM_max);   // [nJ_max] joint has a constrained axis
     const int* fi = free_index + (size_t)b * ndof_max;
     const double* F = loads + (size_t)b * ndof_max;
     const double* ufb = uf + (size_t)b * ld_uf;
+    const int members = nM[b];
+    // The end joints of a thread's first MR members stay in registers: both passes over the members need them (axial
+    // forces; grouping of the member ends at constrained joints), and the second read came from HBM again - with
+    // eight trusses per CU the first pass's lines are long gone from L2 (a third of this kernel's excess traffic).
+    constexpr int MR = 4;
+    int2 cjr[MR];
+    const int2* CNI = reinterpret_cast<const int2*>(conn + (size_t)b * 2 * nM_max);
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const int m = tid + 256 * r;
+        cjr[r] = m < members ? CNI[m] : int2{0, 0};
+    }
     // joint_out (optional): results of joint j go to row joint_out[b][j] of u / f_ext - a batch whose joints
     // were renumbered for a narrower envelope delivers its results in the caller's numbering at no cost.
     // STAGED: the map is applied by the final copy out of LDS; otherwise u and f ARE the output arrays and
@@ -90,17 +103,30 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         f[o] = r >= 0 ? F[d] : 0.0;  // constrained: reaction accumulated below (load ignored)
     }
     if constexpr (STAGED)
-        for (int j = tid; j < nJ_max; j += 256) cnt[j] = 0;
+        for (int j = tid; j < nJ_max; j += 256) {
+            cnt[j] = 0;
+            held[j] = j < joints ? (unsigned char)((fi[3 * j] < 0) | (fi[3 * j + 1] < 0) | (fi[3 * j + 2] < 0)) : (unsigned char)0;
+        }
     if constexpr (!STAGED) __threadfence_block();
     __syncthreads();
     const double* X = xyz + (size_t)b * ndof_max;
-    const int members = nM[b];
-    auto constrained = [&](int j) { return (fi[3 * j] < 0) | (fi[3 * j + 1] < 0) | (fi[3 * j + 2] < 0); };
-    for (int m = tid; m < nM_max; m += 256) {
+    auto constrained = [&](int j) {
+        if constexpr (STAGED) return (int)held[j];
+        else return (fi[3 * j] < 0) | (fi[3 * j + 1] < 0) | (fi[3 * j + 2] < 0);
+    };
+    auto ends_of = [&](int r, int m) {   // end joints of member m = tid + 256 r of this thread
+        int2 c = CNI[m < members ? m : 0];
+#pragma unroll
+        for (int q = 0; q < MR; ++q)
+            if (r == q) c = cjr[q];
+        return c;
+    };
+    for (int m = tid, r = 0; m < nM_max; m += 256, ++r) {
         const size_t mm = (size_t)b * nM_max + m;
         double axial = 0.0;
         if (m < members) {
-            const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
+            const int2 c = r < MR ? ends_of(r, m) : CNI[m];
+            const int j0 = c.x, j1 = c.y;
             const MemberGeom g = member_geom(X, j0, j1);
             axial = member_axial(g, E[mm] * A[mm], u, J(j0), J(j1));
             if constexpr (STAGED) {
@@ -136,9 +162,9 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         __syncthreads();
         for (int j = tid; j < joints; j += 256) cnt[j] = 0;  // reused as the fill cursor
         __syncthreads();
-        for (int m = tid; m < members; m += 256) {
-            const size_t mm = (size_t)b * nM_max + m;
-            const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
+        for (int m = tid, r = 0; m < members; m += 256, ++r) {
+            const int2 c = r < MR ? ends_of(r, m) : CNI[m];
+            const int j0 = c.x, j1 = c.y;
             if (constrained(j0)) ends[start[j0] + atomicAdd(&cnt[j0], 1)] = m << 1;
             if (constrained(j1)) ends[start[j1] + atomicAdd(&cnt[j1], 1)] = (m << 1) | 1;
         }
@@ -160,7 +186,8 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
             for (int i = 0; i < deg; ++i) {
                 const int m = list[i] >> 1, end = list[i] & 1;
                 const size_t mm = (size_t)b * nM_max + m;
-                const int j0 = conn[2 * mm], j1 = conn[2 * mm + 1];
+                const int2 c = CNI[m];
+                const int j0 = c.x, j1 = c.y;
                 const MemberGeom g = member_geom(X, j0, j1);
                 const double axial = member_axial(g, E[mm] * A[mm], u, j0, j1);
 #pragma unroll
@@ -238,9 +265,9 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
                                   const long long* out_rows, int nJ_out, int nM_out, const int* info_in,
                                   int* info_out) {
     if (B <= 0) return 0;
-    // u, f_ext (doubles) + member-end tables (ints)
+    // u, f_ext (doubles) + member-end tables (ints) + one "has a constrained axis" byte per joint
     const size_t lds = ((size_t)6 * nJ_max * sizeof(double) +
-                        ((size_t)2 * nJ_max + 1 + 2 * (size_t)nM_max) * sizeof(int) + 15) / 16 * 16;
+                        ((size_t)2 * nJ_max + 1 + 2 * (size_t)nM_max) * sizeof(int) + (size_t)nJ_max + 15) / 16 * 16;
     if (lds > 160 * 1024 || force_unstaged) {
         hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), 0, stream, xyz, conn, E, A, loads,
                            free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out, out_rows, nJ_out,

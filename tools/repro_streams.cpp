@@ -62,6 +62,7 @@ struct Api {
     decltype(&trs_joint_order_fits) order_fits;
     decltype(&trs_abi_version) abi;
     int (*bounds)(int, int, int, int, int, int*, int*);
+    int (*race_probe)(unsigned long long*, int);   // -DTRS_EXP_ORDER_RACE_PROBE builds only (else null)
 };
 
 template <typename T>
@@ -187,6 +188,7 @@ int main(int argc, char** argv) {
     SYM(slab_ld, "trs_slab_ld") SYM(slab_rows, "trs_slab_rows") SYM(env_ints, "trs_env_ints")
     SYM(work_bytes, "trs_assemble_work_bytes") SYM(order_fits, "trs_joint_order_fits") SYM(abi, "trs_abi_version")
 #undef SYM
+    api.race_probe = reinterpret_cast<decltype(api.race_probe)>(dlsym(h, "trs_order_race_probe"));
     api.bounds = reinterpret_cast<decltype(api.bounds)>(dlsym(hh, "trs_cubegen_bounds"));
     if (!api.bounds) { fprintf(stderr, "missing trs_cubegen_bounds\n"); return 2; }
 
@@ -432,7 +434,11 @@ int main(int argc, char** argv) {
         const long failed = std::count_if(hinfo.begin(), hinfo.end(), [](int v) { return v != 0; });
         printf("reference step (1 lane): %.1f ms, %ld trusses with a failed pivot\n", ref_ms, failed);
     }
-    // a second one-lane run must reproduce the reference bit for bit (the property the multi-lane runs are held to)
+    if (api.race_probe) {   // probe build: reads of a MOVING level counter in trs_joint_order's breadth-first sweeps
+        unsigned long long hits[2] = {0, 0};
+        TRS(api.race_probe(hits, 1));
+        printf("probe: %llu hazardous counter reads in the 2 one-lane reference steps\n", hits[0]);
+    }
     setup_lanes(lanes);
     const unsigned long long noise_ticks = (unsigned long long)(ref_ms * 1.2 * 1e5);   // 100 MHz clock: 1e5 ticks per ms
     long bad_steps = 0, bad_trusses = 0, bad_perms = 0;
@@ -470,6 +476,12 @@ int main(int argc, char** argv) {
     }
     finished.store(1);
     watchdog.join();
+    if (api.race_probe) {
+        unsigned long long hits[2] = {0, 0};
+        TRS(api.race_probe(hits, 1));
+        printf("probe: %llu hazardous counter reads in %d steps (each one a thread that, with the single running counter of "
+               "rounds 3-4, would have taken a wrong level end)\n", hits[0], steps);
+    }
     printf("RESULT lanes=%d variants=%d noise=%d serial=%d steps=%d: %ld steps with differences, %ld truss results, "
            "%ld non-permutation orders\n", lanes, variants, noise, serial, steps, bad_steps, bad_trusses, bad_perms);
     return bad_steps ? 1 : 0;
