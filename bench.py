@@ -463,8 +463,9 @@ def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world,
             "device_generate_s": t_gen,
             "cpu_baseline": cpu[0] if cpu is not None else None,
             "max_rel_err_vs_oracle": check,
-            "note": "generated on the device, resident in generator order; one launch pipeline per size bucket on a "
-                    "shared workspace"}
+            "note": "generated on the device, resident in generator order; one launch pipeline per size bucket, the "
+                    "buckets dealt onto `lanes` streams (fork from / join into the caller's stream inside the step), a "
+                    "workspace per lane"}
 
 
 def host_fed_leg(args, device, torch, batch):
@@ -491,9 +492,9 @@ def host_fed_leg(args, device, torch, batch):
             "info_nonzero": int((got.info != 0).sum()), "calls_repeat_bitwise": repeat,
             "note": "host arrays in -> host results out per CALL of batch.solve_batch_streamed (set-up "
                     "included): buckets pulled over PCIe by the gather kernel (live bytes only), ordered "
-                    "and solved on the device, results pushed into page-locked arrays; three ordinary "
-                    "streams (TRS_PCIE_CUS=16,8 gives the copy kernels compute units of their own: opt-in); "
-                    "never the leg's value"}
+                    "and solved on the device, results pushed into page-locked arrays; three streams, "
+                    "the copy kernels on compute units of their own (CU masks, TRS_PCIE_CUS=16,8: the default "
+                    "again since the joint-order race of EXPERIMENTS R5.1 is fixed); never the leg's value"}
 
 
 def dataset_leg(args, device, torch, barrier, reduce_max, rank, world):

@@ -1062,8 +1062,8 @@ class SolverWorkspace:
 _SHARED_WORKSPACES = {}
 _LANE_STREAMS = {}
 #: streams a resident `RaggedSolver` deals its buckets onto unless told otherwise (`lanes=`), and the slab budget per lane
-DEFAULT_LANES = 3
-LANE_SLAB_BYTES = 32 << 30
+DEFAULT_LANES = 4
+LANE_SLAB_BYTES = 36 << 30
 
 
 def lane_streams(torch, device, count):
@@ -1175,14 +1175,15 @@ def _flow_shop_order(groups, packed, n_pad_of, rule="johnson"):
 
 
 def _pipeline_streams(torch, dev, lib):
-    """(pull, run, push) streams of `RaggedSolver`'s host-fed pipeline: three ordinary streams by default.
-    `TRS_PCIE_CUS="pull,push"` (e.g. "16,8" = two CUs per XCD for the pull, one for the push: the row copies reach the
-    link's rate on those, `tools/masked_pipeline_check.py`) sets compute units apart for the copy kernels through
-    CU-masked streams - 73 instead of 91 ms per host-fed call of the 65 536-truss cube batch, because the copies no
-    longer compete with the factorisation for registers on every CU - but OPT-IN: on this runtime processes that
-    use CU-masked streams die of memory access faults or hang once in five runs of the host-fed tests (ordinary
-    streams: once in twenty-six; EXPERIMENTS R4.9)."""
-    spec = os.environ.get("TRS_PCIE_CUS", "0")
+    """(pull, run, push) streams of `RaggedSolver`'s host-fed pipeline.  By default the copy kernels get compute units
+    of their own through CU-masked streams (`TRS_PCIE_CUS="pull,push"`, default "16,8" = two CUs per XCD for the pull,
+    one for the push: the row copies reach the link's rate on those, `tools/masked_pipeline_check.py`) and the solver
+    kernels the rest - 73 instead of 91 ms per host-fed call of the 65 536-truss cube batch, because the copies no
+    longer compete with the factorisation for registers on every CU.  `TRS_PCIE_CUS=0` = three ordinary streams.
+    (Round 4 had to make the masks opt-in: processes using them died of memory access faults or hung once in five
+    runs of the host-fed tests.  That was the joint-order kernel's race, which any concurrent kernel could bring out -
+    EXPERIMENTS R5.1; with it fixed, 36 of 36 runs of those tests with the masks passed.)"""
+    spec = os.environ.get("TRS_PCIE_CUS", "16,8")
     key = (str(dev), spec)
     if key not in _PIPELINE_STREAMS:   # (a queue with a CU mask takes ~20 ms to create: once per process and device)
         pull_cus, push_cus = int(spec.split(",")[0]), int(spec.split(",")[-1])
@@ -1227,15 +1228,15 @@ class RaggedSolver:
         (e.g. from `generate.generate_cube_batch_device`), just its `BatchSizes`.  `workspace`: a
         `SolverWorkspace` shared with other solvers that run on the same stream one after the other.
 
-        `lanes` (default `DEFAULT_LANES` = 3; resident batches only): the buckets are dealt onto that many streams -
+        `lanes` (default `DEFAULT_LANES` = 4; resident batches only): the buckets are dealt onto that many streams -
         lane 0 is the caller's stream, the others fork from it at the start of `step()` and join it at the end, so
         a step still is ONE stream-ordered operation for the caller -, each lane with a workspace of its own, so that
-        one bucket's kernels fill the emptying-chip tails and the latency-bound phases of another's: 47.2 -> 44-45 ms
+        one bucket's kernels fill the emptying-chip tails and the latency-bound phases of another's: 46.7 -> 43.8 ms
         per step of the 65 536-truss cube batch.  Results are bit for bit those of one lane (asserted step by step:
         `tests/test_gpu_streams.py`).  Rounds 3-4 had to keep this switched off - stalls and bursts of corrupted
         trusses once in a few dozen steps; the cause was a race in `trs_joint_order`'s kernel that only concurrent
         kernels brought out, found with the torch-free reproducer `tools/repro_streams.cpp` (EXPERIMENTS R5.1).
-        `max_slab_bytes` (default `LANE_SLAB_BYTES` = 32 GiB per lane, at most 60 % of the device's memory) is the
+        `max_slab_bytes` (default `LANE_SLAB_BYTES` = 36 GiB per lane, at most 60 % of the device's memory) is the
         budget of all lanes together.
 
         `host_io=(inputs, outputs)`: the batch STAYS in page-locked host memory - `inputs` / `outputs` are dicts of

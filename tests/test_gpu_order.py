@@ -315,21 +315,17 @@ def test_ragged_solver_section_variants_equal_solve_batch_sections(gpu):
 
 
 def test_masked_streams_run_kernels_and_refuse_bad_masks():
-    """`trs_stream_create_masked` (ABI 8; the host-fed pipeline's opt-in `TRS_PCIE_CUS`): kernels queued on a CU-masked
-    stream run (on whichever CUs the mask names) and give the same results; masks that leave a role without CUs are
-    refused.  In a process of its own (`tests/masked_streams_check.py`): on this runtime a process that has created
-    CU-masked streams may fault later (EXPERIMENTS R4.9), and this one has eighty tests still to run."""
+    """`trs_stream_create_masked` (ABI 8; the host-fed pipeline's `TRS_PCIE_CUS`): kernels queued on a CU-masked stream
+    run (on whichever CUs the mask names) and give the same results; masks that leave a role without CUs are refused.
+    In a process of its own (`tests/masked_streams_check.py`) under a timeout.  (Round 4 skipped this test when the
+    process stalled or faulted - "the runtime"; it was the joint-order kernel's race, EXPERIMENTS R5.1, and a stall
+    or a fault is a failure again.)"""
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "masked_streams_check.py")
-    try:
-        run = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
-    except subprocess.TimeoutExpired:
-        pytest.skip("the CU-masked streams (opt-in) stalled the device in their own process on this runtime")
-    if "refused:" in run.stdout:
+    run = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=250)
+    if "refused:" in run.stdout:      # a runtime (or a partitioned device) without CU masks: nothing to test
         pytest.skip(run.stdout.strip().splitlines()[-1])
-    if run.returncode < 0 or "Memory access fault" in run.stderr:   # killed by a signal: the runtime, not the assertions
-        pytest.skip(f"the CU-masked streams (opt-in) crashed their own process on this runtime: {run.stderr[-300:]!r}")
     assert run.returncode == 0 and "masked streams ok" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
 
 

@@ -6,6 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
+from python_stable_3d_truss_analysis_amd import _capi
+if os.environ.get("VARIANT"):   # a variant build (tools/build_variants.sh) instead of the product library
+    _capi.LIB_PATH = os.path.join(ROOT, "python_stable_3d_truss_analysis_amd", "variants", f"libtrs_{os.environ['VARIANT']}.so")
 from python_stable_3d_truss_analysis_amd import batch
 
 ap = argparse.ArgumentParser()
