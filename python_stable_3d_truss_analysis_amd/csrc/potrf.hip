@@ -678,10 +678,17 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
         auto aload = [&](int off, int v, int k) {
             return S.load_at(S.lane_off(v == 0 || k >= kv[v]), off + 128 * v);
         };
+#ifdef TRS_EXP_HALF_IFB   // timing experiment only (wrong results): every OTHER item of a panel takes its block-side
+        // fragments through the out-of-range lane offset (zeros, no memory traffic, same instruction stream) - what two
+        // waves per matrix that share a panel's block-side rows through LDS could save AT MOST (EXPERIMENTS R5.4)
+        const unsigned fbo = (((c0 - (r0 / 16 + CT)) >> 1) & 1) ? Slab::gone : S.loff;
+#else
+        const unsigned fbo = S.loff;
+#endif
 #pragma unroll
         for (int d = 0; d < DEPTHN - 1; ++d) {
 #pragma unroll
-            for (int s = 0; s < CT; ++s) fb[d][s] = S.load(ob + d * step + 128 * s);
+            for (int s = 0; s < CT; ++s) fb[d][s] = S.load_at(fbo, ob + d * step + 128 * s);
 #pragma unroll
             for (int v = 0; v < NV; ++v) fa[d][v] = aload(oa + d * step, v, kstart + 4 * d);
         }
@@ -694,7 +701,7 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
 #ifdef TRS_EXP_NO_IFB      // timing experiment only (wrong results): the items' block-side fragment loads
                     fb[nd][s] = 0.0 * (double)(ob + s);
 #else
-                    fb[nd][s] = S.load(ob + (d + DEPTHN - 1) * step + 128 * s);
+                    fb[nd][s] = S.load_at(fbo, ob + (d + DEPTHN - 1) * step + 128 * s);
 #endif
 #pragma unroll
                 for (int v = 0; v < NV; ++v)

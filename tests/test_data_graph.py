@@ -66,6 +66,68 @@ def test_graph_tensors_match_reference_capture(task, meta):
     assert creator.jointIndexToID == list(range(10)) and creator.memberIndexToID == list(range(25))
 
 
+class _PygLikeHeteroData:
+    """What this module uses of `torch_geometric.data.HeteroData`, with PyG's documented semantics (the reference
+    builds its graphs with exactly these four forms, data.py:260-282): `g[str]` is the storage of a node type (created
+    on first use), `g[src, rel, dst]` the storage of an edge type, `g[str] = value` a GLOBAL attribute - which a later
+    `g[str]` then returns as the value -, attributes of a storage by assignment; `node_types` / `edge_types` list them.
+    torch_geometric cannot be installed in the build container (no network, not in the wheelhouse: DESIGN section 4),
+    so this class is what executes the `from torch_geometric.data import HeteroData` branch here."""
+
+    class _Storage(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    def __init__(self):
+        object.__setattr__(self, "_global", {})
+        object.__setattr__(self, "_nodes", {})
+        object.__setattr__(self, "_edges", {})
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            assert len(key) == 3
+            return self._edges.setdefault(key, self._Storage())
+        if key in self._global:
+            return self._global[key]
+        return self._nodes.setdefault(key, self._Storage())
+
+    def __setitem__(self, key, value):
+        assert isinstance(key, str) and key not in self._nodes
+        self._global[key] = value
+
+    node_types = property(lambda self: list(self._nodes))
+    edge_types = property(lambda self: list(self._edges))
+
+
+def test_pyg_branch_builds_a_hetero_data_object(monkeypatch):
+    """`data._new_graph` with a `torch_geometric.data.HeteroData` in reach (the branch had never executed
+    anywhere): the graph of bar-25 is then an instance of that class, filled through PyG's item / attribute forms only,
+    and carries the reference's tensors (tests/golden/hetero_bar25.npz)."""
+    import sys
+    import types
+    from python_stable_3d_truss_analysis_amd import data as gdata
+    pkg, mod = types.ModuleType("torch_geometric"), types.ModuleType("torch_geometric.data")
+    mod.HeteroData = _PygLikeHeteroData
+    pkg.data = mod
+    monkeypatch.setitem(sys.modules, "torch_geometric", pkg)
+    monkeypatch.setitem(sys.modules, "torch_geometric.data", mod)
+    monkeypatch.setattr(gdata, "_GRAPH_FACTORY", None)
+    z = np.load(os.path.join(H.GOLDEN, "hetero_bar25.npz"))
+    data = H.load_json("bar-25_input_0")
+    truss = Truss(3).LoadFromJSON(data=data)
+    for task in COMBOS:
+        for meta in METAS:
+            creator = TrussHeteroDataCreator(meta[1], task[1])
+            graph = creator.FromTruss(truss, fixedMemberType=FIXED, _results=_oracle_results(data), **SCALES)
+            assert isinstance(graph, _PygLikeHeteroData) and gdata._GRAPH_FACTORY is _PygLikeHeteroData
+            _compare(graph, z, f"{task[0]}_{meta[0]}")
+            assert graph.node_types == ["joint", "member"]
+            want = [("joint", "j2m", "member"), ("member", "m2j", "joint")]
+            if meta[1] == MetapathType.USE_IMPLICIT:
+                want += [("joint", "j2j", "joint"), ("member", "m2m", "member")]
+            assert graph.edge_types == want
+
+
 def test_dense_edges_master_node_and_member_type_targets():
     data = H.load_json("bar-25_input_0")
     truss = Truss(3).LoadFromJSON(data=data)

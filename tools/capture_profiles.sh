@@ -27,7 +27,7 @@ PY
 timeout 900 tools/profile_pmc.sh ${TAG}_dense_pmc --dense > $OUT/${TAG}_dense_pmc_files.log 2>&1
 python3 tools/summarize_pmc.py $OUT/${TAG}_dense_pmc $OUT/${TAG}_dense_pmc_summary.json > $OUT/${TAG}_dense_sum.log 2>&1
 find $OUT/${TAG}_dense_pmc/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_dense_kernel_stats.csv
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cube_stats -- python3 tools/cube_step.py > $OUT/${TAG}_cube_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cube_stats -- python3 tools/cube_step.py --lanes 1 > $OUT/${TAG}_cube_stats.log 2>&1   # (ONE lane: per-kernel durations without the overlap of the default four)
 find $OUT/${TAG}_cube_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_cube_kernel_stats.csv
 timeout 600 tools/cube_pmc.sh ${TAG}_cubepmc > /dev/null 2>&1
 cp $OUT/${TAG}_cubepmc/cube_pmc.txt $OUT/${TAG}_cube_pmc.txt

@@ -4,9 +4,9 @@
 #   tools/cube_pmc.sh <tag> -> gpurun_out/<tag>/cube_pmc.txt
 set -u
 TAG=${1:-cubepmc}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/sq" -- python3 tools/cube_step.py --steps 2 > "$OUT/sq.log" 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 tools/cube_step.py --steps 2 > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 tools/cube_step.py --steps 2 > "$OUT/write.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/sq" -- python3 tools/cube_step.py --steps 2 --lanes 1 > "$OUT/sq.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 tools/cube_step.py --steps 2 --lanes 1 > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 tools/cube_step.py --steps 2 --lanes 1 > "$OUT/write.log" 2>&1
 python3 - "$OUT" <<'PY' | tee "$OUT/cube_pmc.txt"
 import csv, glob, sys
 from collections import defaultdict

@@ -27,7 +27,9 @@ def load(tag):
 
 tags = ["default"] + (sys.argv[1:] or ["ign", "nifb", "ndl", "nkl", "niu", "nch", "nis"])
 sizes, tensors = bench.cube_workload(65536, 0, device="cuda:0")
-solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors)
+# (one lane and the 48 GiB budget of round 4 by default, so that the bucket set - and the numbers - compare with R4.1)
+solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors, lanes=int(os.environ.get("LANES", 1)),
+                            max_slab_bytes=int(os.environ.get("SLAB_GB", 48)) << 30)
 solver.step(); torch.cuda.synchronize()
 solver.adopt_launch_hints()
 libs = {t: load(t[4:] if t.startswith("asm-") else t) for t in tags}

@@ -19,7 +19,9 @@ lib = ctypes.CDLL(path)
 for name, (restype, argtypes) in _capi.SIGNATURES.items():
     fn = getattr(lib, name); fn.restype, fn.argtypes = restype, argtypes
 sizes, tensors = bench.cube_workload(65536, 0, device="cuda:0")
-solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors)
+# (one lane and the 48 GiB budget of round 4 by default, so that the bucket set - and the numbers - compare with R4.1)
+solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors, lanes=int(os.environ.get("LANES", 1)),
+                            max_slab_bytes=int(os.environ.get("SLAB_GB", 48)) << 30)
 solver.step(); torch.cuda.synchronize()
 solver.adopt_launch_hints()
 n = 0
