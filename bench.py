@@ -1119,6 +1119,7 @@ def main():
             "rank_ms_per_step": {"min": elapsed_min / args.steps * 1e3, "max": elapsed / args.steps * 1e3},
             "repeats": repeat_stats(repeat_s, repeat_potrf_ms, args.steps, world * args.batch),
             "host_threads_per_rank": host_threads,
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),   # (set to 8 by the package unless the caller chose)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

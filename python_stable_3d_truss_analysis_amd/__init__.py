@@ -6,6 +6,16 @@ slientruss3d (reference: leo27945875/Python_Stable_3D_Truss_Analysis).
 The arithmetic runs in hand-written HIP kernels for gfx950 reached through a C ABI
 (`include/trs_solver.h`); there is no CPU fallback.
 """
+import os as _os
+
+# The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin; streams beyond that SHARE
+# a queue, and work on one then waits behind the other's.  This package uses four lanes for a ragged batch
+# (`batch.RaggedSolver`) plus a DMA stream in `data.dataset_stream` and three streams in the host-fed pipeline: with four
+# queues the dataset stream's device -> host copy lands on a lane's queue for some lane counts (measured: 351-471 K
+# samples/s delivered instead of 512-521 K, EXPERIMENTS R5.5).  Eight queues unless the caller has chosen; read by the
+# runtime when the process first touches the GPU, so this must come before that (importing torch does not).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .type import GenerateMethod, LinkType, MemberType, MetapathType, SupportType, TaskType
 from .truss import Member, Truss
 from .utils import HipExtensionError, TrussNotStableError
