@@ -872,10 +872,11 @@ def main():
             call()
             ev[1].record()
 
-    for _ in range(args.warmup):
-        step()
-    if args.warmup > 0:
-        dev.adopt_tile_hint()   # (bar-942: too few envelope tiles without an entry of K_ff - the masks are not formed again)
+    warm_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    for k in range(args.warmup):   # (the form the timed steps have: five calls, events around the factorisation)
+        step(potrf_events=warm_events)
+        if k == 0:
+            dev.adopt_tile_hint()   # (bar-942: too few envelope tiles without an entry of K_ff - the masks are not formed again)
     # Events are recorded on torch's current stream, which is the stream the C ABI launches on.  The TIMED
     # steps carry two events each, around the factorisation (roofline.avg_launch_ms); an event pair around
     # every stage costs 2.5 % of the step (tools/event_overhead.py), so the per-stage breakdown comes from an
