@@ -883,6 +883,9 @@ def main():
     # equal number of instrumented steps right after the timed region.
     new_event = lambda: torch.cuda.Event(enable_timing=True)
     potrf_events = [(new_event(), new_event()) for _ in range(args.steps)]
+    for e0, e1 in potrf_events:   # (an event object is created by the runtime at its first record(): not inside the timed
+        e0.record()               # region - 2 x K creations were 1-2 % of a 27 ms region, which the repeats did not pay)
+        e1.record()
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):

@@ -1318,15 +1318,10 @@ class RaggedSolver:
             groups, self._chip_bound_buckets = _flow_shop_order(groups, packed, n_pad_of,
                                                                 os.environ.get("TRS_HOSTFED_ORDER", "johnson"))
         self.buckets = []
-        # lanes: longest-processing-time-first on the slab sizes (the groups come largest first)
         self.lanes = max(1, min(n_lanes, len(groups)))
-        lane_load = [0] * self.lanes
-        needs = [{"S": 0, "uf": 0, "work": 0, "env": 0, "raw_j": 0, "raw_m": 0} for _ in range(self.lanes)]
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
         for idx in groups:
-            lane = min(range(self.lanes), key=lambda l: lane_load[l])
-            lane_load[lane] += slab_of(idx)
-            need = needs[lane]
+            need = {"S": 0, "uf": 0, "work": 0, "env": 0, "raw_j": 0, "raw_m": 0}
             nJ_b, nM_b = max(1, int(packed.nJ[idx].max())), max(1, int(packed.nM[idx].max()))
             n_b, Bb = int(packed.n_free[idx].max()), len(idx)
             sub = {"xyz": e([Bb, nJ_b, 3], torch.float64), "loads": e([Bb, nJ_b, 3], torch.float64),
@@ -1342,10 +1337,9 @@ class RaggedSolver:
             db = DeviceBatch.from_device(sub, n_b, joint_out=jout)
             db.options.update(options or {})
             if not db.small:
-                need["S"] = max(need["S"], Bb * db.rows * db.ld)
-                need["uf"] = max(need["uf"], Bb * db.rows)
-                need["work"] = max(need["work"], Bb * self.lib.trs_assemble_work_bytes(nJ_b, nM_b, n_b))
-                need["env"] = max(need["env"], Bb * self.lib.trs_env_ints(n_b))
+                need["S"], need["uf"] = Bb * db.rows * db.ld, Bb * db.rows
+                need["work"] = Bb * self.lib.trs_assemble_work_bytes(nJ_b, nM_b, n_b)
+                need["env"] = Bb * self.lib.trs_env_ints(n_b)
             on_device = renumbered and self.device_effort is not None and \
                 (plan[0] == "device" or bool(self.lib.trs_joint_order_fits(nJ_b, nM_b)))
             # A resident bucket that is ordered on the device needs neither a gather nor a scatter launch: its
@@ -1353,20 +1347,44 @@ class RaggedSolver:
             # writes the results straight into the caller's rows (`fused_io`).
             fused = on_device and not self.host_io and os.environ.get("TRS_RAGGED_FUSED_IO", "1") != "0"
             if on_device and not self.host_io and not fused:   # the bucket's rows in the caller's numbering: input of its trs_joint_order
-                need["raw_j"], need["raw_m"] = max(need["raw_j"], Bb * nJ_b), max(need["raw_m"], Bb * nM_b)
+                need["raw_j"], need["raw_m"] = Bb * nJ_b, Bb * nM_b
             self.buckets.append({"rows": up(np.ascontiguousarray(idx, dtype=np.int64)), "dev": db, "count": Bb,
                                  "renumbered": renumbered, "order_on_device": on_device, "idx": idx, "fused_io": fused,
-                                 "reach": e([Bb], torch.int32) if on_device else None, "lane": lane})
-        # one workspace per lane, shared by the lane's buckets (they run one after the other on its stream)
-        ws = workspace if workspace is not None else SolverWorkspace(torch, dev)
-        self.workspace = ws
+                                 "reach": e([Bb], torch.int32) if on_device else None, "lane": 0, "need": need,
+                                 # microseconds, roughly: what a bucket of the cube batch takes alone on the chip, per
+                                 # truss 0.1 + 1.3e-6 rows^2 (EXPERIMENTS R5.6) - the lanes are dealt by it
+                                 "cost": Bb * (0.1 + 1.3e-6 * float(db.rows) ** 2)})
+        self.workspace = workspace if workspace is not None else SolverWorkspace(torch, dev)
+        self._side_streams = lane_streams(torch, dev, self.lanes - 1) if self.lanes > 1 else []
+        self._deal_lanes()
+        if self.host_io:
+            self._streams = _pipeline_streams(torch, dev, self.lib)
+
+    def _deal_lanes(self):
+        """Deal the buckets onto the lanes - longest processing time first on `bk["cost"]` (a size model; re-dealing by
+        MEASURED bucket times was tried and is no better: a bucket's time depends on what runs beside it, EXPERIMENTS
+        R5.6) -, give every lane a workspace that holds the largest of ITS
+        buckets (they run one after the other on its stream) and point the buckets at it.  The buckets are launched in
+        the order of `self.buckets`; resident batches keep them by descending cost, so every lane starts with its
+        longest bucket and the step ends over the short ones.  Nothing of this solver may be in flight."""
+        torch, dev = self.torch, self.device
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        if not self.host_io:   # (the host-fed pipeline has its own order: the flow shop's)
+            self.buckets.sort(key=lambda bk: -bk["cost"])
+        load = [0.0] * self.lanes
+        needs = [{"S": 0, "uf": 0, "work": 0, "env": 0, "raw_j": 0, "raw_m": 0} for _ in range(self.lanes)]
+        for bk in self.buckets:
+            lane = min(range(self.lanes), key=lambda l: load[l])
+            load[lane] += bk["cost"]
+            bk["lane"] = lane
+            for k, v in bk["need"].items():
+                needs[lane][k] = max(needs[lane][k], v)
         lane_bufs = []
         for lane, need in enumerate(needs):
-            lane_bufs.append(ws.lane(lane).get(
+            lane_bufs.append(self.workspace.lane(lane).get(
                 {"S": need["S"], "uf": need["uf"], "work": need["work"], "env": need["env"],
                  "raw_xyz": need["raw_j"] * 3, "raw_loads": need["raw_j"] * 3, "raw_cbits": need["raw_j"],
                  "raw_conn": need["raw_m"] * 2}))
-        self._side_streams = lane_streams(torch, dev, self.lanes - 1) if self.lanes > 1 else []
         for bk in self.buckets:
             db, Bb = bk["dev"], bk["count"]
             bufs = lane_bufs[bk["lane"]]
@@ -1381,10 +1399,11 @@ class RaggedSolver:
                 pass
             elif bk["order_on_device"] and self.host_io:
                 # (the pull of bucket k + 1 runs while bucket k is being ordered: every bucket its own buffers)
-                nJ_b, nM_b = db.nJ_max, db.nM_max
-                bk["raw"] = {"xyz": e([Bb, nJ_b, 3], torch.float64), "loads": e([Bb, nJ_b, 3], torch.float64),
-                             "cbits": e([Bb, nJ_b], torch.uint8), "conn": e([Bb, nM_b, 2], torch.int32),
-                             "nJ": db.nJ, "nM": db.nM}
+                if "raw" not in bk:
+                    nJ_b, nM_b = db.nJ_max, db.nM_max
+                    bk["raw"] = {"xyz": e([Bb, nJ_b, 3], torch.float64), "loads": e([Bb, nJ_b, 3], torch.float64),
+                                 "cbits": e([Bb, nJ_b], torch.uint8), "conn": e([Bb, nM_b, 2], torch.int32),
+                                 "nJ": db.nJ, "nM": db.nM}
             elif bk["order_on_device"]:
                 nJ_b, nM_b = db.nJ_max, db.nM_max
                 bk["raw"] = {"xyz": raw["xyz"][:Bb * nJ_b * 3].view(Bb, nJ_b, 3),
@@ -1396,8 +1415,6 @@ class RaggedSolver:
                 bk["ordered"] = {"perm": db.joint_out, "reach": bk["reach"], "xyz": db.xyz, "conn": db.conn,
                                  "cbits": db.cbits, "loads": db.loads}
         self._tables = self._copy_tables()
-        if self.host_io:
-            self._streams = _pipeline_streams(torch, dev, self.lib)
 
     def _copy_tables(self):
         """ctypes argument arrays of the gather / scatter launches of every bucket (all device pointers are

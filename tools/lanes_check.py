@@ -41,4 +41,8 @@ for lanes in (2, 3) * int(os.environ.get("LANES_CHECK_ROUNDS", "10")):
                     assert torch.equal(torch.nan_to_num(got[k], nan=0.0), ref[k]), (lanes, attempt, k)
         if attempt == 0:
             solver.adopt_launch_hints()
+            for bk in solver.buckets:       # any deal of the buckets onto the lanes gives the same bits
+                bk["cost"] = float(rng.random())
+            torch.cuda.synchronize()
+            solver._deal_lanes()
 print("lanes ok")
