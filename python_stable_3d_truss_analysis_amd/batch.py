@@ -1361,9 +1361,9 @@ class RaggedSolver:
             self._streams = _pipeline_streams(torch, dev, self.lib)
 
     def _deal_lanes(self):
-        """Deal the buckets onto the lanes - longest processing time first on `bk["cost"]` (a size model; re-dealing by
-        MEASURED bucket times was tried and is no better: a bucket's time depends on what runs beside it, EXPERIMENTS
-        R5.6) -, give every lane a workspace that holds the largest of ITS
+        """Deal the buckets onto the lanes - longest processing time first on `bk["cost"]` (a size model; dealing by MEASURED
+        times, and evening out the lanes' ends move by move, were tried: the lanes then end together and the step is
+        no shorter - the chip is busy either way, EXPERIMENTS R5.6) -, give every lane a workspace that holds the largest of ITS
         buckets (they run one after the other on its stream) and point the buckets at it.  The buckets are launched in
         the order of `self.buckets`; resident batches keep them by descending cost, so every lane starts with its
         longest bucket and the step ends over the short ones.  Nothing of this solver may be in flight."""
@@ -1372,13 +1372,20 @@ class RaggedSolver:
         if not self.host_io:   # (the host-fed pipeline has its own order: the flow shop's)
             self.buckets.sort(key=lambda bk: -bk["cost"])
         load = [0.0] * self.lanes
-        needs = [{"S": 0, "uf": 0, "work": 0, "env": 0, "raw_j": 0, "raw_m": 0} for _ in range(self.lanes)]
         for bk in self.buckets:
             lane = min(range(self.lanes), key=lambda l: load[l])
             load[lane] += bk["cost"]
             bk["lane"] = lane
+        self._bind_lanes()
+
+    def _bind_lanes(self):
+        """Workspaces for the lanes as the buckets are dealt now (`bk["lane"]`), the buckets pointed at them."""
+        torch, dev = self.torch, self.device
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        needs = [{"S": 0, "uf": 0, "work": 0, "env": 0, "raw_j": 0, "raw_m": 0} for _ in range(self.lanes)]
+        for bk in self.buckets:
             for k, v in bk["need"].items():
-                needs[lane][k] = max(needs[lane][k], v)
+                needs[bk["lane"]][k] = max(needs[bk["lane"]][k], v)
         lane_bufs = []
         for lane, need in enumerate(needs):
             lane_bufs.append(self.workspace.lane(lane).get(
