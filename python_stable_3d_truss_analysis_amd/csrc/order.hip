@@ -31,8 +31,12 @@
 
 namespace {
 
-constexpr int NT = 256;
+#ifndef TRS_ORDER_THREADS
+#define TRS_ORDER_THREADS 256   // (512 = eight waves, one candidate task per wave instead of two on half of the waves, was
+#endif                          // measured: 1.35-2.1 x SLOWER - the kernel's rate follows the work-groups per CU: R5.7)
+constexpr int NT = TRS_ORDER_THREADS;
 constexpr int NWAVE = NT / 64;
+static_assert(NT == 256 || NT == 512, "four or eight waves");
 constexpr int ID_BITS = 13;                 // joint ids in the sort keys: nJ_max < 8192
 constexpr int PERMANENT = 0x40000000;       // visit stamp of a joint that has its final Cuthill-McKee number
 constexpr unsigned long long NO_COST = ~0ull;
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     // stage (in the space the adjacency fill will take over later), the members' end joints are kept in
     // registers for the two passes that need them.
     double* Xs = reinterpret_cast<double*>(lds + lay.keys);  // [3 nJ_max] staged coordinates, in the shared region (dead before the fill)
-    constexpr int MR = 8;
+    constexpr int MR = 2048 / NT;   // a thread's first members stay in registers (2048 members without a second read)
     int2 cr[MR];
     const int2* CNI = reinterpret_cast<const int2*>(CN);
 #pragma unroll
@@ -722,11 +726,11 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
             auto ord = [&](int k) { return (int)t.ids[k]; };
             consider(price_order(t, nf, ord, newidx, c01, cmin, lane, &ndof), 0, 14, ord);
         }
-        if (use_rcm && wave == (n_sweep > 1 ? 2 : 0)) {  // reverse Cuthill-McKee
+        if (use_rcm && wave == (n_sweep > 1 ? NWAVE - 2 : 0)) {  // reverse Cuthill-McKee
             auto ord = [&](int k) { return t.order[nf - 1 - k]; };
             consider(price_order(t, nf, ord, newidx, c01, cmin, lane, &ndof), 0, 0, ord);
         }
-        if (use_rcm && wave == (n_sweep > 1 ? 3 : 1)) {  // plain Cuthill-McKee
+        if (use_rcm && wave == (n_sweep > 1 ? NWAVE - 1 : 1)) {  // plain Cuthill-McKee
             auto ord = [&](int k) { return t.order[k]; };
             consider(price_order(t, nf, ord, newidx, c01, cmin, lane, &ndof), 1, 1, ord);
         }
@@ -812,14 +816,14 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     // ---- phase C: the winner ---------------------------------------------------------------------------------
     if (lane == 0) {
         t.red[wave] = my_cost;
-        t.ctrl[4 + wave] = my_rank;
-        t.ctrl[8 + wave] = my_choice;
+        t.ctrl[8 + wave] = my_rank;
+        t.ctrl[16 + wave] = my_choice;
     }
     __syncthreads();
     st.mark(6);
     int win = 0;
     for (int w = 1; w < NWAVE; ++w)
-        if (t.red[w] < t.red[win] || (t.red[w] == t.red[win] && t.ctrl[4 + w] < t.ctrl[4 + win])) win = w;
+        if (t.red[w] < t.red[win] || (t.red[w] == t.red[win] && t.ctrl[8 + w] < t.ctrl[8 + win])) win = w;
     const unsigned short* wperm = t.best + (size_t)win * nJ_max;
     int* inverse = t.fill;
     int* fullperm = t.ppos;   // [nJ_max] the whole permutation (the sweeps' parent positions are dead)
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
             fullperm[k] = j;
             inverse[j] = k;
         }
-    if (tid == 0 && choice_out != nullptr) choice_out[b] = nf > 0 ? t.ctrl[8 + win] : 0;
+    if (tid == 0 && choice_out != nullptr) choice_out[b] = nf > 0 ? t.ctrl[16 + win] : 0;
     __syncthreads();
     for (int k = tid; k < nJ_max; k += NT) P[k] = fullperm[k];
     // envelope reach of the chosen order below the 64 x 64 diagonal blocks (reorder.c trs_envelope_reach; what
