@@ -36,7 +36,7 @@ namespace {
 #endif                          // measured: 1.35-2.1 x SLOWER - the kernel's rate follows the work-groups per CU: R5.7)
 constexpr int NT = TRS_ORDER_THREADS;
 constexpr int NWAVE = NT / 64;
-static_assert(NT == 256 || NT == 512, "four or eight waves");
+static_assert(NT == 128 || NT == 256 || NT == 512, "two, four or eight waves");
 constexpr int ID_BITS = 13;                 // joint ids in the sort keys: nJ_max < 8192
 constexpr int PERMANENT = 0x40000000;       // visit stamp of a joint that has its final Cuthill-McKee number
 constexpr unsigned long long NO_COST = ~0ull;
