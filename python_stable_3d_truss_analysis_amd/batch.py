@@ -976,7 +976,10 @@ def size_buckets(packed: PackedBatch, max_slab_bytes=64 << 30, granularity=64, q
     groups = []
     small = np.flatnonzero(packed.n_free <= SMALL_N)
     taken = np.zeros(packed.B, dtype=bool)
-    if len(small) and len(np.unique(n_pad[small])) > 1:
+    # (with `quantum` also when they are of one size class: a bucket that spans further classes would take them through
+    # the staged kernels, whose rounding differs from the small-system kernel's in the last bit - which kernel solves a
+    # truss must not depend on how the batch is grouped, `tools/fuzz_streamed.py`)
+    if len(small) and (quantum > 0 or len(np.unique(n_pad[small])) > 1):
         try:
             fits = _capi.load().trs_solve_small_fits(int(packed.nJ[small].max()), int(packed.nM[small].max()),
                                                      int(packed.n_free[small].max()))

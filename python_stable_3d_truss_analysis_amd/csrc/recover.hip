@@ -162,14 +162,22 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         __syncthreads();
         for (int j = tid; j < joints; j += 256) cnt[j] = 0;  // reused as the fill cursor
         __syncthreads();
+#ifdef TRS_EXP_RECOVER_NOFILL   // timing experiment only (wrong reactions): no grouping of the member ends either
+        for (int m = tid, r = 0; m < 0; m += 256, ++r) {
+#else
         for (int m = tid, r = 0; m < members; m += 256, ++r) {
+#endif
             const int2 c = r < MR ? ends_of(r, m) : CNI[m];
             const int j0 = c.x, j1 = c.y;
             if (constrained(j0)) ends[start[j0] + atomicAdd(&cnt[j0], 1)] = m << 1;
             if (constrained(j1)) ends[start[j1] + atomicAdd(&cnt[j1], 1)] = (m << 1) | 1;
         }
         __syncthreads();
+#ifdef TRS_EXP_RECOVER_NOREACT   // timing experiment only (wrong reactions): what the per-joint reaction sums cost
+        for (int j = tid; j < 0; j += 256) {
+#else
         for (int j = tid; j < joints; j += 256) {
+#endif
             const int deg = cnt[j];
             if (deg == 0) continue;
             int* list = ends + start[j];

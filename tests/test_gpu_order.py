@@ -314,6 +314,30 @@ def test_ragged_solver_section_variants_equal_solve_batch_sections(gpu):
         np.testing.assert_array_equal(got.internal.cpu().numpy(), ref.internal)
 
 
+def test_which_kernel_solves_a_truss_does_not_depend_on_the_grouping(gpu):
+    """A ragged batch whose small systems (n_free <= 128) all lie in ONE size class beside larger ones: the resident
+    bucket pipeline (buckets cut at whole rounds of the factorisation kernel, up to three size classes each) and the
+    host-fed `solve_batch` (one bucket per size class) must send them through the same kernel - the fused small-system
+    kernel and the staged pipeline differ in the last bit - and give the same bits (found by `tools/fuzz_streamed.py` at
+    batch sizes the suite had not covered; `batch.size_buckets`)."""
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    import torch
+    rng = np.random.default_rng(5)
+    packed = gen.generate_cube_batch(rng.integers(13, 25, size=400), gridRange=(6, 6, 6), seed=9)   # n_free 90 .. 255
+    small = packed.n_free <= 128
+    assert 10 < small.sum() < 200 and len(np.unique((packed.n_free[small] + 63) // 64)) == 1 and packed.n_free.max() <= 256
+    # (three size classes 128 / 192 / 256: ONE bucket of the round-cut grouping unless the small systems are set apart)
+    assert [int(packed.n_free[g].max()) <= 128 for g in gpu.size_buckets(packed, quantum=3072)] == [True, False]
+    dev_in = {f: torch.from_numpy(np.ascontiguousarray(getattr(packed, f))).cuda() for f in gpu.DeviceBatch.INPUT_FIELDS}
+    for reorder in (True, "rcm"):
+        want = gpu.solve_batch(packed, reorder=reorder)
+        got = gpu.solve_batch(packed, reorder=reorder, device_inputs=dev_in, on_device=True)
+        np.testing.assert_array_equal(got.displace.cpu().numpy(), want.displace)
+        np.testing.assert_array_equal(got.external.cpu().numpy(), want.external)
+        np.testing.assert_array_equal(got.internal.cpu().numpy(), want.internal)
+        assert not want.info.any()
+
+
 def test_masked_streams_run_kernels_and_refuse_bad_masks():
     """`trs_stream_create_masked` (ABI 8; the host-fed pipeline's `TRS_PCIE_CUS`): kernels queued on a CU-masked stream
     run (on whichever CUs the mask names) and give the same results; masks that leave a role without CUs are refused.

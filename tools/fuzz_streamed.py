@@ -6,6 +6,9 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from python_stable_3d_truss_analysis_amd import batch, generate as gen
+if os.environ.get("LANES"):
+    batch.DEFAULT_LANES = int(os.environ["LANES"])
+ONLY = [int(v) for v in os.environ.get("ONLY_TRIALS", "").split()]   # (replay: only these trials are solved, the draws stay)
 rng = np.random.default_rng(0)
 bad = 0
 pool = batch.ResultPool()
@@ -16,6 +19,8 @@ for trial in range(TRIALS):
     lo, hi = [(1, 3), (1, 30), (20, 60), (1, 190), (150, 190)][trial % 5]
     packed = gen.generate_cube_batch(rng.integers(lo, hi + 1, size=B), gridRange=(6, 6, 6), seed=int(rng.integers(1 << 30)))
     reorder = [True, False, "rcm", "fast"][trial % 4]
+    if ONLY and trial not in ONLY:
+        continue
     ref = batch.solve_batch(packed, reorder=reorder)
     got = batch.solve_batch_streamed(packed.pinned(), reorder=reorder, pool=pool if trial % 3 else None)
     ok = all(np.array_equal(getattr(got, k), getattr(ref, k)) for k in ("displace", "external", "internal", "info"))
@@ -29,4 +34,14 @@ for trial in range(TRIALS):
     if not (ok and ok2):
         bad += 1
         print("MISMATCH trial", trial, B, (lo, hi), reorder, ok, ok2)
+        for v, (r, w) in enumerate(zip(res, want)):
+            du = np.abs(r.displace.cpu().numpy() - w.displace).reshape(B, -1).max(1)
+            dn = np.abs(r.internal.cpu().numpy() - w.internal).reshape(B, -1).max(1)
+            rows = np.flatnonzero((du > 0) | (dn > 0) | ~np.isfinite(du))
+            print(f"   variant {v}: {len(rows)} trusses differ, rows {rows[:8].tolist()}, n_free {packed.n_free[rows[:8]].tolist()}, "
+                  f"max |du| {np.nanmax(du) if len(du) else 0:.3e} of {np.abs(w.displace).max():.3e}, info {r.info.cpu().numpy()[rows[:8]].tolist()}")
+        again = batch.solve_batch(packed, reorder=reorder, sections=sec, device_inputs=t, on_device=True)
+        print("   the same call again equals the staged results:", all(
+            np.array_equal(r.displace.cpu().numpy(), w.displace) and np.array_equal(r.internal.cpu().numpy(), w.internal)
+            for r, w in zip(again, want)))
 print("trials done, mismatches:", bad)
