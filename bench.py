@@ -851,6 +851,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN, group=tgroup)
         return float(tmax.item())
 
+    # The legs of the other configurations run FIRST (each with its own barrier-bracketed region): they are seconds of
+    # device work, after which the chip sits at its steady clocks - the headline's timed region, 27 ms of work behind a
+    # handful of warm-up steps, otherwise starts on a device that is still ramping up (first region 2.4 % slower than
+    # the median of its own 25 repeats; `leg_order` in the line says which way round it was).
+    # the ragged workload of north_star (BASELINE config 3), on EVERY rank, with its own barrier-bracketed region
+    cube = None
+    if args.cube_batch > 0:
+        torch.cuda.empty_cache()
+        try:
+            cube = cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world, cpu=cube_cpu)
+        except Exception as exc:  # never lose the headline line over it
+            cube = {"error": repr(exc)}
+            if distributed:
+                raise
+    dataset = None
+    if args.dataset_samples > 0:
+        try:
+            dataset = dataset_leg(args, device, torch, barrier, reduce_max, rank, world)
+        except Exception as exc:
+            dataset = {"error": repr(exc)}
+            if distributed:
+                raise
+    batch.release_workspaces()   # (the legs' slabs go back to the driver: the headline batch allocates on a clean device)
+
     packed = batch.pack_json([data]).replicate(args.batch)
     order = False if args.joint_order == "given" or args.dense else args.joint_order
     dev = batch.DeviceBatch(packed, device, use_envelope=not args.dense, reorder=order,
@@ -1009,24 +1033,6 @@ def main():
         except Exception as exc:
             pcie = {"error": repr(exc)}
 
-    # the ragged workload of north_star (BASELINE config 3), on EVERY rank, with its own barrier-bracketed region
-    cube = None
-    if args.cube_batch > 0:
-        torch.cuda.empty_cache()
-        try:
-            cube = cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world, cpu=cube_cpu)
-        except Exception as exc:  # never lose the headline line over it
-            cube = {"error": repr(exc)}
-            if distributed:
-                raise
-    dataset = None
-    if args.dataset_samples > 0:
-        try:
-            dataset = dataset_leg(args, device, torch, barrier, reduce_max, rank, world)
-        except Exception as exc:
-            dataset = {"error": repr(exc)}
-            if distributed:
-                raise
     if rank == 0:
         total_trusses = world * args.batch * args.steps
         potrf_s = potrf_ms_timed * 1e-3   # the dominant kernel, measured inside the timed region
@@ -1123,6 +1129,7 @@ def main():
             "rank_ms_per_step": {"min": elapsed_min / args.steps * 1e3, "max": elapsed / args.steps * 1e3},
             "repeats": repeat_stats(repeat_s, repeat_potrf_ms, args.steps, world * args.batch),
             "host_threads_per_rank": host_threads,
+            "leg_order": "cube_batch, dataset, then the headline (config 2) and the informational legs",
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),   # (set to 8 by the package unless the caller chose)
             "higher_is_better": True,
             "scaling": "weak",
