@@ -626,7 +626,93 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             if (e_first < pdeg) run_values(adj + start[a], pdeg, e_first, r, pq0, pq1, pq2, pv0, pv1, pv2);
         }
     };
+#ifdef TRS_ASM_PIPELINE   // (A/B build: measured EQUAL to the one-block-ahead form below, which stays - EXPERIMENTS R5.11)
+    // The walk that forms a thread's piece is a chain of four dependent LDS look-ups (row -> DOF -> joint's list ->
+    // list entry -> neighbour's free indices and member geometry): with the piece formed ONE block ahead the whole
+    // chain sat between a block's stores and the next block's scatter, and the wave issued nothing meanwhile (the row
+    // loop waits 0.60 of its cycles, two work-groups per CU cannot hide it).  As a FOUR-STAGE software pipeline:
+    // every pass issues stage 4 for the next block, stage 3 for the one after, stage 2 and stage 1 for the two behind
+    // - four independent look-ups whose results are a whole block of stores old when they are used (EXPERIMENTS R5.11).
+    // Same values in the same order: same bits.
+    struct Walk {
+        int a = -1, r = 0, deg = 0, s = 0;           // joint and axis of the row, its list (stage 2)
+        unsigned key = 0, prev = ~0u, next = ~0u;    // this thread's list entry and its neighbours in the list (stage 3)
+    };
+    auto stage1 = [&](int c0) {                      // -> DOF of the thread's row in block c0, or -1
+        const int c = c0 + rr;
+#ifdef TRS_EXP_ASM_NOWALK
+        return -1;
+#endif
+        return c < n ? rowdof[c] : -1;
+    };
+    auto stage2 = [&](int dof) {
+        Walk w;
+        if (dof >= 0) {
+            w.a = dof / 3;
+            w.r = dof - 3 * w.a;
+            if (e_first != TPR - 1) {
+                w.deg = cnt[w.a];
+                w.s = start[w.a];
+            }
+        }
+        return w;
+    };
+    auto stage3 = [&](Walk w) {
+        if (w.a >= 0 && e_first < w.deg) {           // (deg stays 0 for the thread of the joint's own block)
+            const unsigned* list = adj + w.s;
+            w.key = list[e_first];
+            w.prev = e_first > 0 ? list[e_first - 1] : ~w.key;
+            w.next = e_first + 1 < w.deg ? list[e_first + 1] : ~w.key;
+        }
+        return w;
+    };
+    auto stage4 = [&](const Walk& w) {               // -> pq*, pv*, pdeg of the block the walk belongs to
+        pq0 = pq1 = pq2 = -1;
+        pdeg = w.deg;
+        if (w.a < 0) return;
+        if (e_first == TPR - 1) {
+            const double* dg = diag + 6 * w.a;       // row r of [xx xy xz; xy yy yz; xz yz zz]
+            pv0 = dg[w.r];
+            pv1 = dg[w.r == 0 ? 1 : (w.r == 1 ? 3 : 4)];
+            pv2 = dg[w.r == 0 ? 2 : (w.r == 1 ? 4 : 5)];
+            pq0 = fi[3 * w.a];
+            pq1 = fi[3 * w.a + 1];
+            pq2 = fi[3 * w.a + 2];
+        } else if (e_first < w.deg) {
+            const int other = (int)(w.key >> 16);
+            if ((int)(w.prev >> 16) == other) return;    // not the head of a run
+            pq0 = fi[3 * other];
+            pq1 = fi[3 * other + 1];
+            pq2 = fi[3 * other + 2];
+            pv0 = pv1 = pv2 = 0.0;
+            unsigned key = w.key;
+            int q = e_first;
+            const unsigned* list = adj + w.s;
+            for (;;) {  // parallel members between the same two joints, in member order
+                const int m = (int)(key & 0xffffu);
+                const double k = mk[m], cr = mc[3 * m + w.r];
+                pv0 -= k * (cr * mc[3 * m]);
+                pv1 -= k * (cr * mc[3 * m + 1]);
+                pv2 -= k * (cr * mc[3 * m + 2]);
+                ++q;
+                if (q >= w.deg) break;
+                key = q == e_first + 1 ? w.next : list[q];   // (the entry after the thread's own came with stage 3)
+                if ((int)(key >> 16) != other) break;
+            }
+        }
+    };
+    Walk w3, w2;
+    int dof1;
+    {   // fill: blocks 0 .. 3
+        const Walk b0 = stage3(stage2(stage1(0)));
+        stage4(b0);
+        w3 = stage3(stage2(stage1(TR)));
+        w2 = stage2(stage1(2 * TR));
+        dof1 = stage1(3 * TR);
+    }
+#else
     prepare(0);
+#endif
     for (int c0 = 0; c0 < npad; c0 += TR) {
         // stored part of these rows: columns [i_lo, i_hi) (diagonal tile .. end of the envelope of
         // the panel the rows belong to); the 16-wide load-column chunk rides with the last segment
@@ -678,7 +764,16 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                     *reinterpret_cast<d2*>(src + x) = d2{0.0, 0.0};
                 }
             }
+#ifdef TRS_ASM_PIPELINE
+            if (is_last && c0 + TR < npad) {   // the four stages, one block each: independent look-ups
+                stage4(w3);
+                w3 = stage3(w2);
+                w2 = stage2(dof1);
+                dof1 = stage1(c0 + 4 * TR);
+            }
+#else
             if (is_last && c0 + TR < npad) prepare(c0 + TR);  // overlaps with the stores in flight
+#endif
             __builtin_amdgcn_wave_barrier();
         }
     }
