@@ -89,6 +89,13 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     const int npad = trs_round_up(n, TRS_NB);
     if (npad == 0) return;
     const int nch = npad / 16;
+#ifdef TRS_EXP_ASM_STAGGER_TICKS   // experiment (EXPERIMENTS R5.12): half of the FIRST round of work-groups starts late, so that
+    // the two work-groups of a CU are out of phase (one forms its tables while the other stores) instead of in lockstep
+    if (blockIdx.x < TRS_EXP_ASM_STAGGER_FIRST && ((blockIdx.x / TRS_EXP_ASM_STAGGER_GROUP) & 1)) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)TRS_EXP_ASM_STAGGER_TICKS) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
 
     const AsmLds lay = asm_lds_layout(nJ_max, nM_max, n_pad_max, MODE == 2 ? -16 : WT, MODE != 1, TR);
     unsigned char* wbase = work_all + (size_t)b * work_stride;
