@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""SHA-1 of the results (u, f_ext, N, info) of a cube batch and of the bundled cases solved with the product library or a
+variant build: two builds that claim "same bits" must print the same digests.   python tools/variant_digest.py [tag]"""
+import hashlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from python_stable_3d_truss_analysis_amd import _capi
+if len(sys.argv) > 1 and sys.argv[1] != "default":
+    _capi.LIB_PATH = os.path.join(ROOT, "python_stable_3d_truss_analysis_amd", "variants", f"libtrs_{sys.argv[1]}.so")
+import bench
+from python_stable_3d_truss_analysis_amd import batch
+from tests import helpers as H
+
+def digest(res):
+    h = hashlib.sha1()
+    for a in (res.displace, res.external, res.internal, res.info):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()[:16]
+
+sizes, tensors = bench.cube_workload(16384, 0, device="cuda:0")
+solver = batch.RaggedSolver(sizes, reorder=True, tensors=tensors)
+solver.step()
+print("cube 16384:", digest(solver.result()))
+packed = batch.pack_json([H.load_json(n) for n in H.data_case_names()])
+for reorder in (False, True):
+    print(f"bundled cases, reorder={reorder}:", digest(batch.solve_batch(packed, reorder=reorder)))
+dev = batch.DeviceBatch(batch.pack_json([H.load_json("bar-942_input_0")]).replicate(64), use_small=False)
+dev.solve()
+print("bar-942 x 64:", digest(dev.result()))
