@@ -585,153 +585,6 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     }
     double* S = S_all + (size_t)b * slab_stride;
     const int rr = tid / TPR, e_first = tid % TPR;
-#ifdef TRS_ASM_JOINT_WALK
-    // JOINT-SHARED WALK (EXPERIMENTS R5.13).  The row loop is bound by the CU's LDS pipe, and more than half of its LDS
-    // cycles are the walk's look-ups - which the three rows of a joint repeat: the same neighbour's free indices, the same
-    // member stiffness and cosines, once per row.  Here the 16 threads of a wave's row group g form the pieces of ALL rows
-    // of the joint that row g belongs to (the rows of a joint are consecutive, at most three, and a wave owns four
-    // consecutive rows): the group of the joint's first row inside the wave leads, the groups of its other rows idle in
-    // the walk.  A neighbour is looked up once per joint and wave, its 3 x 3 block is formed in registers (the same
-    // products in the same order: same bits) and dropped into up to three tile rows - all of them rows of this wave, so
-    // the loop still has no work-group barrier.
-    {
-        static_assert(TPR == 16, "four row groups of sixteen threads per wave");
-        const int g = (tid >> 4) & 3, e = tid & 15;
-        const int wbase = (tid >> 6) * 4;          // this wave's first row inside a block
-        int jq0 = -1, jq1 = -1, jq2 = -1, jdeg = 0, jnr = 0, ja = -1, js = 0, jr0 = 0, jr1 = 0, jr2 = 0;
-        double jv[3][3];
-        auto axis_pick = [](int r, double c0, double c1, double c2) { return r == 0 ? c0 : (r == 1 ? c1 : c2); };
-        // the 3 x 3 block rows (rows r0 .. of joint a, nr of them) of the neighbour at list position i, if it heads a run
-        auto nbr = [&](int s, int deg, int i, int nr, int r0, int r1, int r2, int& q0, int& q1, int& q2, double (&v)[3][3]) {
-            const unsigned* list = adj + s;
-            const int other = (int)(list[i] >> 16);
-            q0 = q1 = q2 = -1;
-            if (i > 0 && (int)(list[i - 1] >> 16) == other) return;
-            q0 = fi[3 * other];
-            q1 = fi[3 * other + 1];
-            q2 = fi[3 * other + 2];
-#pragma unroll
-            for (int x = 0; x < 3; ++x) v[x][0] = v[x][1] = v[x][2] = 0.0;
-            int q = i;
-            do {  // parallel members between the same two joints, in member order
-                const int m = (int)(list[q] & 0xffffu);
-                const double k = mk[m], c0 = mc[3 * m], c1 = mc[3 * m + 1], c2 = mc[3 * m + 2];
-                const int rx[3] = {r0, r1, r2};
-#pragma unroll
-                for (int x = 0; x < 3; ++x)
-                    if (x < nr) {
-                        const double cr = axis_pick(rx[x], c0, c1, c2);
-                        v[x][0] -= k * (cr * c0);
-                        v[x][1] -= k * (cr * c1);
-                        v[x][2] -= k * (cr * c2);
-                    }
-                ++q;
-            } while (q < deg && (int)(list[q] >> 16) == other);
-        };
-        auto prepare_j = [&](int c0) {
-            jq0 = jq1 = jq2 = -1;
-            jdeg = jnr = 0;
-            ja = -1;
-            const int w0 = c0 + wbase;
-            if (w0 >= n) return;
-#ifdef TRS_EXP_ASM_NOWALK
-            return;
-#endif
-            const int d0 = rowdof[w0], d1 = w0 + 1 < n ? rowdof[w0 + 1] : -1, d2 = w0 + 2 < n ? rowdof[w0 + 2] : -1,
-                      d3 = w0 + 3 < n ? rowdof[w0 + 3] : -1;     // (the same four words for the whole wave)
-            const int dme = g == 0 ? d0 : (g == 1 ? d1 : (g == 2 ? d2 : d3));
-            if (dme < 0) return;
-            const int dprev = g == 1 ? d0 : (g == 2 ? d1 : (g == 3 ? d2 : -1));
-            const int a = dme / 3;
-            if (dprev >= 0 && dprev / 3 == a) return;            // an earlier row group of this wave leads the joint
-            const int dn1 = g == 0 ? d1 : (g == 1 ? d2 : (g == 2 ? d3 : -1)), dn2 = g == 0 ? d2 : (g == 1 ? d3 : -1);
-            ja = a;
-            jr0 = dme - 3 * a;
-            jnr = 1;
-            if (dn1 >= 0 && dn1 / 3 == a) {
-                jr1 = dn1 - 3 * a;
-                jnr = 2;
-                if (dn2 >= 0 && dn2 / 3 == a) {
-                    jr2 = dn2 - 3 * a;
-                    jnr = 3;
-                }
-            }
-            if (e == TPR - 1) {                                   // the joint's own block
-                const double* dg = diag + 6 * a;                  // [xx xy xz; xy yy yz; xz yz zz]
-                const int rx[3] = {jr0, jr1, jr2};
-#pragma unroll
-                for (int x = 0; x < 3; ++x)
-                    if (x < jnr) {
-                        const int r = rx[x];
-                        jv[x][0] = dg[r];
-                        jv[x][1] = dg[r == 0 ? 1 : (r == 1 ? 3 : 4)];
-                        jv[x][2] = dg[r == 0 ? 2 : (r == 1 ? 4 : 5)];
-                    }
-                jq0 = fi[3 * a];
-                jq1 = fi[3 * a + 1];
-                jq2 = fi[3 * a + 2];
-            } else {
-                jdeg = cnt[a];
-                js = start[a];
-                if (e < jdeg) nbr(js, jdeg, e, jnr, jr0, jr1, jr2, jq0, jq1, jq2, jv);
-            }
-        };
-        prepare_j(0);
-        for (int c0 = 0; c0 < npad; c0 += TR) {
-            const int chunk = __builtin_amdgcn_readfirstlane(c0 + rr) >> 4;  // of this wave's rows
-            const int i_lo = full ? 0 : 16 * chunk;
-            const int i_hi = (has_env && !full) ? 16 * cendl[chunk] : npad;
-            const unsigned kmw = masked ? kmask[chunk] : 0xffffffffu;
-            for (int seg_lo = i_lo; seg_lo < i_hi; seg_lo += WTe) {
-                const int seg_hi = min(i_hi, seg_lo + WTe);
-                const int Ws = seg_hi - seg_lo;
-                const bool is_last = seg_hi == i_hi;
-                const int W = Ws + (is_last && with_col ? 16 : 0);
-                {   // scatter: every (row, column) of the tile is written by exactly one thread
-                    double* row0 = Tt + (size_t)(wbase + g) * Wstride - seg_lo;   // row group g; the joint's next rows follow
-                    auto drop = [&](int q0, int q1, int q2, const double (&v)[3][3]) {
-#pragma unroll
-                        for (int x = 0; x < 3; ++x)
-                            if (x < jnr) {
-                                double* row = row0 + (size_t)x * Wstride;
-                                if (q0 >= seg_lo && q0 < seg_hi) row[q0] = v[x][0];
-                                if (q1 >= seg_lo && q1 < seg_hi) row[q1] = v[x][1];
-                                if (q2 >= seg_lo && q2 < seg_hi) row[q2] = v[x][2];
-                            }
-                    };
-                    drop(jq0, jq1, jq2, jv);
-                    if (jdeg > e + TPR - 1) {  // joints with more than TPR-1 list entries: rare
-                        for (int i = e + TPR - 1; i < jdeg; i += TPR - 1) {
-                            int q0, q1, q2;
-                            double v[3][3];
-                            nbr(js, jdeg, i, jnr, jr0, jr1, jr2, q0, q1, q2, v);
-                            drop(q0, q1, q2, v);
-                        }
-                    }
-                    if (e == TPR - 1) {
-                        const int cc = c0 + rr;
-                        if (is_last && with_col) row0[seg_lo + Ws] = cc < n ? rhs[cc] : 0.0;  // load column
-                        if (cc >= n && cc >= seg_lo && cc < seg_hi) row0[cc] = 1.0;          // identity padding
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                {   // all TR rows in parallel: TPR threads per row, 16 bytes per thread and pass
-                    double* dst = S + (size_t)(c0 + rr) * ld;
-                    double* src = Tt + (size_t)rr * Wstride;
-                    for (int x = e_first * 2; x < W; x += 2 * TPR) {
-                        const int col = x < Ws ? seg_lo + x : npad + (x - Ws);
-                        if (masked && ((kmw >> (((unsigned)col >> 4) - (unsigned)chunk)) & 1u) == 0u) continue;
-                        *reinterpret_cast<d2*>(dst + col) = *reinterpret_cast<const d2*>(src + x);
-                        *reinterpret_cast<d2*>(src + x) = d2{0.0, 0.0};
-                    }
-                }
-                if (is_last && c0 + TR < npad) prepare_j(c0 + TR);  // overlaps with the stores in flight
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        return;
-    }
-#endif
     // Thread TPR-1 of a row carries the joint's own block, threads 0 .. TPR-2 the heads of the runs of
     // its adjacency list (stride TPR-1).  The first piece of every thread is formed one block AHEAD,
     // while the previous block's stores drain, so the scatter itself is three LDS writes.
