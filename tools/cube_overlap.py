@@ -16,8 +16,14 @@ for r in rows:
         continue
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "")))
 ev.sort()
-# the LAST third of the dispatches = the timed steps (warm-up, hints and the instrumented step come first)
-ev = ev[len(ev) // 2:]
+# the LAST burst of dispatches = the timed steps (the run's phases are separated by host synchronisations: gaps with
+# nothing in flight for more than a millisecond)
+cut, reach = 0, ev[0][1]
+for k, (s0, e0, _, _) in enumerate(ev):
+    if s0 - reach > 1_000_000:
+        cut = k
+    reach = max(reach, e0)
+ev = ev[cut:]
 t0, t1 = ev[0][0], max(e[1] for e in ev)
 points = sorted([(s, 1) for s, _, _, _ in ev] + [(e, -1) for _, e, _, _ in ev])
 hist, level, last = defaultdict(int), 0, t0
