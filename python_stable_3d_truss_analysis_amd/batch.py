@@ -1370,8 +1370,6 @@ class RaggedSolver:
         buckets (they run one after the other on its stream) and point the buckets at it.  The buckets are launched in
         the order of `self.buckets`; resident batches keep them by descending cost, so every lane starts with its
         longest bucket and the step ends over the short ones.  Nothing of this solver may be in flight."""
-        torch, dev = self.torch, self.device
-        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
         if not self.host_io:   # (the host-fed pipeline has its own order: the flow shop's)
             self.buckets.sort(key=lambda bk: -bk["cost"])
         load = [0.0] * self.lanes
