@@ -9,6 +9,10 @@ inputs resident in HBM before the timed region.  One step = one pass of the whol
 the batch: dofmap -> assemble -> potrf -> potrs -> recover (five stages through the C ABI).
 Weak scaling: every rank solves its own batch; no collective on the data path.
 
+Order of a run: the legs of configs 3 and 5 (each with a barrier-bracketed region of its own), then the headline - W
+warm-up steps in the form of the timed ones, the K timed steps between barriers (`value`), `--repeats` further repeats of
+that region (`repeats`: min / median / max) -, then the informational legs (`leg_order` in the line).
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline      dominant kernel (the factorisation with the fused substitution): algorithmic bytes or executed
                 tile FLOP / measured average launch duration (events recorded on the launch stream inside the
