@@ -101,7 +101,11 @@ extern "C" {
                                         metadata of an earlier solve of the same topology - that no matrix of the
                                         batch skips tiles: the mask need not be formed again) */
 #define TRS_HINT_RECOVER_UNSTAGED 32 /* trs_recover / trs_solve: the path for trusses whose tables exceed a CU's LDS
-                                        (u, f_ext in the output arrays, reactions by FP64 atomics), whatever the size */
+                                        (u, f_ext in the output arrays; the reactions in the same fixed order, bit for
+                                        bit those of the staged path), whatever the size */
+#define TRS_HINT_RECOVER_SCAN 128    /* with TRS_HINT_RECOVER_UNSTAGED (tests): also the fall-back of that path for a truss
+                                        with more than 32768 member ends at its supports - no member-end lists, a wave
+                                        per constrained joint walks all members; same bits again */
 
 int trs_abi_version(void);
 
@@ -186,7 +190,7 @@ int trs_recover(int B, int nJ_max, int nM_max, const double *xyz, const int32_t 
                 const double *uf, int ld_uf, double *u /* [B][nJ_max][3] */,
                 double *f_ext /* [B][nJ_max][3] */, double *N /* [B][nM_max] */,
                 const int32_t *joint_out /* [B][nJ_max] or NULL */,
-                int hints /* TRS_HINT_RECOVER_UNSTAGED or 0 */, void *stream);
+                int hints /* TRS_HINT_RECOVER_UNSTAGED (| TRS_HINT_RECOVER_SCAN) or 0 */, void *stream);
 
 /* trs_recover with the bucket SCATTER of a ragged batch folded in (ABI 9; `batch.RaggedSolver`): the results of truss b
  * go to row out_rows[b] (int64, device) of result arrays whose rows are nJ_out_max joints / nM_out_max members wide

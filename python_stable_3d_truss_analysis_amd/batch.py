@@ -282,7 +282,8 @@ def _require_gpu(device):
 #:   compact             K_ff leaves the assembly as compact entry lists, tiles formed in the factorisation
 #:   fused_substitution  the wave that factors a narrow-envelope matrix substitutes it as well
 #:   recover_unstaged    force trs_recover's path for trusses whose tables exceed a CU's LDS
-DEFAULT_OPTIONS = {"compact": False, "fused_substitution": True, "recover_unstaged": False}
+#:   recover_scan        with recover_unstaged: also that path's fall-back without member-end lists (tests)
+DEFAULT_OPTIONS = {"compact": False, "fused_substitution": True, "recover_unstaged": False, "recover_scan": False}
 
 
 def default_options():
@@ -495,7 +496,8 @@ class DeviceBatch:
     def _stage_hints(self):
         return (HINT_COMPACT if self.options["compact"] and self.env is not None else 0) | \
                (0 if self.options["fused_substitution"] else HINT_SEPARATE_STAGES) | \
-               (HINT_RECOVER_UNSTAGED if self.options["recover_unstaged"] else 0)
+               (HINT_RECOVER_UNSTAGED if self.options["recover_unstaged"] else 0) | \
+               (HINT_RECOVER_SCAN if self.options["recover_scan"] else 0)
 
     def assemble(self, flags=0):
         if self.all_narrow and self.env is not None:
@@ -532,7 +534,7 @@ class DeviceBatch:
             self.nJ.data_ptr(), self.nM.data_ptr(), self.uf.data_ptr(), self.rows, self.u.data_ptr(),
             self.f_ext.data_ptr(), self.N.data_ptr(),
             self.joint_out.data_ptr() if self.joint_out is not None else None,
-            self._stage_hints() & HINT_RECOVER_UNSTAGED, self._stream()), "trs_recover")
+            self._stage_hints() & (HINT_RECOVER_UNSTAGED | HINT_RECOVER_SCAN), self._stream()), "trs_recover")
 
     def recover_rows(self, rows, out, nJ_out_max, nM_out_max):
         """`trs_recover_rows`: the recovery with a ragged batch's bucket scatter folded in - the results of truss b go
@@ -544,7 +546,7 @@ class DeviceBatch:
             self.nJ.data_ptr(), self.nM.data_ptr(), self.uf.data_ptr(), self.rows,
             self.joint_out.data_ptr() if self.joint_out is not None else None, self.info.data_ptr(),
             rows.data_ptr(), int(nJ_out_max), int(nM_out_max), out["u"].data_ptr(), out["f_ext"].data_ptr(),
-            out["N"].data_ptr(), out["info"].data_ptr(), self._stage_hints() & HINT_RECOVER_UNSTAGED, self._stream()),
+            out["N"].data_ptr(), out["info"].data_ptr(), self._stage_hints() & (HINT_RECOVER_UNSTAGED | HINT_RECOVER_SCAN), self._stream()),
             "trs_recover_rows")
 
     def solve_rows(self, rows, out, nJ_out_max, nM_out_max):
@@ -844,6 +846,7 @@ def profile_permutation(packed: PackedBatch, return_choice=False, effort=2):
 NARROW_MAX_BELOW = 24   # csrc/trs_common.h TRS_NARROW_MAX_BELOW: reach up to which a matrix goes to a wave of its own
 # include/trs_solver.h
 HINT_NO_WIDE, HINT_SUBSTITUTED, HINT_COMPACT, HINT_SEPARATE_STAGES, HINT_NO_SMALL, HINT_RECOVER_UNSTAGED = 1, 2, 4, 8, 16, 32
+HINT_RECOVER_SCAN = 128
 HINT_ALL_TILES = 64
 ORDER_RCM_BELOW = 128           # csrc/order.hip RCM_BELOW: effort 3 prices Cuthill-McKee below this many free joints
 ASM_FULL_SYMMETRIC, ASM_COMPACT, ASM_ALL_NARROW, ASM_ALL_TILES = 1, 2, 4, 8
@@ -1338,7 +1341,11 @@ class RaggedSolver:
             renumbered = plan is not None and not small   # the fused small-system kernel gains nothing from an order
             jout = e([Bb, nJ_b], torch.int32) if renumbered else None
             db = DeviceBatch.from_device(sub, n_b, joint_out=jout)
-            db.options.update(options or {})
+            opts = dict(options or {})
+            compact_rows = opts.pop("compact_rows", None)   # (lo, hi): the compact form for the buckets of lo <= rows < hi
+            db.options.update(opts)
+            if compact_rows is not None:
+                db.options["compact"] = bool(compact_rows[0] <= db.rows < compact_rows[1])
             if not db.small:
                 need["S"], need["uf"] = Bb * db.rows * db.ld, Bb * db.rows
                 need["work"] = Bb * self.lib.trs_assemble_work_bytes(nJ_b, nM_b, n_b)

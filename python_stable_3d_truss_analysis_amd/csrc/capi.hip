@@ -107,7 +107,7 @@ int trs_recover(int B, int nJ_max, int nM_max, const double* xyz, const int32_t*
                 const int32_t* joint_out, int hints, void* stream) {
     if (B < 0 || nJ_max <= 0 || nM_max < 0) return (int)hipErrorInvalidValue;
     return trs_recover_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf,
-                              u, f_ext, N, joint_out, (hints & TRS_HINT_RECOVER_UNSTAGED) != 0,
+                              u, f_ext, N, joint_out, hints & (TRS_HINT_RECOVER_UNSTAGED | TRS_HINT_RECOVER_SCAN),
                               (hipStream_t)stream, nullptr, 0, 0, nullptr, nullptr);
 }
 
@@ -120,7 +120,7 @@ int trs_recover_rows(int B, int nJ_max, int nM_max, const double* xyz, const int
         (info_out != nullptr && info == nullptr))
         return (int)hipErrorInvalidValue;
     return trs_recover_launch(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf,
-                              u, f_ext, N, joint_out, (hints & TRS_HINT_RECOVER_UNSTAGED) != 0,
+                              u, f_ext, N, joint_out, hints & (TRS_HINT_RECOVER_UNSTAGED | TRS_HINT_RECOVER_SCAN),
                               (hipStream_t)stream, reinterpret_cast<const long long*>(out_rows), nJ_out_max,
                               nM_out_max, info, info_out);
 }
@@ -242,7 +242,7 @@ int trs_solve(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
                            stream);
     if (rc) return rc;
     return trs_recover(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf, u,
-                       f_ext, N, joint_out, hints & TRS_HINT_RECOVER_UNSTAGED, stream);
+                       f_ext, N, joint_out, hints & (TRS_HINT_RECOVER_UNSTAGED | TRS_HINT_RECOVER_SCAN), stream);
 }
 
 int trs_solve_rows(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz, const int32_t* conn,
@@ -271,7 +271,8 @@ int trs_solve_rows(int B, int nJ_max, int nM_max, int n_max_bound, const double*
                            stream);
     if (rc) return rc;
     return trs_recover_rows(B, nJ_max, nM_max, xyz, conn, E, A, loads, free_index, nJ, nM, uf, ld_uf, joint_out, info,
-                            out_rows, nJ_out_max, nM_out_max, u, f_ext, N, info_out, hints & TRS_HINT_RECOVER_UNSTAGED,
+                            out_rows, nJ_out_max, nM_out_max, u, f_ext, N, info_out,
+                            hints & (TRS_HINT_RECOVER_UNSTAGED | TRS_HINT_RECOVER_SCAN),
                             stream);
 }
 

@@ -6,6 +6,7 @@
 //
 // Also the constraint reductions the GA fitness needs (truss.py:166-168,429-462; ga.py:139-149).
 #include "trs_common.h"
+#include "../../include/trs_solver.h"
 
 namespace {
 
@@ -36,12 +37,56 @@ __device__ __forceinline__ double member_axial(const MemberGeom& g, double EA, c
     return k * proj;
 }
 
+// The end force of member (g, axial) on its joint `end` (1: +N c on joint1, 0: -N c on joint0), added to a
+// running reaction sum.  ONE function with explicit fused multiply-adds for every path of the kernel: the paths
+// then round alike and their reactions are equal bit for bit.
+__device__ __forceinline__ void add_end_force(double (&r)[3], const double (&c)[3], double axial, int end) {
+    const double s = end ? axial : -axial;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) r[a] = fma(s, c[a], r[a]);
+}
+
+// Reaction at one constrained joint from its list of member ends ((member << 1) | end): the list is sorted by
+// member id in place (insertion sort: the lists are short) and summed in that order.
+template <class ListPtr>
+__device__ __forceinline__ void joint_reaction(ListPtr list, const int deg, const int2* __restrict__ CNI,
+                                               const double* __restrict__ X, const double* __restrict__ E,
+                                               const double* __restrict__ A, const size_t mbase, const double* u,
+                                               const int* jo, double (&r)[3]) {
+    for (int i = 1; i < deg; ++i) {
+        const int key = list[i];
+        int p = i - 1;
+        while (p >= 0 && list[p] > key) {
+            list[p + 1] = list[p];
+            --p;
+        }
+        list[p + 1] = key;
+    }
+    r[0] = r[1] = r[2] = 0.0;
+    for (int i = 0; i < deg; ++i) {
+        const int m = list[i] >> 1, end = list[i] & 1;
+        const int2 c = CNI[m];
+        const MemberGeom g = member_geom(X, c.x, c.y);
+        const double axial = member_axial(g, E[mbase + m] * A[mbase + m], u, jo ? jo[c.x] : c.x, jo ? jo[c.y] : c.y);
+        add_end_force(r, g.c, axial, end);
+    }
+}
+
+// entries of the member-end lists the path without LDS staging keeps in LDS (128 KB)
+#define TRS_RECOVER_LIST_CAP 32768
+
 // STAGED: u and f_ext of the truss are staged in LDS (gathers and the reaction sums stay on chip), and
 // the reactions are summed in a FIXED order: the member ends at constrained joints are counting-sorted
 // by joint (integer LDS atomics), every such joint's short list is sorted by member id and one thread
 // adds its members' end forces in that order - no floating-point atomics, bit-reproducible.
-// For trusses with more than ~2500 joints (tables beyond a CU's LDS) u and f_ext live directly in the
-// output arrays and the reactions are global FP64 atomics (reproducible to rounding only).
+// !STAGED - trusses with more than ~1500 joints, whose tables exceed a CU's LDS: u and f_ext live directly in
+// the output arrays; the reactions are summed in the SAME fixed order (results bit for bit those of the staged
+// path).  Only the member ends at CONSTRAINED joints need lists, and those are few (the supports): the lists are
+// kept in LDS (TRS_RECOVER_LIST_CAP entries), their per-joint (count, start) pair in the one place of the output
+// that is free until the reaction is known - the f_ext entry of the joint's first constrained axis, as two
+// 32-bit integers, counted with integer atomics.  A truss with more member ends at its supports than the lists
+// hold (or `scan_only`, for tests) takes the slow path without lists: a wave per constrained joint walks ALL
+// members in id order.  No floating-point atomics anywhere.
 template <bool STAGED>
 __global__ __launch_bounds__(256) void trs_recover_kernel(
     const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
@@ -53,7 +98,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     // scatter form (trs_recover_rows; null / 0 otherwise): the results of truss b go to row out_rows[b] of result
     // arrays whose rows are nJ_out / nM_out wide (>= this batch's), and its factorisation status to info_out
     const long long* __restrict__ out_rows, const int nJ_out, const int nM_out, const int* __restrict__ info_in,
-    int* __restrict__ info_out) {
+    int* __restrict__ info_out, const int scan_only) {
     extern __shared__ double sh[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int joints = nJ[b];
@@ -107,13 +152,21 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
             cnt[j] = 0;
             held[j] = j < joints ? (unsigned char)((fi[3 * j] < 0) | (fi[3 * j + 1] < 0) | (fi[3 * j + 2] < 0)) : (unsigned char)0;
         }
-    if constexpr (!STAGED) __threadfence_block();
+    if constexpr (!STAGED) __threadfence();
     __syncthreads();
     const double* X = xyz + (size_t)b * ndof_max;
     auto constrained = [&](int j) {
         if constexpr (STAGED) return (int)held[j];
         else return (fi[3 * j] < 0) | (fi[3 * j + 1] < 0) | (fi[3 * j + 2] < 0);
     };
+    // !STAGED: the (count / fill cursor, list start) pair of constrained joint j - two ints in the f_ext entry of its
+    // first constrained axis (zeroed above; the reaction overwrites it at the end)
+    auto slot = [&](int j) {
+        const int a0 = fi[3 * j] < 0 ? 0 : (fi[3 * j + 1] < 0 ? 1 : 2);
+        return reinterpret_cast<int*>(&f[3 * J(j) + a0]);
+    };
+    auto slot_get = [&](int j, int k) { return __hip_atomic_load(slot(j) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto slot_set = [&](int j, int k, int v) { __hip_atomic_store(slot(j) + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto ends_of = [&](int r, int m) {   // end joints of member m = tid + 256 r of this thread
         int2 c = CNI[m < members ? m : 0];
 #pragma unroll
@@ -133,11 +186,8 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
                 if (constrained(j0)) atomicAdd(&cnt[j0], 1);
                 if (constrained(j1)) atomicAdd(&cnt[j1], 1);
             } else {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    if (fi[3 * j1 + a] < 0) atomicAdd(&f[3 * J(j1) + a], axial * g.c[a]);
-                    if (fi[3 * j0 + a] < 0) atomicAdd(&f[3 * J(j0) + a], -axial * g.c[a]);
-                }
+                if (constrained(j0)) atomicAdd(slot(j0), 1);
+                if (constrained(j1)) atomicAdd(slot(j1), 1);
             }
         }
         N_out[orow * omem + m] = axial;
@@ -162,45 +212,18 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         __syncthreads();
         for (int j = tid; j < joints; j += 256) cnt[j] = 0;  // reused as the fill cursor
         __syncthreads();
-#ifdef TRS_EXP_RECOVER_NOFILL   // timing experiment only (wrong reactions): no grouping of the member ends either
-        for (int m = tid, r = 0; m < 0; m += 256, ++r) {
-#else
         for (int m = tid, r = 0; m < members; m += 256, ++r) {
-#endif
             const int2 c = r < MR ? ends_of(r, m) : CNI[m];
             const int j0 = c.x, j1 = c.y;
             if (constrained(j0)) ends[start[j0] + atomicAdd(&cnt[j0], 1)] = m << 1;
             if (constrained(j1)) ends[start[j1] + atomicAdd(&cnt[j1], 1)] = (m << 1) | 1;
         }
         __syncthreads();
-#ifdef TRS_EXP_RECOVER_NOREACT   // timing experiment only (wrong reactions): what the per-joint reaction sums cost
-        for (int j = tid; j < 0; j += 256) {
-#else
         for (int j = tid; j < joints; j += 256) {
-#endif
             const int deg = cnt[j];
             if (deg == 0) continue;
-            int* list = ends + start[j];
-            for (int i = 1; i < deg; ++i) {  // insertion sort by member id: the lists are short
-                const int key = list[i];
-                int p = i - 1;
-                while (p >= 0 && list[p] > key) {
-                    list[p + 1] = list[p];
-                    --p;
-                }
-                list[p + 1] = key;
-            }
-            double r[3] = {0.0, 0.0, 0.0};
-            for (int i = 0; i < deg; ++i) {
-                const int m = list[i] >> 1, end = list[i] & 1;
-                const size_t mm = (size_t)b * nM_max + m;
-                const int2 c = CNI[m];
-                const int j0 = c.x, j1 = c.y;
-                const MemberGeom g = member_geom(X, j0, j1);
-                const double axial = member_axial(g, E[mm] * A[mm], u, j0, j1);
-#pragma unroll
-                for (int a = 0; a < 3; ++a) r[a] += end ? axial * g.c[a] : -axial * g.c[a];
-            }
+            double r[3];
+            joint_reaction(ends + start[j], deg, CNI, X, E, A, (size_t)b * nM_max, u, nullptr, r);
 #pragma unroll
             for (int a = 0; a < 3; ++a)
                 if (fi[3 * j + a] < 0) f[3 * j + a] = r[a];
@@ -210,6 +233,97 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
             const int o = jo ? 3 * jo[d / 3] + d % 3 : d;
             u_out[orow * odof + o] = u[d];
             f_out[orow * odof + o] = d < ndof ? f[d] : 0.0;
+        }
+    } else {
+        int* lists = reinterpret_cast<int*>(sh);        // [TRS_RECOVER_LIST_CAP] member ends, grouped by joint
+        int* wsum = lists + TRS_RECOVER_LIST_CAP;        // [4] wave totals of the scan
+        // (the phases of this path talk through global memory - the counts, starts and cursors in f_ext: every phase
+        // boundary is a device-scope fence and a barrier; the path is rare and the fences are cheap)
+        __threadfence();
+        __syncthreads();
+        // exclusive scan of the counts over the constrained joints, 256 joints a round
+        int base = 0;
+        for (int j0 = 0; j0 < joints; j0 += 256) {
+            const int j = j0 + tid;
+            const bool own = j < joints && constrained(j);
+            const int v = own ? slot_get(j, 0) : 0;
+            int incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off);
+                if ((tid & 63) >= off) incl += up;
+            }
+            if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                before += w < (tid >> 6) ? wsum[w] : 0;
+                total += wsum[w];
+            }
+            if (own) {
+                slot_set(j, 1, base + before + incl - v);
+                slot_set(j, 0, 0);   // reused as the fill cursor
+            }
+            base += total;
+            __syncthreads();
+        }
+        __threadfence();
+        __syncthreads();
+        if (base <= TRS_RECOVER_LIST_CAP && scan_only == 0) {
+            for (int m = tid, r = 0; m < members; m += 256, ++r) {
+                const int2 c = r < MR ? ends_of(r, m) : CNI[m];
+                const int j0 = c.x, j1 = c.y;
+                if (constrained(j0)) lists[slot_get(j0, 1) + atomicAdd(slot(j0), 1)] = m << 1;
+                if (constrained(j1)) lists[slot_get(j1, 1) + atomicAdd(slot(j1), 1)] = (m << 1) | 1;
+            }
+            __threadfence();
+            __syncthreads();
+            for (int j = tid; j < joints; j += 256) {
+                if (!constrained(j)) continue;
+                double r[3];
+                joint_reaction(lists + slot_get(j, 1), slot_get(j, 0), CNI, X, E, A, (size_t)b * nM_max, u, jo, r);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if (fi[3 * j + a] < 0) f[3 * J(j) + a] = r[a];   // (the joint's own slot among them)
+            }
+        } else {
+            // no lists: a wave per constrained joint walks all members, 64 at a time, and adds the ends it finds in
+            // member order (every lane carries the same sum)
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int j = wave; j < joints; j += 4) {
+                if (!constrained(j)) continue;
+                double r[3] = {0.0, 0.0, 0.0};
+                for (int m0 = 0; m0 < members; m0 += 64) {
+                    const int m = m0 + lane;
+                    const int2 c = m < members ? CNI[m] : int2{-1, -1};
+                    const bool h0 = c.x == j, h1 = c.y == j;
+                    const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+                    unsigned long long any = b0 | b1;
+                    if (any == 0ull) continue;
+                    double axial = 0.0, cc[3] = {0.0, 0.0, 0.0};
+                    if (h0 || h1) {
+                        const MemberGeom g = member_geom(X, c.x, c.y);
+                        const size_t mm = (size_t)b * nM_max + m;
+                        axial = member_axial(g, E[mm] * A[mm], u, J(c.x), J(c.y));
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) cc[a] = g.c[a];
+                    }
+                    while (any != 0ull) {
+                        const int src = __builtin_ctzll(any);
+                        any &= any - 1;
+                        const double ax = __shfl(axial, src);
+                        const double cs[3] = {__shfl(cc[0], src), __shfl(cc[1], src), __shfl(cc[2], src)};
+                        if ((b0 >> src) & 1ull) add_end_force(r, cs, ax, 0);
+                        if ((b1 >> src) & 1ull) add_end_force(r, cs, ax, 1);
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        if (fi[3 * j + a] < 0) f[3 * J(j) + a] = r[a];
+                }
+            }
         }
     }
 }
@@ -277,9 +391,14 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
     const size_t lds = ((size_t)6 * nJ_max * sizeof(double) +
                         ((size_t)2 * nJ_max + 1 + 2 * (size_t)nM_max) * sizeof(int) + (size_t)nJ_max + 15) / 16 * 16;
     if (lds > 160 * 1024 || force_unstaged) {
-        hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), 0, stream, xyz, conn, E, A, loads,
+        const size_t lds_lists = (size_t)(TRS_RECOVER_LIST_CAP + 8) * sizeof(int);
+        static const int lists_limit_set = (int)hipFuncSetAttribute(
+            reinterpret_cast<const void*>(trs_recover_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            160 * 1024);
+        (void)lists_limit_set;
+        hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), lds_lists, stream, xyz, conn, E, A, loads,
                            free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out, out_rows, nJ_out,
-                           nM_out, info_in, info_out);
+                           nM_out, info_in, info_out, (force_unstaged & TRS_HINT_RECOVER_SCAN) != 0);
         return (int)hipGetLastError();
     }
     static const int lds_limit_set = (int)hipFuncSetAttribute(   // once per process, not per launch
@@ -288,7 +407,7 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
     (void)lds_limit_set;
     hipLaunchKernelGGL(trs_recover_kernel<true>, dim3(B), dim3(256), lds, stream, xyz, conn, E, A, loads,
                        free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out, out_rows, nJ_out, nM_out,
-                       info_in, info_out);
+                       info_in, info_out, 0);
     return (int)hipGetLastError();
 }
 

@@ -11,7 +11,7 @@ for spec in "$@"; do
   objs=""
   for f in dofmap assemble potrf potrs recover small graphfeat order rows cubegen capi; do
     if [ -n "${ONLY:-}" ] && ! echo " $ONLY " | grep -q " $f "; then objs="$objs $f.o"; continue; fi
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-value $flags -c $f.hip -o /tmp/var_${tag}_$f.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value $flags -c $f.hip -o /tmp/var_${tag}_$f.o &
     objs="$objs /tmp/var_${tag}_$f.o"
   done
   wait
