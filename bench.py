@@ -20,11 +20,16 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 timed steps), the roof picked by arithmetic intensity; `frac_dense_8d` = SURVEY 8d's dense figure
   cpu_baseline  the numpy oracle (faithful restatement of the reference's per-truss path) timed on
                 the host cores of this box, bounded sample, 1 thread (rank 0, N = 1 only)
+  north_star_scaling   the three per-N lines north_star asks for in one record: config 2 weak-scaled (= the headline),
+                config 3 strong-scaled (`--cube-total` trusses in all), config 5 strong-scaled and streamed
+                (`--dataset-total` samples in all), each with the spread over the ranks and its global-index shards
   cube_batch    BASELINE config 3 at EVERY N: `--cube-batch` random cube trusses per GPU generated on the device,
                 joint order INSIDE the timed step (batch.RaggedSolver), solves/s + roofline fractions
   dataset       BASELINE config 5 at every N: samples/s of data.dataset_chunks (generation, order, two solves and
                 graph features on the device)
   extra.profile_order_hoisted (the headline of rounds 1-5: order found once before the timed region),
+  large_truss   the route of trusses beyond the wave-per-matrix kernel's envelopes (8x8x8 grid, n ~ 2 000): stage
+                times, executed TFLOP/s and algorithmic GB/s of the work-group factorisation
   pcie_inclusive, given_joint_order, dense_mode_potrf, ga_generation (BASELINE config 4),
   reference_protocol (the reference's own published benchmark: 30 x Truss.Solve() per case)   informational legs at N = 1
 """
@@ -346,15 +351,105 @@ def envelope_counts_batch(n_free, nJ, nM, ft, last, cend, narrow, kmask=None):
             "order_bytes": 2 * (49 * np.asarray(nJ, dtype=np.int64) + 8 * np.asarray(nM, dtype=np.int64)) + 4 * np.asarray(nJ)}
 
 
-def cube_workload(B, rank, seed=CUBE_SEED, device=None):
+def cube_workload(B, rank, seed=CUBE_SEED, device=None, first=None):
     """BASELINE config 3: B random cube trusses as `GenerateRandomCubeTrusses(gridRange=(6,6,6), numCube ~ U{8..190},
     LinkType.Random, GenerateMethod.Random)`, generated ON THE DEVICE (csrc/cubegen.hip: bit for bit the native
     host generator csrc/cubegen.c, whose distribution is pinned against the reference in tests/test_generate.py).
-    Rank r draws the trusses with global indices r B .. (r + 1) B - 1.  Returns (sizes, device tensors)."""
+    The dataset is keyed by the GLOBAL truss index: rank r draws the trusses r B .. (r + 1) B - 1, or - `first` -
+    the trusses first .. first + B - 1.  Returns (sizes, device tensors)."""
     from python_stable_3d_truss_analysis_amd import generate as gen
     from python_stable_3d_truss_analysis_amd.data import dataset_sizes
-    sizes = dataset_sizes(seed, rank * B, B, (8, 190))
-    return gen.generate_cube_batch_device(sizes, gridRange=(6, 6, 6), seed=seed, first_index=rank * B, device=device)
+    first = rank * B if first is None else int(first)
+    sizes = dataset_sizes(seed, first, B, (8, 190))
+    return gen.generate_cube_batch_device(sizes, gridRange=(6, 6, 6), seed=seed, first_index=first, device=device)
+
+
+def strong_shard(total, rank, world):
+    """Contiguous shard of a dataset of `total` globally indexed units: (first, count) of `rank`.  The units are i.i.d.
+    draws, so contiguous shards are balanced in cost as well as in count (SURVEY 8e asks for a size-balanced deal
+    where the host knows the sizes: `shard.py` does that for packed batches)."""
+    share = (int(total) + world - 1) // world
+    first = min(int(total), rank * share)
+    return first, max(0, min(share, int(total) - first))
+
+
+def config3_strong_leg(args, device, torch, batch, barrier, reduce_max, gather, rank, world):
+    """north_star's scaling sentence for config 3, STRONG-scaled: `--cube-total` (65 536) cube trusses in all, rank r
+    solves the global indices of `strong_shard`; K steps between barriers, max over the ranks."""
+    import numpy as np
+    first, count = strong_shard(args.cube_total, rank, world)
+    packed, tensors = cube_workload(count, rank, device=device, first=first)
+    solver = batch.RaggedSolver(packed, reorder=True, tensors=tensors)
+    for _ in range(max(1, args.cube_warmup)):
+        solver.step()
+    torch.cuda.synchronize(device)
+    solver.adopt_launch_hints()
+    solver.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.cube_steps):
+        solver.step()
+    barrier()
+    local = time.perf_counter() - t0
+    lo, hi = reduce_max(local, "min"), reduce_max(local)
+    bad = int((solver.info != 0).sum().item())
+    shards = gather({"rank": rank, "first": first, "count": count, "members": int(packed.nM.astype(np.int64).sum()),
+                     "joints": int(packed.nJ.astype(np.int64).sum()), "info_nonzero": bad})
+    del solver
+    batch.release_workspaces()
+    if rank != 0:
+        return None
+    return {"config": "BASELINE config 3: mixed cube trusses (grid 6x6x6, 8..190 cubes), one ragged batch",
+            "scaling": "strong", "total_trusses": int(args.cube_total), "steps": args.cube_steps,
+            "value": args.cube_total * args.cube_steps / hi, "unit": "solves/s",
+            "ms_per_step": hi / args.cube_steps * 1e3,
+            "rank_ms_per_step": {"min": lo / args.cube_steps * 1e3, "max": hi / args.cube_steps * 1e3},
+            "shards": shards, "info_nonzero": sum(sh["info_nonzero"] for sh in shards),
+            "note": "rank r holds the trusses with the global indices [first, first + count) resident and solves them "
+                    "every step (joint order inside the step); no exchange between the ranks"}
+
+
+def config5_strong_leg(args, device, torch, barrier, reduce_max, gather, rank, world):
+    """north_star's scaling sentence for config 5, STRONG-scaled and END TO END: a dataset of `--dataset-total` (1e6)
+    cube trusses, two solves per sample, every sample delivered in host memory as the packed HeteroData tensors
+    (`data.dataset_stream`); rank r owns the chunks r, r + world, ... of the globally indexed dataset."""
+    from python_stable_3d_truss_analysis_amd import MemberType, TaskType
+    from python_stable_3d_truss_analysis_amd import data as gdata
+    total = int(args.dataset_total)
+    per_rank = (total + world - 1) // world
+    chunks_per_rank = max(1, (per_rank + 32767) // 32768)
+    chunk = max(1, (per_rank + chunks_per_rank - 1) // chunks_per_rank)   # equal chunks of at most 32 768, the same number per rank
+    kw = dict(seed=11, numCubeRange=(8, 190), gridRange=(6, 6, 6), fixedMemberType=MemberType(1., 1e7, 0.1),
+              taskType=TaskType.REGRESSION, device=device, forceScale=1e3, displaceScale=0.1, positionScale=100.)
+    for _ in gdata.dataset_stream(min(total, 2 * chunk), rank=0, world=1, chunk=chunk, **kw):   # warm: rings, allocator
+        pass
+    barrier()
+    t0 = time.perf_counter()
+    got = nbytes = bad = joints = 0
+    firsts = []
+    for graphs in gdata.dataset_stream(total, rank=rank, world=world, chunk=chunk, **kw):
+        got += len(graphs)
+        nbytes += graphs.nbytes
+        bad += int(graphs.tensors["info"].ne(0).sum().item())
+        joints += int(graphs.nJ.sum())
+        firsts.append([int(graphs.first), len(graphs)])
+    barrier()
+    local = time.perf_counter() - t0
+    lo, hi = reduce_max(local, "min"), reduce_max(local)
+    shards = gather({"rank": rank, "chunks": firsts, "samples": got, "joints": joints, "bytes": nbytes, "info_nonzero": bad})
+    gdata.release_stream_buffers()
+    if rank != 0:
+        return None
+    return {"config": "BASELINE config 5: cube-truss dataset generation, two solves per sample, streamed to the host "
+                      "as packed HeteroData tensors",
+            "scaling": "strong", "total_samples": total, "chunk": chunk, "solves_per_sample": 2,
+            "value": total / hi, "unit": "samples/s", "seconds": hi,
+            "rank_seconds": {"min": lo, "max": hi},
+            "bytes_per_sample": sum(sh["bytes"] for sh in shards) / max(1, sum(sh["samples"] for sh in shards)),
+            "shards": shards, "info_nonzero": sum(sh["info_nonzero"] for sh in shards),
+            "note": "data.dataset_stream on every rank: generation, joint order, two solves, packed feature kernel on "
+                    "the device; DMA into page-locked host memory overlapped with the next chunk; no exchange "
+                    "between the ranks"}
 
 
 def cube_batch_leg(args, device, torch, batch, barrier, reduce_max, rank, world, cpu=None):
@@ -569,6 +664,75 @@ def dataset_streamed_leg(args, device, resident_rate):
                     "torch_geometric is installed, else the dict-of-stores stand-in)"}
 
 
+def large_truss_leg(args, device, torch, batch):
+    """Informational, rank 0 at N = 1: the route LARGE trusses take (the reference has no size cap, truss.py:307-316) -
+    `--large-trusses` (512) cube trusses of 300..400 cubes on an 8 x 8 x 8 grid (n_free ~ 1 500..2 000, ~4 000
+    members): joint order on the device, then the staged pipeline - their envelopes reach further below the diagonal
+    blocks than the wave-per-matrix kernel takes, so the factorisation is `trs_potrf_kernel` (a work-group per matrix,
+    LDS hand-offs) and the substitution `trs_potrs_kernel`.  Stage times from events, algorithmic bytes and executed
+    MFMA FLOP from the envelope metadata of every truss."""
+    import numpy as np
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    B = int(args.large_trusses)
+    cubes = np.random.default_rng(21).integers(300, 401, size=B)
+    sizes, tensors = gen.generate_cube_batch_device(cubes, gridRange=(8, 8, 8), seed=21, device=device)
+    ordered = batch.joint_order_device(torch, tensors, effort=3)
+    tens = dict(tensors)
+    tens.update({k: ordered[k] for k in ("xyz", "conn", "cbits", "loads")})
+    dev = batch.DeviceBatch.from_device(tens, sizes.n_max, joint_out=ordered["perm"])
+    find_order = lambda: batch.joint_order_device(torch, tensors, effort=3, out=ordered)
+    calls = (("order", find_order), ("dofmap", dev.dofmap), ("assemble", dev.assemble), ("potrf", dev.potrf),
+             ("potrs", dev.potrs), ("recover", dev.recover))
+    for _ in range(2):
+        for _, call in calls:
+            call()
+    torch.cuda.synchronize(device)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for _, call in calls:
+            call()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / reps
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in calls] for _ in range(reps)]
+    for r in range(reps):
+        for (name, call), (e0, e1) in zip(calls, ev[r]):
+            e0.record(); call(); e1.record()
+    torch.cuda.synchronize(device)
+    stage_ms = {name: float(np.mean([ev[r][i][0].elapsed_time(ev[r][i][1]) for r in range(reps)]))
+                for i, (name, _) in enumerate(calls)}
+    env = dev.env.cpu().numpy()
+    nchm, npan = dev.rows // 16, dev.rows // 64
+    narrow = (env[:, nchm + npan] & 0xff) == 1
+    flops = asm_b = potrf_b = potrs_b = rec_b = dense_flops = 0.0
+    for b in range(B):
+        n, nJ, nM = int(sizes.n_free[b]), int(sizes.nJ[b]), int(sizes.nM[b])
+        ft, last = env[b, :nchm], env[b, nchm:nchm + npan]
+        cend = env[b, nchm + npan + 8: nchm + npan + 8 + nchm]
+        kmask = env[b, 2 * nchm + npan + 8: 3 * nchm + npan + 8]
+        c = algorithmic_counts(n, nJ, nM, cend, bool(narrow[b]), kmask)
+        flops += potrf_tile_flops(n, ft, last, cend, bool(narrow[b]))
+        dense_flops += c["potrf_flops"]
+        asm_b += c["assemble_bytes"]; potrf_b += c["potrf_bytes"]; potrs_b += c["potrs_bytes"]; rec_b += c["recover_bytes"]
+    res_info = int((dev.info != 0).sum().item())
+    gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9
+    potrf_tf = flops / (stage_ms["potrf"] * 1e-3) / 1e12
+    return {"workload": f"{B} cube trusses of 300..400 cubes on an 8x8x8 grid: {int(sizes.nM.min())}..{int(sizes.nM.max())} "
+                        f"members, n_free {int(sizes.n_free.min())}..{int(sizes.n_free.max())}; joint order inside the step",
+            "solves_per_s": B / dt, "ms_per_step": dt * 1e3, "stages_ms": stage_ms, "info_nonzero": res_info,
+            "wide_envelopes": int((~narrow).sum()), "slab_rows": int(dev.rows),
+            "potrf": {"kernel": "trs_potrf_kernel" if not narrow.all() else "trs_potrf_narrow_kernel<false, 2>",
+                      "mfma_tflops": potrf_tf, "frac_of_fp64_peak": potrf_tf / PEAK_FP64_TFLOPS,
+                      "dense_equivalent_tflops": dense_flops / (stage_ms["potrf"] * 1e-3) / 1e12,
+                      "algorithmic_GBps": gbs(potrf_b, stage_ms["potrf"]), "frac_of_hbm_peak": gbs(potrf_b, stage_ms["potrf"]) / PEAK_HBM_GBS,
+                      "intensity_flop_per_byte": flops / max(1.0, potrf_b)},
+            "assemble": {"algorithmic_GBps": gbs(asm_b, stage_ms["assemble"]), "frac_of_hbm_peak": gbs(asm_b, stage_ms["assemble"]) / PEAK_HBM_GBS},
+            "potrs": {"algorithmic_GBps": gbs(potrs_b, stage_ms["potrs"]), "frac_of_hbm_peak": gbs(potrs_b, stage_ms["potrs"]) / PEAK_HBM_GBS},
+            "recover": {"algorithmic_GBps": gbs(rec_b, stage_ms["recover"]), "frac_of_hbm_peak": gbs(rec_b, stage_ms["recover"]) / PEAK_HBM_GBS},
+            "note": "informational: FLOP = the MFMA work inside the 16x16-tile envelopes (what the kernel executes), bytes = "
+                    "stored tiles once per stage + vectors + inputs (`algorithmic_counts`); profile: profiles/r06_large_*"}
+
+
 def ga_leg(device, torch):
     """BASELINE config 4 (informational, rank 0 at N = 1): one GA generation on bar-120 with nPop = 1024 - every
     fitness evaluation of the generation in ONE batched solve (the fused small-system kernel with the constraint
@@ -772,6 +936,12 @@ def main():
                     help="trusses per GPU of the mixed cube-truss leg, BASELINE config 3 (0 = skip)")
     ap.add_argument("--dataset-samples", type=int, default=131072,
                     help="samples per GPU of the dataset leg, BASELINE config 5 (0 = skip)")
+    ap.add_argument("--cube-total", type=int, default=65536,
+                    help="trusses IN ALL of the strong-scaled config-3 entry of `north_star_scaling` (0 = skip)")
+    ap.add_argument("--dataset-total", type=int, default=1000000,
+                    help="samples IN ALL of the strong-scaled, streamed config-5 entry of `north_star_scaling` (0 = skip)")
+    ap.add_argument("--large-trusses", type=int, default=512,
+                    help="trusses of the informational large-truss leg (8x8x8 grid, 300..400 cubes; 0 = skip)")
     ap.add_argument("--cube-steps", type=int, default=5)
     ap.add_argument("--cube-warmup", type=int, default=1)
     ap.add_argument("--dense", action="store_true",
@@ -857,6 +1027,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN, group=tgroup)
         return float(tmax.item())
 
+    def gather(obj):
+        """`obj` of every rank on rank 0, in rank order (the gloo control plane; a list of one at N = 1)."""
+        if not distributed:
+            return [obj]
+        out = [None] * world if rank == 0 else None
+        dist.gather_object(obj, out, dst=0)
+        return out
+
     # The legs of the other configurations run FIRST (each with its own barrier-bracketed region): they are seconds of
     # device work, after which the chip sits at its steady clocks - the headline's timed region, 27 ms of work behind a
     # handful of warm-up steps, otherwise starts on a device that is still ramping up (first region 2.4 % slower than
@@ -871,6 +1049,10 @@ def main():
             cube = {"error": repr(exc)}
             if distributed:
                 raise
+    cube_strong = None
+    if args.cube_total > 0 and not (world == 1 and args.cube_total == args.cube_batch and isinstance(cube, dict)
+                                    and "value" in cube):
+        cube_strong = config3_strong_leg(args, device, torch, batch, barrier, reduce_max, gather, rank, world)
     dataset = None
     if args.dataset_samples > 0:
         try:
@@ -879,6 +1061,9 @@ def main():
             dataset = {"error": repr(exc)}
             if distributed:
                 raise
+    data_strong = None
+    if args.dataset_total > 0 and world > 1:   # (N = 1: a late leg under the watchdog, like the other multi-stream legs)
+        data_strong = config5_strong_leg(args, device, torch, barrier, reduce_max, gather, rank, world)
     batch.release_workspaces()   # (the legs' slabs go back to the driver: the headline batch allocates on a clean device)
 
     packed = batch.pack_json([data]).replicate(args.batch)
@@ -1188,6 +1373,27 @@ def main():
             "info_nonzero": int((res.info != 0).sum()),
             "envelope": not args.dense,
         }
+        # north_star's last sentence in ONE record: config 2 weak-scaled (the headline), config 3 and config 5
+        # strong-scaled, each with the spread over the ranks - what a driver that runs this command at N = 1, 2, 4, 8
+        # tabulates
+        scaling = {"n_gpus": n_devices_used, "ranks": world,
+                   "config2_weak": {"config": f"BASELINE config 2: {args.case} x {args.batch} independent copies per GPU",
+                                    "scaling": "weak", "value": line["value"], "unit": "solves/s",
+                                    "ms_per_step": line["ms_per_step"], "rank_ms_per_step": line["rank_ms_per_step"]}}
+        if cube_strong is not None:
+            scaling["config3_strong"] = cube_strong
+        elif args.cube_total > 0 and isinstance(cube, dict) and "value" in cube:
+            scaling["config3_strong"] = {
+                "config": "BASELINE config 3: mixed cube trusses (grid 6x6x6, 8..190 cubes), one ragged batch",
+                "scaling": "strong", "total_trusses": int(args.cube_total), "steps": args.cube_steps,
+                "value": cube["value"], "unit": "solves/s", "ms_per_step": cube["ms_per_step"],
+                "rank_ms_per_step": cube["rank_ms_per_step"],
+                "shards": [{"rank": 0, "first": 0, "count": int(args.cube_total), "info_nonzero": cube["info_nonzero"]}],
+                "info_nonzero": cube["info_nonzero"],
+                "note": "at N = 1 the strong-scaled entry IS the `cube_batch` leg (same trusses, same steps)"}
+        if data_strong is not None:
+            scaling["config5_strong"] = data_strong
+        line["north_star_scaling"] = scaling
         if pcie is not None:
             line["pcie_inclusive"] = pcie
         if cube is not None:
@@ -1199,6 +1405,12 @@ def main():
                 line["ga_generation"] = ga_leg(device, torch)
             except Exception as exc:
                 line["ga_generation"] = {"error": repr(exc)}
+            if args.large_trusses > 0:
+                try:
+                    line["large_truss"] = large_truss_leg(args, device, torch, batch)
+                except Exception as exc:
+                    line["large_truss"] = {"error": repr(exc)}
+                batch.release_workspaces()
             try:
                 line["reference_protocol"] = reference_protocol_leg()
             except Exception as exc:
@@ -1229,12 +1441,18 @@ def main():
         # The legs that drive SEVERAL streams (informational, N = 1) run last, each under a watchdog: this runtime has
         # stopped multi-stream work on the device without an error (EXPERIMENTS R4.9) - if one of them does not come
         # back, the line is printed without it and the process ends instead of hanging the caller.
-        if world == 1 and not args.no_pcie:
+        if world == 1:
             late = []
-            if isinstance(dataset, dict) and "value" in dataset:
+            if args.dataset_total > 0:   # (first: the one late leg the scaling record needs)
+                late.append(("north_star_scaling.config5_strong",
+                             lambda: config5_strong_leg(args, device, torch, barrier, reduce_max, gather, rank, world),
+                             lambda v: scaling.__setitem__("config5_strong", v)))
+            if args.no_pcie:   # (the informational legs' switch)
+                pass
+            elif isinstance(dataset, dict) and "value" in dataset:
                 late.append(("dataset.streamed", lambda: dataset_streamed_leg(args, device, dataset["value"]),
                              lambda v: dataset.__setitem__("streamed", v)))
-            if isinstance(cube, dict) and "value" in cube:
+            if not args.no_pcie and isinstance(cube, dict) and "value" in cube:
                 late.append(("cube_batch.host_fed", lambda: host_fed_leg(args, device, torch, batch),
                              lambda v: cube.__setitem__("host_fed", v)))
             for name, run, put in late:

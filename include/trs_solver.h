@@ -49,9 +49,12 @@
  * kernel assumes anything about what else runs on the device: CONCURRENT CALLS ON DISTINCT STREAMS WITH DISTINCT
  * BUFFERS DO NOT INTERACT, and their results are bit for bit those of the same calls issued one after the other.
  * This clause is tested: tools/repro_streams.cpp (a plain HIP program: hipMalloc, hipStream_t and this header, no
- * tensor library) runs the launch sequences of a ragged batch's size buckets on two to five streams, compares every
- * step truss by truss with a one-stream step and checks every joint order for being a permutation
- * (tests/test_gpu_streams.py; 200 steps per test).  Rounds 3-4 of this library violated it: a work-group race in
+ * tensor library) runs the launch sequences of a ragged batch's size buckets on two, three and four streams, compares
+ * every step truss by truss with a one-stream step and checks every joint order for being a permutation; and
+ * tools/repro_families.cpp runs every OTHER kernel family beside that pipeline - trs_solve_small with the fitness
+ * reductions, trs_ga_sections, trs_graph_features_packed, trs_fitness, trs_copy_rows through page-locked host memory
+ * and trs_cubegen_dev on a CU-masked stream - each on a stream of its own, every output compared bit for bit with the
+ * same calls on one stream (tests/test_gpu_streams.py; 200 steps per test).  Rounds 3-4 of this library violated it: a work-group race in
  * trs_joint_order's kernel (a breadth-first level counter read while faster waves already advanced it) that only
  * concurrent kernels on other streams, which pull the waves of a work-group apart, brought out - wrong joint orders,
  * stores through garbage indices into other calls' buffers, device stalls (EXPERIMENTS.md R4.9, R5.1).

@@ -14,7 +14,18 @@ import os as _os
 # queues the dataset stream's device -> host copy lands on a lane's queue for some lane counts (measured: 351-471 K
 # samples/s delivered instead of 512-521 K, EXPERIMENTS R5.5).  Eight queues unless the caller has chosen; read by the
 # runtime when the process first touches the GPU, so this must come before that (importing torch does not).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    import sys as _sys
+    _torch = _sys.modules.get("torch")
+    if _torch is not None and getattr(_torch, "cuda", None) is not None and _torch.cuda.is_initialized():
+        # too late for this process: the runtime read the variable when the GPU was first touched.  Say so - the
+        # multi-stream paths then run on four hardware queues, 10-30 % slower ("Hardware queues")
+        import warnings as _warnings
+        _warnings.warn("python_stable_3d_truss_analysis_amd imported after the GPU was initialised: GPU_MAX_HW_QUEUES=8 "
+                       "can no longer take effect; export it in the launcher (see INTEGRATION.md)", RuntimeWarning,
+                       stacklevel=2)
+    else:
+        _os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 from .type import GenerateMethod, LinkType, MemberType, MetapathType, SupportType, TaskType
 from .truss import Member, Truss

@@ -1038,6 +1038,11 @@ class SolverWorkspace:
             self._lanes[index] = SolverWorkspace(self.torch, self.device)
         return self._lanes[index]
 
+    def nbytes(self):
+        """Bytes this workspace and its lanes hold now."""
+        own = sum(int(b.numel() * b.element_size()) for b in self.buf.values() if b is not None)
+        return own + sum(ws.nbytes() for ws in self._lanes.values())
+
     def get(self, need):
         """Flat tensors of at least `need[kind]` elements each (zero-filled for the envelope metadata)."""
         t = self.torch
@@ -1063,6 +1068,20 @@ class SolverWorkspace:
             if kind == "S" and os.environ.get("TRS_DEBUG_POISON"):
                 self.buf[kind].fill_(float("nan"))
         return self.buf
+
+
+def default_slab_budget(torch, device, n_lanes, workspace=None):
+    """Slab bytes a resident `RaggedSolver` may spread over its lanes when the caller names no budget:
+    `LANE_SLAB_BYTES` per lane, but never more than 60 % of the device's memory and never more than 85 % of what is
+    FREE now plus what the solver's own workspace (and this process's cached, unused blocks) already holds - a
+    co-tenant of the device, e.g. the network being trained on the samples, keeps its memory; at least 2 GiB, so that a
+    crowded device gives small buckets rather than none."""
+    total = int(torch.cuda.get_device_properties(device).total_memory)
+    free, _ = torch.cuda.mem_get_info(device)
+    reusable = int(torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+    held = workspace.nbytes() if workspace is not None else 0
+    roomy = int(0.85 * (int(free) + reusable + held))
+    return max(2 << 30, min(n_lanes * LANE_SLAB_BYTES, int(0.6 * total), roomy))
 
 
 _SHARED_WORKSPACES = {}
@@ -1091,8 +1110,8 @@ def shared_workspace(torch, device):
     threads that drive the SAME stream must serialise their calls themselves, as for any other stream-ordered
     resource.
 
-    The cache is BOUNDED: at most `MAX_SHARED_WORKSPACES` (4; a workspace is up to tens of GB) live at a time, the
-    least recently used one is dropped when a further stream asks (its buffers go back to the caching allocator once
+    The cache is BOUNDED: at most `MAX_SHARED_WORKSPACES` (4; a workspace is up to tens of GB) live at a time PER DEVICE,
+    the device's least recently used one is dropped when a further stream of it asks (its buffers go back to the caching allocator once
     the solvers built on it are gone; kernels still queued on them keep them alive through the allocator's
     stream-ordered reuse, as for any freed tensor).  A stream handle value that comes back after its stream was
     destroyed inherits the old entry - harmless: a destroyed stream has no work left, and the buffers carry no state
@@ -1101,8 +1120,14 @@ def shared_workspace(torch, device):
     ws = _SHARED_WORKSPACES.pop(key, None)
     if ws is None:
         ws = SolverWorkspace(torch, device)
-        while len(_SHARED_WORKSPACES) >= MAX_SHARED_WORKSPACES:
-            _SHARED_WORKSPACES.pop(next(iter(_SHARED_WORKSPACES)))     # (dicts keep insertion order: the oldest use)
+        # The bound is PER DEVICE (a process that drives eight devices in turn keeps every device's workspaces).
+        # Dropping a workspace also drops its lanes' buffers, which were allocated on the caller's stream and used on
+        # the side streams of the lanes: that is safe only because `RaggedSolver.step` always JOINS its lanes back into
+        # the caller's stream before it returns - every use of a lane buffer is ordered before whatever the caller's
+        # stream does next, the allocator's stream-ordered reuse included.
+        mine = [k for k in _SHARED_WORKSPACES if k[0] == key[0]]       # (dicts keep insertion order: oldest use first)
+        for old_key in mine[:max(0, len(mine) - MAX_SHARED_WORKSPACES + 1)]:
+            _SHARED_WORKSPACES.pop(old_key)
     _SHARED_WORKSPACES[key] = ws                                       # most recently used last
     return ws
 
@@ -1111,8 +1136,9 @@ MAX_SHARED_WORKSPACES = 4
 
 
 def release_workspaces():
-    """Drop the shared workspaces of every device and stream (they hold the largest slab a call needed, up to
-    48 GB, for the life of the process) and hand the cached blocks back to the driver."""
+    """Drop the shared workspaces of every device and stream (they hold the largest slabs a call needed - up to
+    `default_slab_budget`, i.e. up to 60 % of a device's memory over the lanes - for the life of the process) and hand
+    the cached blocks back to the driver."""
     import torch
     _SHARED_WORKSPACES.clear()
     if torch.cuda.is_available():
@@ -1242,8 +1268,8 @@ class RaggedSolver:
         `tests/test_gpu_streams.py`).  Rounds 3-4 had to keep this switched off - stalls and bursts of corrupted
         trusses once in a few dozen steps; the cause was a race in `trs_joint_order`'s kernel that only concurrent
         kernels brought out, found with the torch-free reproducer `tools/repro_streams.cpp` (EXPERIMENTS R5.1).
-        `max_slab_bytes` (default `LANE_SLAB_BYTES` = 36 GiB per lane, at most 60 % of the device's memory) is the
-        budget of all lanes together.
+        `max_slab_bytes` (default `default_slab_budget`: `LANE_SLAB_BYTES` = 36 GiB per lane, at most 60 % of the
+        device's memory and 85 % of what is free on it now) is the budget of all lanes together.
 
         `host_io=(inputs, outputs)`: the batch STAYS in page-locked host memory - `inputs` / `outputs` are dicts of
         pinned CPU tensors (the padded arrays of a `PackedBatch.pinned()`; `u`, `f_ext`, `N`, `info` of a
@@ -1310,8 +1336,7 @@ class RaggedSolver:
             self.u, self.f_ext, self.N, self.info = first["u"], first["f_ext"], first["N"], first["info"]
         n_lanes = 1 if self.host_io else max(1, int(lanes if lanes is not None else DEFAULT_LANES))
         if max_slab_bytes is None:
-            max_slab_bytes = min(n_lanes * LANE_SLAB_BYTES,
-                                 int(0.6 * torch.cuda.get_device_properties(dev).total_memory))
+            max_slab_bytes = default_slab_budget(torch, dev, n_lanes, workspace)
         # resident batches: groups cut at whole rounds of the factorisation kernel (3 waves x 4 SIMDs per CU in flight)
         quantum = 0 if self.host_io else 12 * int(torch.cuda.get_device_properties(dev).multi_processor_count)
         groups = size_buckets(packed, max_slab_bytes // n_lanes, granularity, quantum=quantum) if B else []

@@ -89,13 +89,6 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     const int npad = trs_round_up(n, TRS_NB);
     if (npad == 0) return;
     const int nch = npad / 16;
-#ifdef TRS_EXP_ASM_STAGGER_TICKS   // experiment (EXPERIMENTS R5.12): half of the FIRST round of work-groups starts late, so that
-    // the two work-groups of a CU are out of phase (one forms its tables while the other stores) instead of in lockstep
-    if (blockIdx.x < TRS_EXP_ASM_STAGGER_FIRST && ((blockIdx.x / TRS_EXP_ASM_STAGGER_GROUP) & 1)) {
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (unsigned long long)TRS_EXP_ASM_STAGGER_TICKS) __builtin_amdgcn_s_sleep(32);
-    }
-#endif
 
     const AsmLds lay = asm_lds_layout(nJ_max, nM_max, n_pad_max, MODE == 2 ? -16 : WT, MODE != 1, TR);
     unsigned char* wbase = work_all + (size_t)b * work_stride;
@@ -236,7 +229,6 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     for_members([&](int m, int j0, int j1) {
         unsorted[start[j0] + atomicAdd(&fill[j0], 1)] = ((unsigned)j1 << 16) | (unsigned)m;
         unsorted[start[j1] + atomicAdd(&fill[j1], 1)] = ((unsigned)j0 << 16) | (unsigned)m;
-#ifndef TRS_NO_KMASK   // (A/B build without it: every tile of the envelope is written and read, as before ABI 9)
         if (want_mask) {
             int alo, ahi, blo, bhi;
             span_of(j0, alo, ahi);
@@ -246,7 +238,6 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 couple(blo, bhi, alo, ahi);
             }
         }
-#endif
     });
     if (want_mask)
         for (int j = tid; j < nJ; j += NT) {  // a joint's own block
@@ -377,13 +368,9 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 wgflag[1] = (narrow && uf_all != nullptr) ? 1 : 0;
                 // ... and skip the tiles of the envelope that hold no entry of K (kmask, trs_common.h); a matrix only
                 // FORCED narrow may reach further than the 32 bits of a mask word: it keeps every tile
-#ifdef TRS_NO_KMASK
-                wgflag[2] = 0;
-#else
                 wgflag[2] = (narrow && uf_all != nullptr && widest <= TRS_NARROW_MAX_BELOW && !full && (flags & TRS_ASM_ALL_TILES) == 0) ? 1 : 0;
-#endif
             }
-            int empty = 0, stored_tiles = 0, front = 0;
+            int empty = 0, stored_tiles = 0;
             for (int t = tid; t < nch; t += 64) {  // t | 3 lies in the same step: reads precede the writes
                 const int e = narrow ? max(cendl[t] + 1, (t | 3) + 1) : cendl[t | 3] + 1 + (TRS_WIDE_ITEM - 1);
                 __builtin_amdgcn_wave_barrier();
@@ -391,24 +378,13 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                 cend[t] = min(nch, e);
                 const int w = min(nch, e) - t;
                 stored_tiles += w;
-                front = max(front, w);   // (read by experiment builds only: TRS_EXP_WINDOW)
                 empty += w - __popc(kmask[t] & (w >= 32 ? 0xffffffffu : ((1u << w) - 1u)));
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 empty += __shfl_xor(empty, off);
                 stored_tiles += __shfl_xor(stored_tiles, off);
-                front = max(front, __shfl_xor(front, off));
             }
-#ifdef TRS_EXP_WINDOW
-            // the work-group kernel with the window in LDS takes the matrix (trs_common.h, TRS_ENV_WINDOW)
-            if (tid == 0 && narrow && !compact && uf_all != nullptr && widest <= TRS_NARROW_MAX_BELOW && !full &&
-                front <= TRS_WINDOW_MAX_FRONT && front > TRS_EXP_WINDOW_ABOVE && 16 * nch <= 1024) {
-                int* meta = env + n_pad_max / 16 + n_pad_max / 64;
-                meta[0] |= TRS_ENV_WINDOW;
-                meta[5] = front;
-            }
-#endif
             // skipping pays only when enough tiles are skipped (the row loop tests a bit per 16 bytes stored):
             // a tower-like truss (bar-942: 6 of 158 tiles without an entry) keeps every tile
             const bool worth = 8 * empty >= stored_tiles;
@@ -560,9 +536,6 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         return;
     }
 
-#ifdef TRS_EXP_ASM_NOPHASE1  // timing experiment only (wrong results): phase 0 and the envelope only
-    return;
-#endif
     // ---- phase 1 ---------------------------------------------------------------------------------------
     const bool with_col = !(has_env && wgflag[1] != 0);  // the 16-wide load-column chunk rides in the slab
     const bool masked = has_env && wgflag[2] != 0;       // tiles without an entry of K are not written
@@ -615,9 +588,6 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         pdeg = 0;
         const int c = c0 + rr;
         if (c >= n) return;
-#ifdef TRS_EXP_ASM_NOWALK   // timing experiment only (wrong results): no adjacency walk in the row loop
-        return;
-#endif
         const int dof = rowdof[c];
         const int a = dof / 3, r = dof - 3 * a;
         if (e_first == TPR - 1) {
@@ -633,93 +603,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             if (e_first < pdeg) run_values(adj + start[a], pdeg, e_first, r, pq0, pq1, pq2, pv0, pv1, pv2);
         }
     };
-#ifdef TRS_ASM_PIPELINE   // (A/B build: measured EQUAL to the one-block-ahead form below, which stays - EXPERIMENTS R5.11)
-    // The walk that forms a thread's piece is a chain of four dependent LDS look-ups (row -> DOF -> joint's list ->
-    // list entry -> neighbour's free indices and member geometry): with the piece formed ONE block ahead the whole
-    // chain sat between a block's stores and the next block's scatter, and the wave issued nothing meanwhile (the row
-    // loop waits 0.60 of its cycles, two work-groups per CU cannot hide it).  As a FOUR-STAGE software pipeline:
-    // every pass issues stage 4 for the next block, stage 3 for the one after, stage 2 and stage 1 for the two behind
-    // - four independent look-ups whose results are a whole block of stores old when they are used (EXPERIMENTS R5.11).
-    // Same values in the same order: same bits.
-    struct Walk {
-        int a = -1, r = 0, deg = 0, s = 0;           // joint and axis of the row, its list (stage 2)
-        unsigned key = 0, prev = ~0u, next = ~0u;    // this thread's list entry and its neighbours in the list (stage 3)
-    };
-    auto stage1 = [&](int c0) {                      // -> DOF of the thread's row in block c0, or -1
-        const int c = c0 + rr;
-#ifdef TRS_EXP_ASM_NOWALK
-        return -1;
-#endif
-        return c < n ? rowdof[c] : -1;
-    };
-    auto stage2 = [&](int dof) {
-        Walk w;
-        if (dof >= 0) {
-            w.a = dof / 3;
-            w.r = dof - 3 * w.a;
-            if (e_first != TPR - 1) {
-                w.deg = cnt[w.a];
-                w.s = start[w.a];
-            }
-        }
-        return w;
-    };
-    auto stage3 = [&](Walk w) {
-        if (w.a >= 0 && e_first < w.deg) {           // (deg stays 0 for the thread of the joint's own block)
-            const unsigned* list = adj + w.s;
-            w.key = list[e_first];
-            w.prev = e_first > 0 ? list[e_first - 1] : ~w.key;
-            w.next = e_first + 1 < w.deg ? list[e_first + 1] : ~w.key;
-        }
-        return w;
-    };
-    auto stage4 = [&](const Walk& w) {               // -> pq*, pv*, pdeg of the block the walk belongs to
-        pq0 = pq1 = pq2 = -1;
-        pdeg = w.deg;
-        if (w.a < 0) return;
-        if (e_first == TPR - 1) {
-            const double* dg = diag + 6 * w.a;       // row r of [xx xy xz; xy yy yz; xz yz zz]
-            pv0 = dg[w.r];
-            pv1 = dg[w.r == 0 ? 1 : (w.r == 1 ? 3 : 4)];
-            pv2 = dg[w.r == 0 ? 2 : (w.r == 1 ? 4 : 5)];
-            pq0 = fi[3 * w.a];
-            pq1 = fi[3 * w.a + 1];
-            pq2 = fi[3 * w.a + 2];
-        } else if (e_first < w.deg) {
-            const int other = (int)(w.key >> 16);
-            if ((int)(w.prev >> 16) == other) return;    // not the head of a run
-            pq0 = fi[3 * other];
-            pq1 = fi[3 * other + 1];
-            pq2 = fi[3 * other + 2];
-            pv0 = pv1 = pv2 = 0.0;
-            unsigned key = w.key;
-            int q = e_first;
-            const unsigned* list = adj + w.s;
-            for (;;) {  // parallel members between the same two joints, in member order
-                const int m = (int)(key & 0xffffu);
-                const double k = mk[m], cr = mc[3 * m + w.r];
-                pv0 -= k * (cr * mc[3 * m]);
-                pv1 -= k * (cr * mc[3 * m + 1]);
-                pv2 -= k * (cr * mc[3 * m + 2]);
-                ++q;
-                if (q >= w.deg) break;
-                key = q == e_first + 1 ? w.next : list[q];   // (the entry after the thread's own came with stage 3)
-                if ((int)(key >> 16) != other) break;
-            }
-        }
-    };
-    Walk w3, w2;
-    int dof1;
-    {   // fill: blocks 0 .. 3
-        const Walk b0 = stage3(stage2(stage1(0)));
-        stage4(b0);
-        w3 = stage3(stage2(stage1(TR)));
-        w2 = stage2(stage1(2 * TR));
-        dof1 = stage1(3 * TR);
-    }
-#else
     prepare(0);
-#endif
     for (int c0 = 0; c0 < npad; c0 += TR) {
         // stored part of these rows: columns [i_lo, i_hi) (diagonal tile .. end of the envelope of
         // the panel the rows belong to); the 16-wide load-column chunk rides with the last segment
@@ -771,16 +655,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
                     *reinterpret_cast<d2*>(src + x) = d2{0.0, 0.0};
                 }
             }
-#ifdef TRS_ASM_PIPELINE
-            if (is_last && c0 + TR < npad) {   // the four stages, one block each: independent look-ups
-                stage4(w3);
-                w3 = stage3(w2);
-                w2 = stage2(dof1);
-                dof1 = stage1(c0 + 4 * TR);
-            }
-#else
             if (is_last && c0 + TR < npad) prepare(c0 + TR);  // overlaps with the stores in flight
-#endif
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -814,11 +689,7 @@ inline AsmPlan asm_plan(int nJ_max, int nM_max, int n_pad_max) {
     // Geometry in the workspace only when even a whole CU's LDS cannot hold it, and everything but
     // the row tile there when the tables alone do not fit.
     const size_t geom_bytes = ((size_t)(nM_max < 1 ? 1 : nM_max) * 32 + 255) / 256 * 256;
-#ifdef TRS_EXP_ASM_GEOM_IN_WORK_FROM   // A/B: trusses from this many members keep the member geometry in the workspace
-    const int first_g = nM_max >= TRS_EXP_ASM_GEOM_IN_WORK_FROM ? 0 : 1;   // if that gets them two work-groups per CU
-#else
     const int first_g = 1;
-#endif
     for (int gi = 0; gi < 2; ++gi) {
         const int g = gi == 0 ? first_g : 1 - first_g;
         for (int big = 0; big <= 1; ++big) {

@@ -132,9 +132,6 @@ struct OrdStamp {
 };
 #endif
 
-#ifdef TRS_EXP_ORDER_RACE_PROBE   // tools/repro_streams.cpp: how often a thread WOULD have read a wrong level end (see bfs_sweep)
-__device__ unsigned long long g_ord_race_hits[2];   // [0] threads that read a moving count, [1] sweeps that saw one
-#endif
 
 struct Tables {
     unsigned char* nfr;
@@ -165,25 +162,15 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
     // indices: what concurrent kernels on other streams, which pull the waves of a work-group apart, brought out -
     // EXPERIMENTS R5.1).  Counter (d + 1) % 3 is cleared during level d: its last readers read it behind the
     // barrier of level d - 2 and have all passed the barrier of level d - 1 since.
-    // (-DTRS_EXP_ORDER_SINGLE_COUNTER, tools/repro_streams.cpp only: the ONE running counter of rounds 3-4, kept so
-    // that the reproducer can show the fault and its cure with the same sources)
+    // (The ONE running counter of rounds 3-4 and the probe that counts its hazardous reads are kept as a patch,
+    // tools/patches/: the reproducer tools/repro_streams.cpp shows the fault and its cure with them.)
     int* found_cnt = t.ctrl;  // [0 .. 2]
     if constexpr (SORTED)
         for (int j = tid; j < nj; j += NT) t.ppos[j] = 0x7fffffff;
     if (tid == 0) {
         t.queue[0] = (unsigned short)root;
         t.lvl[root] = stamp;
-#ifdef TRS_EXP_ORDER_SINGLE_COUNTER
-        found_cnt[0] = 1;
-#else
         found_cnt[0] = 0;
-#endif
-#ifdef TRS_EXP_ORDER_RACE_PROBE
-        // A SHADOW of the single running counter of rounds 3-4 (ctrl[3]; every discovery bumps it as well).  The
-        // control flow follows the three counters; a thread whose read of the shadow, at the point where the old code
-        // read its counter, differs from the true level end would have taken a wrong `tail` there.  Counted, not acted on.
-        t.ctrl[3] = 1;
-#endif
     }
     __syncthreads();
     unsigned short* found = SORTED ? t.nextq : t.queue;  // a sorted level is copied into the queue by rank
@@ -192,14 +179,9 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
     while (head < tail) {
         begin = head;
         const int mark = stamp + depth + 1;
-#ifdef TRS_EXP_ORDER_SINGLE_COUNTER
-        int* my_cnt = found_cnt;
-        const int next_turn = 0, slot0 = 0;
-#else
         int* my_cnt = found_cnt + turn;
         const int next_turn = turn == 2 ? 0 : turn + 1, slot0 = tail;
         if (tid == 0) found_cnt[next_turn] = 0;
-#endif
         for (int i = head + (tid >> 2); i < tail; i += NT / 4) {
             const int v = t.queue[i];
             const int e1 = t.start[v + 1];
@@ -207,17 +189,11 @@ __device__ int bfs_sweep(const Tables& t, int nj, int root, int stamp, int* last
                 const int w = t.adj[e];
                 const int old = atomicMax(&t.lvl[w], mark);
                 if (old < stamp) found[slot0 + atomicAdd(my_cnt, 1)] = (unsigned short)w;      // first to reach w
-#ifdef TRS_EXP_ORDER_RACE_PROBE
-                if (old < stamp) atomicAdd(&t.ctrl[3], 1);
-#endif
                 if (SORTED && (old < stamp || old == mark)) atomicMin(&t.ppos[w], i);          // w's earliest parent
             }
         }
         __syncthreads();
         const int new_tail = slot0 + *my_cnt;
-#ifdef TRS_EXP_ORDER_RACE_PROBE
-        if (t.ctrl[3] != new_tail) atomicAdd(&g_ord_race_hits[0], 1ull);
-#endif
         if constexpr (SORTED) {
             const int m = new_tail - tail;
             if (m > 1) {
@@ -932,16 +908,6 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
 
 }  // namespace
 
-#ifdef TRS_EXP_ORDER_RACE_PROBE
-extern "C" int trs_order_race_probe(unsigned long long* host_out, int reset) {
-    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ord_race_hits), sizeof(g_ord_race_hits));
-    if (reset) {
-        unsigned long long zero[2] = {0, 0};
-        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ord_race_hits), zero, sizeof(zero));
-    }
-    return rc;
-}
-#endif
 
 #ifdef TRS_ORDER_STAMPS
 extern "C" int trs_order_debug_stamps(unsigned long long* host_out, int reset) {
@@ -968,9 +934,6 @@ extern "C" int trs_joint_order_launch(int B, int nJ_max, int nM_max, const doubl
     if (B <= 0) return 0;
     if (!trs_joint_order_fits(nJ_max, nM_max)) return (int)hipErrorInvalidValue;
     const size_t lds = ord_layout(nJ_max, nM_max).total
-#ifdef TRS_EXP_ORDER_IDLE_LDS   // occupancy experiment: LDS nobody uses, fewer work-groups per CU
-                       + TRS_EXP_ORDER_IDLE_LDS
-#endif
         ;
     // The dynamic-LDS ceiling of the kernel is raised only when a launch needs more than the default 64 KB, once per
     // process (cube trusses: 25-39 KB; only shapes beyond ~500 joints get here).  Raising it for every kernel of the

@@ -653,19 +653,11 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
                 const unsigned vo = S.lane_off(s >= smin[v] && (d0 + v >= 32u || ((km >> (d0 + v)) & 1u) != 0u));
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-#ifdef TRS_EXP_NO_KLOADS
-                    acc[v][s][r] = 0.0 * (double)(o + (int)vo);
-#else
                     acc[v][s][r] = S.load_at(vo, o + r * (S.ld * 32));
-#endif
             }
         }
     }
-#ifdef TRS_EXP_NO_ITEMUPDATE  // timing experiment only (wrong results): no update loop in the items
-    if (false) {
-#else
     if (r0 > kstart) {
-#endif
         int ob = S.at(kstart, r0);
         int oa = S.at(kstart, rowbase);
         const int step = S.ld * 32;
@@ -678,13 +670,7 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
         auto aload = [&](int off, int v, int k) {
             return S.load_at(S.lane_off(v == 0 || k >= kv[v]), off + 128 * v);
         };
-#ifdef TRS_EXP_HALF_IFB   // timing experiment only (wrong results): every OTHER item of a panel takes its block-side
-        // fragments through the out-of-range lane offset (zeros, no memory traffic, same instruction stream) - what two
-        // waves per matrix that share a panel's block-side rows through LDS could save AT MOST (EXPERIMENTS R5.4)
-        const unsigned fbo = (((c0 - (r0 / 16 + CT)) >> 1) & 1) ? Slab::gone : S.loff;
-#else
         const unsigned fbo = S.loff;
-#endif
 #pragma unroll
         for (int d = 0; d < DEPTHN - 1; ++d) {
 #pragma unroll
@@ -698,11 +684,7 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
                 const int nd = (d + DEPTHN - 1) % DEPTHN;
 #pragma unroll
                 for (int s = 0; s < CT; ++s)
-#ifdef TRS_EXP_NO_IFB      // timing experiment only (wrong results): the items' block-side fragment loads
-                    fb[nd][s] = 0.0 * (double)(ob + s);
-#else
                     fb[nd][s] = S.load_at(fbo, ob + (d + DEPTHN - 1) * step + 128 * s);
-#endif
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
                     fa[nd][v] = aload(oa + (d + DEPTHN - 1) * step, v, k0 + 4 * (d + DEPTHN - 1));
@@ -739,11 +721,7 @@ __device__ __forceinline__ void narrow_item(const Slab& S, const int r0, const i
             const int o = S.at(r0 + 16 * s, rowbase + 16 * v);
             const unsigned vo = S.lane_off(s >= smin[v]);
 #pragma unroll
-#ifdef TRS_EXP_NO_ITEMSTORE   // timing experiment only (wrong results): the items' result tiles are not stored
-            for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(acc[v][s][r]), "v"(vo), "s"(o));
-#else
             for (int r = 0; r < 4; ++r) S.store_at(vo, o + r * (S.ld * 32), acc[v][s][r]);
-#endif
         }
 }
 
@@ -774,11 +752,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
     // wrote the highest-numbered trusses last, so their stiffness tiles are the ones still in the memory-side
     // cache when this kernel starts, and the lowest-numbered ones are factored last - where
     // trs_potrs_batched, which runs in ascending order, starts.
-#ifdef TRS_EXP_POTRF_ASCENDING
-    const int b = blockIdx.x * MPW + wave;
-#else
     const int b = ((int)gridDim.x - 1 - (int)blockIdx.x) * MPW + wave;
-#endif
     if (b >= B) return;  // no work-group barrier anywhere in this kernel: waves are independent
     const int npad = trs_round_up(n_free[b], TRS_NB);
     if (npad == 0) {
@@ -788,9 +762,6 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
     const TrsEnv env = trs_env_of(env_all, b, n_pad_max);
     if (!trs_env_is_narrow(env) || trs_env_is_compact(env) != FUSED) return;  // another kernel's matrix
     if (!FUSED && trs_env_is_rs4(env) != (RSV > 2)) return;                   // the other item size's matrix
-#ifdef TRS_EXP_WINDOW
-    if (trs_env_is_window(env)) return;                                      // trs_potrf_window_kernel's matrix
-#endif
     Slab S;
     S.rs = __builtin_amdgcn_make_buffer_rsrc(S_all + (size_t)b * slab_stride, 0,
                                              (int)(slab_stride * sizeof(double)), 0x00020000);
@@ -837,14 +808,10 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
             const unsigned km = (unsigned)env.kmask[min(r0 / 16 + s, npad / 16 - 1)];
 #pragma unroll
             for (int u = s; u < CT; ++u) {
-#ifdef TRS_EXP_NO_KLOADS   // timing experiment only (wrong results): the stiffness tile loads
-                for (int r = 0; r < 4; ++r) t[u][s][r] = (u == s && (lane >> 4) + 4 * r == (lane & 15)) ? 1e6 : 0.0;
-#else
                 const int o = S.at(r0 + 16 * s, r0 + 16 * u);
                 const unsigned vo = S.lane_off(((km >> (u - s)) & 1u) != 0u);   // no entry of K_ff in the tile: zeros
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t[u][s][r] = S.load_at(vo, o + r * (S.ld * 32));
-#endif
             }
         }
 #pragma unroll
@@ -904,11 +871,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
             double fb[DEPTHN][CT], fy[DEPTHN];
             double ys[CT] = {0.0, 0.0, 0.0, 0.0};  // sum_k L[row][k] y[k], partial over this lane's k = k0 + lq
             auto bload = [&](int off, int c, int k) {  // zero where chunk c is left of its envelope
-#ifdef TRS_EXP_NO_DLOADS   // timing experiment only (wrong results): what the block update's re-reads cost
-                return 0.0 * (double)(off + c + k);
-#else
                 return S.load_at(S.lane_off(k >= bks[c]), off + 128 * c);
-#endif
             };
 #pragma unroll
             for (int d = 0; d < DEPTHN - 1; ++d) {
@@ -950,17 +913,10 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
 #pragma unroll
         for (int s = 0; s < CT; ++s) {
             if (bad_col == 0) {
-#ifdef TRS_EXP_NO_CHOL16   // timing experiment only (wrong results): the serial 16x16 factorisations
-                Chol16 f{t[s][s], -1};
-                for (int r = 0; r < 4; ++r) Wl[s * 256 + wfrag_lane(r, lane)] = ((lane >> 4) + 4 * r == (lane & 15)) ? 1.0 : 0.0;
-#else
                 const Chol16 f = chol16_invert(t[s][s], sc, Wl + s * 256);
-#endif
                 t[s][s] = f.u;
                 __builtin_amdgcn_wave_barrier();
-#ifndef TRS_EXP_IGNORE_PIVOT   // (knock-out timing builds: their wrong values must not end the panel loop early)
                 if (f.bad >= 0) bad_col = r0 + 16 * s + f.bad + 1;
-#endif
             }
             if (bad_col == 0) {
                 if (s + 1 < CT) {
@@ -1041,9 +997,7 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
         // zeros that nobody reads; a condition here would keep the old tiles alive beside the new ones)
         if constexpr (!FUSED) load_block(r0 + TRS_NB);
         // this wave's stores must have landed before its own loads of the next panel's block update
-#ifndef TRS_EXP_NO_PANEL_FENCE
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#endif
         st.mark(5);
     }
     if (lane == 0) info[b] = bad_col;
@@ -1063,9 +1017,6 @@ __global__ __launch_bounds__(64 * MPW, FUSED ? TRS_FUSED_WAVES_PER_SIMD : (RSV >
     st.flush();
 }
 
-#ifdef TRS_EXP_WINDOW   // (experiment builds only - EXPERIMENTS R4.8: measured slower, not part of the product)
-#include "trs_window.h"
-#endif
 
 }  // namespace
 
@@ -1103,22 +1054,6 @@ extern "C" int trs_potrf_launch(int B, const int* n_free, int ld, size_t slab_st
         hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 2>), grid, block, 0, stream, S, n_free, ld, slab_stride,
                            info, env, n_pad_max, B, wk, uf, ld_uf, fused_substitution);
         if ((rc = (int)hipGetLastError())) return rc;
-#ifdef TRS_EXP_WINDOW
-        if (n_pad_max <= 1024) {
-            const int M = TRS_WINDOW_MAX_FRONT;
-            const size_t lds = trs_window_lds_bytes(M, n_pad_max);
-            static int raised = 0;
-            if (!raised) {
-                if ((rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(trs_potrf_window_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024)))
-                    return rc;
-                raised = 1;
-            }
-            hipLaunchKernelGGL(trs_potrf_window_kernel, dim3(B), dim3(64 * WINW), lds, stream, S, n_free, ld, slab_stride,
-                               info, env, n_pad_max, B, uf, ld_uf, M, 0);
-            if ((rc = (int)hipGetLastError())) return rc;
-        }
-#endif
         if (TRS_NARROW_RS4_ABOVE <= TRS_NARROW_MAX_BELOW) {  // (compile-time: see trs_common.h)
             hipLaunchKernelGGL((trs_potrf_narrow_kernel<false, 4>), grid, block, 0, stream, S, n_free, ld, slab_stride,
                                info, env, n_pad_max, B, wk, uf, ld_uf, fused_substitution);

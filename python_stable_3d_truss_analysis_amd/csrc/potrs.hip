@@ -84,11 +84,7 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
                 if (c0 < col_end) {  // uniform: the envelope ends on a 16-column boundary
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-#ifdef TRS_EXP_POTRS_NOLOAD   // timing experiment only (wrong results): no off-diagonal streaming
-                        ov[p][4 * q + k] = 1e-30 * (double)(c0 + q);
-#else
                         ov[p][4 * q + k] = rows[(size_t)q * ld + c0 + l];
-#endif
                 }
             }
     };
@@ -134,12 +130,7 @@ __global__ __launch_bounds__(256, TRS_POTRS_WAVES_PER_SIMD) void trs_potrs_kerne
         }
         if (cb >= BS) request(cb - BS);  // in flight during the triangle solve
         __syncthreads();
-#ifdef TRS_EXP_POTRS_NOTRI   // timing experiment only (wrong results): no triangle solve
-        if (wave == 0) us[cb + lane] = tb[lane];
-        if (false) {
-#else
         if (wave == 0 && TILESTEP) {
-#endif
             // Back substitution inside the 64 x 64 triangle in four 16 x 16 steps.  trs_potrf left the
             // strictly-lower part of inv(L_ss) below the diagonal of every diagonal tile, so a step is
             // u_s = inv(L_ss)^T t_s (a 16 x 16 product spread over the four quarter-waves) followed by
@@ -242,10 +233,8 @@ extern "C" int trs_potrs_launch(int B, const int* n_free, int ld, size_t slab_st
     // (and the slab fits the 31-bit offsets of a buffer descriptor, as in trs_potrf_batched)
     const size_t lds_narrow = (size_t)PMW * n_pad_max * sizeof(double);
     const int narrow = env != nullptr && lds_narrow <= 64 * 1024 && slab_stride * sizeof(double) < ((size_t)1 << 31);
-#ifndef TRS_EXP_WINDOW   // (the window kernel leaves the substitution to this launch)
     if (narrow && (hints & TRS_HINT_SUBSTITUTED) != 0 && (hints & TRS_HINT_NO_WIDE) != 0 && n_pad_max <= 1024)
         return 0;  // every matrix was substituted by the wave that factored it
-#endif
     if (narrow) {
         hipLaunchKernelGGL(trs_potrs_narrow_kernel, dim3((B + PMW - 1) / PMW), dim3(64 * PMW), lds_narrow, stream, S,
                            n_free, ld, slab_stride, uf, ld_uf, env, n_pad_max, B);

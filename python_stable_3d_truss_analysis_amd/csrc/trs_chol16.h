@@ -40,16 +40,11 @@ __device__ __forceinline__ d4 mfma_f64_negA(double a, double b, d4 c) {
 // (chol16_invert: 16 lanes of one quarter-wave hold 16 columns c of one row t) and the readers (a wave reads
 // k-step r: lanes (lq, li) = 64 consecutive doubles up to the XOR) then both touch every LDS bank once.
 // Unswizzled, the 16 writing lanes sit 32 dwords apart: a 16-way bank conflict on every store.
-#ifndef TRS_NO_WSWIZZLE
 __device__ __forceinline__ int wfrag_index(int t, int c) { return (c >> 2) * 64 + (c & 3) * 16 + (t ^ c); }
 // the same for the reading lane: index of this lane's element of k-step r
 __device__ __forceinline__ int wfrag_lane(int r, int lane) {
     return r * 64 + (lane & 48) + ((lane & 15) ^ (4 * r + (lane >> 4)));
 }
-#else  // A/B builds: the plain layout of round 1
-__device__ __forceinline__ int wfrag_index(int t, int c) { return (c >> 2) * 64 + (c & 3) * 16 + t; }
-__device__ __forceinline__ int wfrag_lane(int r, int lane) { return r * 64 + lane; }
-#endif
 
 struct ChScratch {
     double G[4][16];  // G[q][row] = T[row][4 b + q] of the running block (conflict-free both ways)
@@ -73,65 +68,6 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
 // and also wait on the global-memory counter.
 typedef __attribute__((address_space(3))) double lds_f64;
 
-#ifdef TRS_CHOL16_RANK1
-// COLUMN BY COLUMN on the matrix core (round 5, -DTRS_CHOL16_RANK1: an A/B build - measured EQUAL to the 4-column-block
-// form below, which stays the product: an f64 MFMA is 16 passes = 64 cycles of the matrix core, so the twenty MFMAs this
-// form adds cost what the ~120 VALU instructions it saves were worth, EXPERIMENTS R5.9).  In D-form row j of the symmetric tile - and by symmetry its column j - sits in
-// register j >> 2 of the quarter-wave lq == (j & 3), one entry per lane li.  That register, scaled by 1 / L[j][j] and
-// zeroed in the other three quarter-waves, IS the operand of a rank-1 MFMA in k-slot j & 3 (A[m][k] = l[m],
-// B[k][n] = l[n]) - no gather through LDS, no per-block column factorisation on the VALU.  Per column:
-//     d = T[j][j]             one v_readlane pair (compile-time lane), pivot test
-//     p = T[j][:] / sqrt(d)   column j of L (entries above the diagonal are rounding residue: they only touch rows and
-//                             columns that are finished), quarter-wave j & 3 only
-//     T -= p p^T              ONE MFMA (the following columns' entries)
-//     w = R[j][:] / sqrt(d)   row j of inv(L): R is the running right-hand side of L W = I, D-form, starts as I
-//     R -= p w^T              ONE MFMA
-// ~16 VALU instructions and 2 MFMAs per column (250 + 30 per tile) instead of ~23 and 0.6 (370 + 10).
-static __device__ __noinline__ Chol16 chol16_invert_lds(d4 t, lds_f64* G, lds_f64* wfrag) {
-    (void)G;
-    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
-    unsigned badmask = 0;
-    d4 R, u;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) R[r] = (lq + 4 * r == li) ? 1.0 : 0.0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        double pacc = 0.0, wacc = 0.0;   // this lane's entries of the block: L[li][4 b + lq], W[4 b + lq][li]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = 4 * b + q;
-            const double d = lane_bcast(t[b], 16 * q + j);      // T[j][j]: register j >> 2 = b, lane (lq = q, li = j)
-            // a non-positive (or NaN) pivot only sets its bit: what follows it is garbage, the first set bit is the answer
-            badmask |= (d > 0.0) ? 0u : 1u << j;
-            const double rinv = rsqrt_refined(d);
-            const double rm = lq == q ? rinv : 0.0;              // 1 / L[j][j] in quarter-wave q, zero elsewhere
-            const double p = t[b] * rm;                          // L[li][j] (li >= j), k-slot q
-            const double w = R[b] * rm;                          // W[j][li]
-            pacc += p;
-            wacc += w;
-            if (j < 15) {
-                // Both accumulators IN PLACE (left to the compiler, every column moved the tile to fresh registers:
-                // 52 copies per tile and callee-saved registers spilled to scratch).  R first, then T and the wait
-                // states a VALU read of an MFMA result needs (16 passes: 19) - by then R's has landed as well.
-                asm volatile(
-                    "s_nop 1\n\t"
-                    "v_mfma_f64_16x16x4_f64 %[R], %[p], %[w], %[R] neg:[1,0,0]\n\t"
-                    "v_mfma_f64_16x16x4_f64 %[t], %[p], %[p], %[t] neg:[1,0,0]\n\t"
-                    "s_nop 15\n\t"
-                    "s_nop 2"
-                    : [t] "+v"(t), [R] "+v"(R), "+v"(pacc), "+v"(wacc)   // (the sums are operands only to keep their FMAs,
-                    : [p] "v"(p), [w] "v"(w));                            // which read the OLD tile, in front of the MFMAs)
-            }
-        }
-        // A-fragment layout of PanelLds::W (swizzled, wfrag_index above): element (row 4 b + lq, column li)
-        wfrag[wfrag_index(4 * b + lq, li)] = wacc;
-        // result tile: U on and above the diagonal; the otherwise unused strictly-lower part carries
-        // inv(L) (its diagonal is 1 / diag(U)) for the 16 x 16 steps of the back substitution
-        u[b] = (4 * b + lq <= li) ? pacc : wacc;
-    }
-    return Chol16{u, badmask ? __builtin_ctz(badmask) : -1};
-}
-#else
 static __device__ __noinline__ Chol16 chol16_invert_lds(d4 t, lds_f64* G, lds_f64* wfrag) {
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
     unsigned badmask = 0;
@@ -187,7 +123,6 @@ static __device__ __noinline__ Chol16 chol16_invert_lds(d4 t, lds_f64* G, lds_f6
     }
     return Chol16{u, badmask ? __builtin_ctz(badmask) : -1};
 }
-#endif
 __device__ __forceinline__ Chol16 chol16_invert(d4 t, ChScratch& sc, double* wfrag) {
     Chol16 out = chol16_invert_lds(t, (lds_f64*)&sc.G[0][0], (lds_f64*)wfrag);
     out.bad = __builtin_amdgcn_readfirstlane(out.bad);

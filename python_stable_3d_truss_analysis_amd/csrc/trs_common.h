@@ -94,18 +94,10 @@ __host__ __device__ static inline TrsEnv trs_env_of(const int* env, int b, int n
 #ifndef TRS_NARROW_RS4_ABOVE
 #define TRS_NARROW_RS4_ABOVE 1000000
 #endif
-// bit 11 = a narrow envelope in slab form whose widest stored column (`front` = max cend[t] - t, kept in the word
-// 5 ints behind the routing word) is at most TRS_WINDOW_MAX_FRONT tiles and whose system has at most 1024 rows: the
-// work-group kernel with the whole active window in LDS takes it (trs_window.h); the wave-per-matrix kernel skips it.
-#define TRS_ENV_WINDOW 0x800
-#ifndef TRS_WINDOW_MAX_FRONT
-#define TRS_WINDOW_MAX_FRONT 11   // 66 tiles = 132 KB of window
-#endif
 __host__ __device__ static inline bool trs_env_is_narrow(const TrsEnv& e) { return (e.slack & 0xff) == TRS_NARROW_ITEM - 1; }
 __host__ __device__ static inline bool trs_env_is_compact(const TrsEnv& e) { return (e.slack & TRS_ENV_COMPACT) != 0; }
 __host__ __device__ static inline bool trs_env_is_rs4(const TrsEnv& e) { return (e.slack & TRS_ENV_RS4) != 0; }
 __host__ __device__ static inline bool trs_env_is_substituted(const TrsEnv& e) { return (e.slack & TRS_ENV_SUBSTITUTED) != 0; }
-__host__ __device__ static inline bool trs_env_is_window(const TrsEnv& e) { return (e.slack & TRS_ENV_WINDOW) != 0; }
 
 // ---- compact stiffness matrix of a narrow-envelope truss (per truss, in the assembly workspace) --------
 // K_ff as per-TILE entry lists instead of slab tiles: the factorisation reads ~10 bytes per non-zero

@@ -94,7 +94,7 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "256", "--no-cpu-baseline", "--no-pcie", "--cube-batch", "384", "--cube-steps", "2",
-           "--dataset-samples", "512", "--no-dense-ref"]
+           "--dataset-samples", "512", "--no-dense-ref", "--cube-total", "600", "--dataset-total", "700"]
     if ndev < 2:
         cmd.append("--oversubscribe")
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -114,6 +114,7 @@ def test_bench_launches_its_own_ranks():
     assert line["dataset"]["value"] > 0 and line["dataset"]["info_nonzero_rank0"] == 0
     assert line["dataset"]["rank0_samples"] == 512
     assert line["timing_group"] in ("nccl", "gloo")
+    _check_scaling_record(line, ranks=2, batch=256, cube_total=600, dataset_total=700)
 
 
 @pytest.mark.timeout(500)
@@ -127,7 +128,7 @@ def test_bench_two_ranks_one_declines_rccl():
     env["TRS_BENCH_NO_RCCL_RANK"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "128", "--no-cpu-baseline", "--no-pcie", "--cube-batch", "0", "--dataset-samples", "0",
-           "--no-dense-ref"]
+           "--no-dense-ref", "--cube-total", "0", "--dataset-total", "0"]
     if ndev < 2:
         cmd.append("--oversubscribe")
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
@@ -150,7 +151,7 @@ def test_bench_eight_ranks_smoke():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
            "--batch", "128", "--no-cpu-baseline", "--no-pcie", "--cube-batch", "256", "--cube-steps", "1",
-           "--dataset-samples", "256", "--no-dense-ref"]
+           "--dataset-samples", "256", "--no-dense-ref", "--cube-total", "2000", "--dataset-total", "3000"]
     if ndev < 8:
         cmd.append("--oversubscribe")
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -167,6 +168,44 @@ def test_bench_eight_ranks_smoke():
     assert "error" not in cube and cube["info_nonzero"] == 0 and cube["batch_per_gpu"] == 256
     assert cube["value"] > 0 and cube["rank_ms_per_step"]["min"] <= cube["rank_ms_per_step"]["max"]
     assert line["dataset"]["value"] > 0 and line["dataset"]["rank0_samples"] == 256
+    _check_scaling_record(line, ranks=8, batch=128, cube_total=2000, dataset_total=3000)
+
+
+def _check_scaling_record(line, ranks, batch, cube_total, dataset_total):
+    """`north_star_scaling` of a bench line: the three per-N entries north_star asks for are present - config 2
+    weak-scaled, config 3 and config 5 strong-scaled - each with the spread over the ranks, and the shards of the two
+    strong-scaled entries, keyed by GLOBAL index, are disjoint, cover the whole dataset and hold the trusses a single
+    process generates for those indices (joint / member totals of the regenerated dataset)."""
+    import torch
+    import bench
+    from python_stable_3d_truss_analysis_amd import generate as gen
+    from python_stable_3d_truss_analysis_amd.data import dataset_sizes
+    rec = line["north_star_scaling"]
+    assert rec["ranks"] == ranks and set(rec) >= {"config2_weak", "config3_strong", "config5_strong"}
+    c2, c3, c5 = rec["config2_weak"], rec["config3_strong"], rec["config5_strong"]
+    assert c2["scaling"] == "weak" and c2["value"] == line["value"] > 0
+    assert c2["rank_ms_per_step"]["min"] <= c2["rank_ms_per_step"]["max"]
+    # config 3: contiguous global-index shards
+    assert c3["scaling"] == "strong" and c3["total_trusses"] == cube_total and c3["value"] > 0 and c3["info_nonzero"] == 0
+    assert c3["rank_ms_per_step"]["min"] <= c3["rank_ms_per_step"]["max"]
+    assert [sh["rank"] for sh in c3["shards"]] == list(range(ranks))
+    covered = sorted((sh["first"], sh["first"] + sh["count"]) for sh in c3["shards"] if sh["count"])
+    assert covered[0][0] == 0 and covered[-1][1] == cube_total
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    whole, _ = bench.cube_workload(cube_total, 0, device="cuda:0", first=0)
+    assert sum(sh["members"] for sh in c3["shards"]) == int(whole.nM.astype(np.int64).sum())
+    assert sum(sh["joints"] for sh in c3["shards"]) == int(whole.nJ.astype(np.int64).sum())
+    # config 5: rank r owns the chunks r, r + ranks, ... of the globally indexed dataset
+    assert c5["scaling"] == "strong" and c5["total_samples"] == dataset_total and c5["value"] > 0
+    assert c5["info_nonzero"] == 0 and c5["solves_per_sample"] == 2
+    assert c5["rank_seconds"]["min"] <= c5["rank_seconds"]["max"]
+    spans = sorted((first, first + count) for sh in c5["shards"] for first, count in sh["chunks"])
+    assert spans[0][0] == 0 and spans[-1][1] == dataset_total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert sum(sh["samples"] for sh in c5["shards"]) == dataset_total
+    sizes = dataset_sizes(11, 0, dataset_total, (8, 190))
+    whole, _ = gen.generate_cube_batch_device(sizes, gridRange=(6, 6, 6), seed=11, first_index=0, device="cuda:0")
+    assert sum(sh["joints"] for sh in c5["shards"]) == int(whole.nJ.astype(np.int64).sum())
+    torch.cuda.empty_cache()
 
 
 def test_ga_population_sharded_over_two_workers():

@@ -1,5 +1,5 @@
-"""Run by tests/test_gpu_streams.py in a process of its own: the buckets of a resident ragged batch dealt onto 1, 2 and 3
-streams (`RaggedSolver(lanes=)`: every lane its own workspace, fork from / join to the caller's stream) give the same
+"""Run by tests/test_gpu_streams.py in a process of its own: the buckets of a resident ragged batch dealt onto 1, 2, 3 and
+`DEFAULT_LANES` (4) streams (`RaggedSolver(lanes=)`: every lane its own workspace, fork from / join to the caller's stream) give the same
 bits, step after step, also on a side stream of the caller's and with two section variants; a second solver that shares
 the workspaces runs right behind.  (Rounds 3-4: a stall or a burst of corrupted trusses once in a few dozen steps -
 the race in trs_joint_order's breadth-first sweep, EXPERIMENTS R5.1.)"""
@@ -22,7 +22,7 @@ one.step(sections=[None, fixed])
 want = [{k: o[k].clone() for k in ("u", "f_ext", "N", "info")} for o in one.outs]
 assert one.lanes == 1 and not any(w["info"].any() for w in want)
 ws = gpu.SolverWorkspace(torch, one.device)
-for lanes in (2, 3) * int(os.environ.get("LANES_CHECK_ROUNDS", "10")):
+for lanes in (2, 3, gpu.DEFAULT_LANES) * int(os.environ.get("LANES_CHECK_ROUNDS", "7")):
     solver = gpu.RaggedSolver(packed, reorder=True, lanes=lanes, n_variants=2, workspace=ws)
     assert solver.lanes == min(lanes, len(solver.buckets)) and {bk["lane"] for bk in solver.buckets} == set(range(solver.lanes))
     other = gpu.RaggedSolver(packed, reorder=True, lanes=lanes, n_variants=2, workspace=ws)   # same buffers, same lanes

@@ -8,7 +8,7 @@
 #   kernel-trace pass's arguments altogether.
 set -u
 TAG=${1:-prof}; shift || true
-QUIET="--no-cpu-baseline --cpu-pool-seconds 0 --no-dense-ref --no-pcie --cube-batch 0 --dataset-samples 0"
+QUIET="--no-cpu-baseline --cpu-pool-seconds 0 --no-dense-ref --no-pcie --cube-batch 0 --dataset-samples 0 --cube-total 0 --dataset-total 0"
 USER_ARGS="$*"
 ARGS="--steps 2 --warmup 1 $QUIET $USER_ARGS"
 OUT=gpurun_out/$TAG

@@ -1,0 +1,635 @@
+// repro_families.cpp - the stream-safety clause of include/trs_solver.h for EVERY kernel family.
+//
+// tools/repro_streams.cpp soaks one launch sequence (trs_joint_order_rows -> trs_solve_rows).  This program runs the
+// other families BESIDE it and beside each other - each job on a stream of its own with buffers of its own - and
+// compares every output of every step, bit for bit, with the same jobs run one after the other on ONE stream:
+//
+//   stream 0            the ragged pipeline: per bucket trs_joint_order_rows -> trs_solve_rows x 2 section variants
+//   stream 1            trs_solve_small with the fitness reductions on a batch of small trusses, then a GA generation:
+//                       trs_ga_sections (gene matrix -> A, E, rho) -> trs_solve_small + fitness on a population that
+//                       shares one geometry
+//   stream 2            trs_graph_features_packed and trs_fitness on a solved batch (read-only inputs)
+//   stream 3 (CU-masked, trs_stream_create_masked: 16 compute units)
+//                       trs_copy_rows: pull of rows out of page-locked HOST arrays (live bytes only, zero fill), push of
+//                       rows into page-locked host arrays; then trs_cubegen_dev regenerating the whole batch
+//   + optionally the spinning noise kernel of repro_streams.cpp on a stream of its own
+//
+// No PyTorch, no Python: hipMalloc, hipHostMalloc, hipStream_t, hipEvent_t and the C ABI only; the library comes in
+// through dlopen.
+//
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/repro_families.cpp -o tools/repro_families -ldl -lpthread
+//   tools/repro_families <libtrs_hip.so> [--trusses B] [--small Bs] [--steps K] [--noise W] [--serial] [--seed S]
+// Exit code: 0 = every output of every step equal, 1 = differences, 3 = a step did not come back (watchdog).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <unistd.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../include/trs_solver.h"
+
+#define HIP(x)                                                                                     \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));    \
+            _exit(2);                                                                              \
+        }                                                                                          \
+    } while (0)
+#define TRS(x)                                                                   \
+    do {                                                                         \
+        int e_ = (x);                                                            \
+        if (e_ != 0) {                                                           \
+            fprintf(stderr, "%s:%d %s -> %d\n", __FILE__, __LINE__, #x, e_);     \
+            _exit(2);                                                            \
+        }                                                                        \
+    } while (0)
+
+struct Api {
+    decltype(&trs_cubegen_dev) cubegen;
+    decltype(&trs_joint_order_rows) order_rows;
+    decltype(&trs_solve_rows) solve_rows;
+    decltype(&trs_solve_small) solve_small;
+    decltype(&trs_solve_small_fits) small_fits;
+    decltype(&trs_ga_sections) ga_sections;
+    decltype(&trs_fitness) fitness;
+    decltype(&trs_graph_features_packed) features_packed;
+    decltype(&trs_copy_rows) copy_rows;
+    decltype(&trs_stream_create_masked) stream_masked;
+    decltype(&trs_stream_destroy) stream_destroy;
+    decltype(&trs_slab_ld) slab_ld;
+    decltype(&trs_slab_rows) slab_rows;
+    decltype(&trs_env_ints) env_ints;
+    decltype(&trs_assemble_work_bytes) work_bytes;
+    decltype(&trs_joint_order_fits) order_fits;
+    decltype(&trs_abi_version) abi;
+    int (*bounds)(int, int, int, int, int, int*, int*);
+};
+
+template <typename T>
+static T* dmalloc(size_t count) {
+    void* p = nullptr;
+    HIP(hipMalloc(&p, std::max<size_t>(1, count) * sizeof(T)));
+    return static_cast<T*>(p);
+}
+template <typename T>
+static T* hmalloc(size_t count) {   // page-locked, mapped into the device's address space
+    void* p = nullptr;
+    HIP(hipHostMalloc(&p, std::max<size_t>(1, count) * sizeof(T), hipHostMallocDefault));
+    return static_cast<T*>(p);
+}
+
+// ---- bitwise comparison of two byte ranges (either may be page-locked host memory) --------------------------------
+__global__ void differ_kernel(const unsigned char* a, const unsigned char* b, size_t bytes, int* bad, int slot) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+    int d = 0;
+    for (; i + 8 <= bytes; i += stride)
+        d |= *reinterpret_cast<const unsigned long long*>(a + i) != *reinterpret_cast<const unsigned long long*>(b + i);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t k = bytes / 8 * 8; k < bytes; ++k) d |= a[k] != b[k];
+    if (d) atomicAdd(&bad[slot], 1);
+}
+
+__global__ void replicate_rows_kernel(unsigned char* dst, const unsigned char* src_row, size_t row_bytes, int count) {
+    const size_t total = row_bytes * (size_t)count;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src_row[i % row_bytes];
+}
+
+// time-limited noise (as tools/repro_streams.cpp): single-wave work-groups spinning at raised priority
+__global__ __launch_bounds__(64) void noise_kernel(unsigned long long ticks, double* sink) {
+    const unsigned long long t0 = wall_clock64();
+    __builtin_amdgcn_s_setprio(3);
+    double x = 1.0 + threadIdx.x * 1e-9, y = 0.999999;
+    while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 256; ++i) x = fma(x, y, 1e-12);
+    }
+    if (x == 123.456) sink[0] = x;
+}
+
+// An output of a job in two copies: `out` (written by the concurrent steps) and `ref` (written once, by the serial
+// run).  Both are filled with `fill` before they are written, so bytes no kernel writes compare equal.
+struct Pair {
+    std::string name;
+    void *out = nullptr, *ref = nullptr;
+    size_t bytes = 0;
+    int fill = 0xA5;
+    bool host = false;
+    bool job_clears = false;   // the job that writes `out` clears it itself (no poison between the steps)
+};
+
+struct Bucket {
+    int count = 0, nJ_b = 0, nM_b = 0, n_b = 0, ld = 0, rows_pad = 0;
+    size_t work_per = 0;
+    int env_per = 0;
+    std::vector<int64_t> idx;
+    int64_t* rows = nullptr;
+    double *xyz = nullptr, *loads = nullptr, *E = nullptr, *A = nullptr;
+    uint8_t* cbits = nullptr;
+    int32_t *conn = nullptr, *nJ = nullptr, *nM = nullptr, *free_index = nullptr, *n_free = nullptr, *info = nullptr,
+            *perm = nullptr, *reach = nullptr;
+};
+
+// a generated batch of cube trusses, padded to its own maxima
+struct Batch {
+    int B = 0, jm = 0, mm = 0;
+    std::vector<int32_t> cubes, h_nJ, h_nM, h_free;
+    int32_t *d_cubes = nullptr, *nJ = nullptr, *nM = nullptr, *nfree = nullptr, *status = nullptr;
+    double *xyz = nullptr, *loads = nullptr, *E = nullptr, *A = nullptr, *rho = nullptr;
+    uint8_t* cbits = nullptr;
+    int32_t* conn = nullptr;
+};
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        fprintf(stderr, "usage: %s <libtrs_hip.so> [--trusses B] [--small Bs] [--steps K] [--noise W] [--serial] [--seed S]\n", argv[0]);
+        return 2;
+    }
+    const std::string libpath = argv[1];
+    int B = 8192, Bs = 8192, steps = 100, noise = 0, serial = 0;
+    unsigned long long seed = 7;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() { return i + 1 < argc ? atoi(argv[++i]) : 0; };
+        if (a == "--trusses") B = next();
+        else if (a == "--small") Bs = next();
+        else if (a == "--steps") steps = next();
+        else if (a == "--noise") noise = next();
+        else if (a == "--serial") serial = 1;
+        else if (a == "--seed") seed = (unsigned long long)next();
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    void* h = dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "dlopen %s: %s\n", libpath.c_str(), dlerror()); return 2; }
+    std::string hostlib = libpath.substr(0, libpath.find_last_of('/') + 1);
+    if (hostlib.size() >= 9 && hostlib.compare(hostlib.size() - 9, 9, "variants/") == 0) hostlib.resize(hostlib.size() - 9);
+    hostlib += "libtrs_host.so";
+    void* hh = dlopen(hostlib.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!hh) { fprintf(stderr, "dlopen %s: %s\n", hostlib.c_str(), dlerror()); return 2; }
+    Api api;
+#define SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, name)); if (!api.field) { fprintf(stderr, "missing %s\n", name); return 2; }
+    SYM(cubegen, "trs_cubegen_dev") SYM(order_rows, "trs_joint_order_rows") SYM(solve_rows, "trs_solve_rows")
+    SYM(solve_small, "trs_solve_small") SYM(small_fits, "trs_solve_small_fits") SYM(ga_sections, "trs_ga_sections")
+    SYM(fitness, "trs_fitness") SYM(features_packed, "trs_graph_features_packed") SYM(copy_rows, "trs_copy_rows")
+    SYM(stream_masked, "trs_stream_create_masked") SYM(stream_destroy, "trs_stream_destroy")
+    SYM(slab_ld, "trs_slab_ld") SYM(slab_rows, "trs_slab_rows") SYM(env_ints, "trs_env_ints")
+    SYM(work_bytes, "trs_assemble_work_bytes") SYM(order_fits, "trs_joint_order_fits") SYM(abi, "trs_abi_version")
+#undef SYM
+    api.bounds = reinterpret_cast<decltype(api.bounds)>(dlsym(hh, "trs_cubegen_bounds"));
+    if (!api.bounds) { fprintf(stderr, "missing trs_cubegen_bounds\n"); return 2; }
+
+    HIP(hipSetDevice(0));
+    hipDeviceProp_t prop;
+    HIP(hipGetDeviceProperties(&prop, 0));
+    const int n_cu = prop.multiProcessorCount;
+    printf("device %s, %d CUs; library %s (ABI %d); %d cube trusses + %d small trusses, %d steps, noise %d, %s\n", prop.name,
+           n_cu, libpath.c_str(), api.abi(), B, Bs, steps, noise, serial ? "streams chained (no overlap)" : "streams free-running");
+    fflush(stdout);
+
+    hipStream_t s_main, s_small, s_feat, s_noise;
+    HIP(hipStreamCreateWithFlags(&s_main, hipStreamNonBlocking));
+    HIP(hipStreamCreateWithFlags(&s_small, hipStreamNonBlocking));
+    HIP(hipStreamCreateWithFlags(&s_feat, hipStreamNonBlocking));
+    HIP(hipStreamCreateWithFlags(&s_noise, hipStreamNonBlocking));
+    void* s_masked_v = nullptr;
+    {
+        std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+        mask[0] = 0x0000ffffu;   // 16 compute units, two of each XCD
+        TRS(api.stream_masked(mask.data(), (int)mask.size(), &s_masked_v));
+    }
+    hipStream_t s_masked = (hipStream_t)s_masked_v;
+
+    const double mtypes_h[3] = {1.0, 1e7, 0.1};
+    double* d_types = dmalloc<double>(3);
+    HIP(hipMemcpy(d_types, mtypes_h, sizeof(mtypes_h), hipMemcpyHostToDevice));
+    const double frange[6] = {-30000, 30000, -30000, 30000, -30000, 30000};
+
+    // ---- generated batches -------------------------------------------------------------------------------------------
+    auto sizes_pass = [&](Batch& g, int count, int lo, int hi, unsigned long long sd) {
+        g.B = count;
+        g.cubes.resize(count);
+        unsigned long long s = sd * 0x9E3779B97F4A7C15ull + 12345;
+        for (int b = 0; b < count; ++b) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            g.cubes[b] = lo + (int)((s >> 33) % (unsigned long long)(hi - lo + 1));
+        }
+        int nJ_bound = 0, nM_bound = 0;
+        api.bounds(6, 6, 6, hi, 0, &nJ_bound, &nM_bound);
+        g.d_cubes = dmalloc<int32_t>(count);
+        HIP(hipMemcpy(g.d_cubes, g.cubes.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
+        g.nJ = dmalloc<int32_t>(count); g.nM = dmalloc<int32_t>(count); g.nfree = dmalloc<int32_t>(count);
+        g.status = dmalloc<int32_t>(2);
+        HIP(hipMemset(g.status, 0, 8));
+        TRS(api.cubegen(count, sd, 6, 6, 6, g.d_cubes, 2, 3, 0, 50.0, 150.0, frange, -1, -1, d_types, 1, nJ_bound, nM_bound,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g.nJ, g.nM, g.nfree, g.status, 0, s_main));
+        HIP(hipStreamSynchronize(s_main));
+        g.h_nJ.resize(count); g.h_nM.resize(count); g.h_free.resize(count);
+        HIP(hipMemcpy(g.h_nJ.data(), g.nJ, count * 4, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(g.h_nM.data(), g.nM, count * 4, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(g.h_free.data(), g.nfree, count * 4, hipMemcpyDeviceToHost));
+        g.jm = *std::max_element(g.h_nJ.begin(), g.h_nJ.end());
+        g.mm = *std::max_element(g.h_nM.begin(), g.h_nM.end());
+    };
+    struct GenOut {   // the arrays one fill pass of the generator writes
+        double *xyz, *loads, *E, *A, *rho;
+        uint8_t* cbits;
+        int32_t *conn, *nJ, *nM, *nfree, *status;
+    };
+    auto alloc_gen = [&](const Batch& g) {
+        GenOut o;
+        o.xyz = dmalloc<double>((size_t)g.B * g.jm * 3); o.loads = dmalloc<double>((size_t)g.B * g.jm * 3);
+        o.E = dmalloc<double>((size_t)g.B * g.mm); o.A = dmalloc<double>((size_t)g.B * g.mm); o.rho = dmalloc<double>((size_t)g.B * g.mm);
+        o.cbits = dmalloc<uint8_t>((size_t)g.B * g.jm); o.conn = dmalloc<int32_t>((size_t)g.B * g.mm * 2);
+        o.nJ = dmalloc<int32_t>(g.B); o.nM = dmalloc<int32_t>(g.B); o.nfree = dmalloc<int32_t>(g.B); o.status = dmalloc<int32_t>(2);
+        return o;
+    };
+    auto clear_gen = [&](const Batch& g, const GenOut& o, hipStream_t st) {
+        HIP(hipMemsetAsync(o.xyz, 0, (size_t)g.B * g.jm * 24, st)); HIP(hipMemsetAsync(o.loads, 0, (size_t)g.B * g.jm * 24, st));
+        HIP(hipMemsetAsync(o.E, 0, (size_t)g.B * g.mm * 8, st)); HIP(hipMemsetAsync(o.A, 0, (size_t)g.B * g.mm * 8, st));
+        HIP(hipMemsetAsync(o.rho, 0, (size_t)g.B * g.mm * 8, st)); HIP(hipMemsetAsync(o.cbits, 0, (size_t)g.B * g.jm, st));
+        HIP(hipMemsetAsync(o.conn, 0, (size_t)g.B * g.mm * 8, st)); HIP(hipMemsetAsync(o.nJ, 0, (size_t)g.B * 4, st));
+        HIP(hipMemsetAsync(o.nM, 0, (size_t)g.B * 4, st)); HIP(hipMemsetAsync(o.nfree, 0, (size_t)g.B * 4, st));
+        HIP(hipMemsetAsync(o.status, 0, 8, st));
+    };
+    auto fill_gen = [&](const Batch& g, const GenOut& o, unsigned long long sd, hipStream_t st) {
+        TRS(api.cubegen(g.B, sd, 6, 6, 6, g.d_cubes, 2, 3, 0, 50.0, 150.0, frange, -1, -1, d_types, 1, g.jm, g.mm, o.xyz, o.conn,
+                        o.E, o.A, o.rho, o.cbits, o.loads, o.nJ, o.nM, o.nfree, o.status, 0, st));
+    };
+    Batch big, small;
+    sizes_pass(big, B, 8, 190, seed);
+    sizes_pass(small, Bs, 1, 8, seed + 1);
+    const int jm = big.jm, mm = big.mm;
+    GenOut g_big = alloc_gen(big), g_big2 = alloc_gen(big), g_small = alloc_gen(small);
+    clear_gen(big, g_big, s_main); fill_gen(big, g_big, seed, s_main);
+    clear_gen(small, g_small, s_main); fill_gen(small, g_small, seed + 1, s_main);
+    HIP(hipStreamSynchronize(s_main));
+    big.xyz = g_big.xyz; big.loads = g_big.loads; big.E = g_big.E; big.A = g_big.A; big.rho = g_big.rho; big.cbits = g_big.cbits;
+    big.conn = g_big.conn;
+    const int n_small_max = *std::max_element(small.h_free.begin(), small.h_free.end());
+    if (n_small_max > 128 || !api.small_fits(small.jm, small.mm, 128)) {
+        fprintf(stderr, "the small batch does not fit trs_solve_small (n_free up to %d)\n", n_small_max);
+        return 2;
+    }
+
+    std::vector<Pair> pairs;
+    auto dpair = [&](const std::string& name, size_t bytes, int fill = 0xA5) {
+        Pair p;
+        p.name = name; p.bytes = bytes; p.fill = fill;
+        p.out = dmalloc<unsigned char>(bytes); p.ref = dmalloc<unsigned char>(bytes);
+        HIP(hipMemset(p.out, fill, std::max<size_t>(1, bytes))); HIP(hipMemset(p.ref, fill, std::max<size_t>(1, bytes)));
+        pairs.push_back(p);
+        return (int)pairs.size() - 1;
+    };
+    auto hpair = [&](const std::string& name, size_t bytes, int fill = 0xA5) {
+        Pair p;
+        p.name = name; p.bytes = bytes; p.fill = fill; p.host = true;
+        p.out = hmalloc<unsigned char>(bytes); p.ref = hmalloc<unsigned char>(bytes);
+        memset(p.out, fill, bytes); memset(p.ref, fill, bytes);
+        pairs.push_back(p);
+        return (int)pairs.size() - 1;
+    };
+    auto side = [&](int id, bool ref) { return ref ? pairs[id].ref : pairs[id].out; };
+
+    // ---- job 0: the ragged pipeline (as tools/repro_streams.cpp, one lane) ------------------------------------------
+    auto n_pad = [&](int b) { return (big.h_free[b] + 63) / 64 * 64; };
+    std::vector<int> order(B);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_pad(a) > n_pad(b); });
+    const size_t slab_cap = (size_t)12 << 30;
+    const int quantum = 12 * n_cu;
+    std::vector<Bucket> buckets;
+    size_t needS = 0, needUf = 0, needWork = 0, needEnv = 0;
+    for (size_t i = 0; i < order.size();) {
+        const int top = std::max(64, n_pad(order[i]));
+        const size_t cap = std::max<size_t>(1, slab_cap / ((size_t)top * (top + 16) * 8));
+        size_t in_span = 0;
+        while (i + in_span < order.size() && n_pad(order[i + in_span]) >= top - 128) ++in_span;
+        size_t take = std::min(cap, in_span);
+        if (take >= (size_t)quantum) take = take / quantum * quantum;
+        Bucket bk;
+        bk.idx.assign(order.begin() + i, order.begin() + i + take);
+        std::sort(bk.idx.begin(), bk.idx.end());
+        std::stable_sort(bk.idx.begin(), bk.idx.end(), [&](int64_t a, int64_t b) { return big.h_free[a] < big.h_free[b]; });
+        bk.count = (int)take;
+        for (int64_t g : bk.idx) {
+            bk.nJ_b = std::max(bk.nJ_b, big.h_nJ[g]);
+            bk.nM_b = std::max(bk.nM_b, big.h_nM[g]);
+            bk.n_b = std::max(bk.n_b, big.h_free[g]);
+        }
+        bk.nJ_b = std::max(1, bk.nJ_b);
+        bk.nM_b = std::max(1, bk.nM_b);
+        if (!api.order_fits(bk.nJ_b, bk.nM_b)) { fprintf(stderr, "bucket does not fit trs_joint_order\n"); return 2; }
+        bk.ld = api.slab_ld(bk.n_b);
+        bk.rows_pad = api.slab_rows(bk.n_b);
+        bk.work_per = api.work_bytes(bk.nJ_b, bk.nM_b, bk.n_b);
+        bk.env_per = api.env_ints(bk.n_b);
+        const size_t Bb = bk.count;
+        needS = std::max(needS, Bb * bk.rows_pad * bk.ld); needUf = std::max(needUf, Bb * bk.rows_pad);
+        needWork = std::max(needWork, Bb * bk.work_per); needEnv = std::max(needEnv, Bb * bk.env_per);
+        bk.rows = dmalloc<int64_t>(Bb);
+        HIP(hipMemcpy(bk.rows, bk.idx.data(), Bb * 8, hipMemcpyHostToDevice));
+        bk.xyz = dmalloc<double>(Bb * bk.nJ_b * 3); bk.loads = dmalloc<double>(Bb * bk.nJ_b * 3);
+        bk.cbits = dmalloc<uint8_t>(Bb * bk.nJ_b); bk.conn = dmalloc<int32_t>(Bb * bk.nM_b * 2);
+        bk.E = dmalloc<double>(Bb * bk.nM_b); bk.A = dmalloc<double>(Bb * bk.nM_b);
+        bk.nJ = dmalloc<int32_t>(Bb); bk.nM = dmalloc<int32_t>(Bb);
+        bk.free_index = dmalloc<int32_t>(Bb * bk.nJ_b * 3); bk.n_free = dmalloc<int32_t>(Bb); bk.info = dmalloc<int32_t>(Bb);
+        bk.perm = dmalloc<int32_t>(Bb * bk.nJ_b); bk.reach = dmalloc<int32_t>(Bb);
+        buckets.push_back(std::move(bk));
+        i += take;
+    }
+    double *S = dmalloc<double>(needS), *uf = dmalloc<double>(needUf);
+    uint8_t* work = dmalloc<uint8_t>(needWork);
+    int32_t* env = dmalloc<int32_t>(needEnv);
+    HIP(hipMemset(env, 0, std::max<size_t>(1, needEnv) * 4));
+    int id_u[2], id_f[2], id_N[2], id_info[2];
+    for (int v = 0; v < 2; ++v) {   // (zero fill: what lies beyond a bucket's width is never written)
+        id_u[v] = dpair("ragged u " + std::to_string(v), (size_t)B * jm * 24, 0);
+        id_f[v] = dpair("ragged f_ext " + std::to_string(v), (size_t)B * jm * 24, 0);
+        id_N[v] = dpair("ragged N " + std::to_string(v), (size_t)B * mm * 8, 0);
+        id_info[v] = dpair("ragged info " + std::to_string(v), (size_t)B * 4, 0);
+    }
+    auto job_ragged = [&](bool ref, hipStream_t st) {
+        for (auto& bk : buckets) {
+            TRS(api.order_rows(bk.count, bk.nJ_b, bk.nM_b, bk.rows, jm, mm, big.xyz, big.conn, big.cbits, big.loads, big.E,
+                               big.A, big.nJ, big.nM, bk.perm, bk.reach, bk.xyz, bk.conn, bk.cbits, bk.loads, bk.E, bk.A,
+                               bk.nJ, bk.nM, 3, st));
+            for (int v = 0; v < 2; ++v)
+                TRS(api.solve_rows(bk.count, bk.nJ_b, bk.nM_b, bk.n_b, bk.xyz, bk.conn, bk.E, bk.A, bk.cbits, bk.loads, bk.nJ,
+                                   bk.nM, bk.free_index, bk.n_free, bk.ld, bk.rows_pad, S, uf, bk.rows_pad,
+                                   (double*)side(id_u[v], ref), (double*)side(id_f[v], ref), (double*)side(id_N[v], ref),
+                                   bk.info, work, env, bk.perm, bk.rows, jm, mm, (int32_t*)side(id_info[v], ref), 0, st));
+        }
+    };
+
+    // ---- job 1: fused small-system kernel with the fitness reductions; a GA generation -------------------------------
+    const int js = small.jm, ms = small.mm;
+    const int sm_u = dpair("small u", (size_t)Bs * js * 24), sm_f = dpair("small f_ext", (size_t)Bs * js * 24),
+              sm_N = dpair("small N", (size_t)Bs * ms * 8), sm_info = dpair("small info", (size_t)Bs * 4),
+              sm_fi = dpair("small free_index", (size_t)Bs * js * 12), sm_nf = dpair("small n_free", (size_t)Bs * 4),
+              sm_w = dpair("small weight", (size_t)Bs * 8), sm_sv = dpair("small stress_vio", (size_t)Bs * 8),
+              sm_dv = dpair("small disp_vio", (size_t)Bs * 8);
+    // the population: the geometry of the small batch's largest truss in every row, sections from a gene matrix
+    const int g0 = (int)(std::max_element(small.h_nM.begin(), small.h_nM.end()) - small.h_nM.begin());
+    const int n_member = small.h_nM[g0], n_type = 20;
+    double *p_xyz = dmalloc<double>((size_t)Bs * js * 3), *p_loads = dmalloc<double>((size_t)Bs * js * 3);
+    uint8_t* p_cbits = dmalloc<uint8_t>((size_t)Bs * js);
+    int32_t *p_conn = dmalloc<int32_t>((size_t)Bs * ms * 2), *p_nJ = dmalloc<int32_t>(Bs), *p_nM = dmalloc<int32_t>(Bs);
+    auto replicate = [&](void* dst, const void* src, size_t row_bytes) {
+        hipLaunchKernelGGL(replicate_rows_kernel, dim3(1024), dim3(256), 0, s_main, (unsigned char*)dst,
+                           (const unsigned char*)src + (size_t)g0 * row_bytes, row_bytes, Bs);
+        HIP(hipGetLastError());
+    };
+    replicate(p_xyz, g_small.xyz, (size_t)js * 24); replicate(p_loads, g_small.loads, (size_t)js * 24);
+    replicate(p_cbits, g_small.cbits, (size_t)js); replicate(p_conn, g_small.conn, (size_t)ms * 8);
+    replicate(p_nJ, g_small.nJ, 4); replicate(p_nM, g_small.nM, 4);
+    std::vector<uint8_t> h_genes((size_t)Bs * n_member);
+    {
+        unsigned long long s = seed ^ 0xabcdefull;
+        for (auto& gbyte : h_genes) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            gbyte = (uint8_t)((s >> 40) % n_type);
+        }
+    }
+    uint8_t* d_genes = dmalloc<uint8_t>(h_genes.size());
+    HIP(hipMemcpy(d_genes, h_genes.data(), h_genes.size(), hipMemcpyHostToDevice));
+    std::vector<double> h_table(3 * n_type);
+    for (int t = 0; t < n_type; ++t) { h_table[3 * t] = 0.5 + 0.25 * t; h_table[3 * t + 1] = 1e7 + 1e6 * t; h_table[3 * t + 2] = 0.1 + 0.01 * t; }
+    double* d_table = dmalloc<double>(h_table.size());
+    HIP(hipMemcpy(d_table, h_table.data(), h_table.size() * 8, hipMemcpyHostToDevice));
+    const int ga_A = dpair("ga A", (size_t)Bs * ms * 8), ga_E = dpair("ga E", (size_t)Bs * ms * 8), ga_rho = dpair("ga rho", (size_t)Bs * ms * 8),
+              ga_u = dpair("ga u", (size_t)Bs * js * 24), ga_f = dpair("ga f_ext", (size_t)Bs * js * 24), ga_N = dpair("ga N", (size_t)Bs * ms * 8),
+              ga_info = dpair("ga info", (size_t)Bs * 4), ga_w = dpair("ga weight", (size_t)Bs * 8), ga_sv = dpair("ga stress_vio", (size_t)Bs * 8),
+              ga_dv = dpair("ga disp_vio", (size_t)Bs * 8);
+    auto job_small = [&](bool ref, hipStream_t st) {
+        TRS(api.solve_small(Bs, js, ms, 128, g_small.xyz, g_small.conn, g_small.E, g_small.A, g_small.cbits, g_small.loads,
+                            g_small.nJ, g_small.nM, (double*)side(sm_u, ref), (double*)side(sm_f, ref), (double*)side(sm_N, ref),
+                            (int32_t*)side(sm_info, ref), (int32_t*)side(sm_fi, ref), (int32_t*)side(sm_nf, ref), g_small.rho,
+                            30000.0, 10.0, (double*)side(sm_w, ref), (double*)side(sm_sv, ref), (double*)side(sm_dv, ref), st));
+        TRS(api.ga_sections(Bs, ms, Bs, n_member, n_type, d_genes, d_table, (double*)side(ga_A, ref), (double*)side(ga_E, ref),
+                            (double*)side(ga_rho, ref), st));
+        TRS(api.solve_small(Bs, js, ms, 128, p_xyz, p_conn, (double*)side(ga_E, ref), (double*)side(ga_A, ref), p_cbits, p_loads,
+                            p_nJ, p_nM, (double*)side(ga_u, ref), (double*)side(ga_f, ref), (double*)side(ga_N, ref),
+                            (int32_t*)side(ga_info, ref), nullptr, nullptr, (double*)side(ga_rho, ref), 30000.0, 10.0,
+                            (double*)side(ga_w, ref), (double*)side(ga_sv, ref), (double*)side(ga_dv, ref), st));
+    };
+
+    // ---- job 2: graph features (packed) and the fitness reductions of a solved batch (inputs: the REFERENCE results) ----
+    std::vector<int64_t> h_joff(B + 1, 0), h_moff(B + 1, 0);
+    for (int b = 0; b < B; ++b) { h_joff[b + 1] = h_joff[b] + big.h_nJ[b]; h_moff[b + 1] = h_moff[b] + big.h_nM[b]; }
+    const size_t SJ = (size_t)h_joff[B], SM = (size_t)h_moff[B];
+    int64_t *d_joff = dmalloc<int64_t>(B + 1), *d_moff = dmalloc<int64_t>(B + 1);
+    HIP(hipMemcpy(d_joff, h_joff.data(), (B + 1) * 8, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(d_moff, h_moff.data(), (B + 1) * 8, hipMemcpyHostToDevice));
+    const int FJ = 10, FM = 10;   // regression with a prior: 7 + 3 joint features, 8 + 1 + 1 member features
+    const int gf_jx = dpair("features joint_x", SJ * FJ * 4), gf_mx = dpair("features member_x", SM * FM * 4),
+              gf_jy = dpair("features joint_y", SJ * 3 * 4), gf_my = dpair("features member_y", SM * 4),
+              gf_j2m = dpair("features j2m_joint", SM * 2 * 4), gf_w = dpair("features weight", (size_t)B * 8),
+              ft_w = dpair("fitness weight", (size_t)B * 8), ft_sv = dpair("fitness stress_vio", (size_t)B * 8),
+              ft_dv = dpair("fitness disp_vio", (size_t)B * 8);
+    auto job_features = [&](bool ref, hipStream_t st) {
+        const double *u_act = (const double*)pairs[id_u[0]].ref, *N_act = (const double*)pairs[id_N[0]].ref,
+                     *u_pri = (const double*)pairs[id_u[1]].ref, *N_pri = (const double*)pairs[id_N[1]].ref;
+        TRS(api.features_packed(B, jm, mm, big.xyz, big.conn, big.A, big.rho, big.cbits, big.loads, big.nJ, big.nM, u_act, N_act,
+                                u_pri, N_pri, 1.0, 1e3, 0.1, 100.0, 1, d_joff, d_moff, (float*)side(gf_jx, ref),
+                                (float*)side(gf_mx, ref), (float*)side(gf_jy, ref), (float*)side(gf_my, ref),
+                                (int32_t*)side(gf_j2m, ref), (double*)side(gf_w, ref), st));
+        TRS(api.fitness(B, jm, mm, big.xyz, big.conn, big.A, big.rho, big.nJ, big.nM, u_act, N_act, 30000.0, 10.0,
+                        (double*)side(ft_w, ref), (double*)side(ft_sv, ref), (double*)side(ft_dv, ref), st));
+    };
+
+    // ---- job 3 (CU-masked stream): trs_copy_rows between page-locked host arrays and the device; the generator ---------
+    const int Bc = std::min(B, 4096);
+    std::vector<int64_t> h_rows(Bc);
+    {   // distinct rows for any B: a strided walk with a stride coprime to B
+        int64_t stride = 7919;
+        while (std::gcd<int64_t>(stride, B) != 1) ++stride;
+        for (int i = 0; i < Bc; ++i) h_rows[i] = ((int64_t)i * stride) % B;
+    }
+    int64_t* d_rows = dmalloc<int64_t>(Bc);
+    HIP(hipMemcpy(d_rows, h_rows.data(), (size_t)Bc * 8, hipMemcpyHostToDevice));
+    std::vector<int32_t> h_cJ(Bc), h_cM(Bc);
+    for (int i = 0; i < Bc; ++i) { h_cJ[i] = big.h_nJ[h_rows[i]]; h_cM[i] = big.h_nM[h_rows[i]]; }
+    int32_t *d_cJ = dmalloc<int32_t>(Bc), *d_cM = dmalloc<int32_t>(Bc);
+    HIP(hipMemcpy(d_cJ, h_cJ.data(), (size_t)Bc * 4, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(d_cM, h_cM.data(), (size_t)Bc * 4, hipMemcpyHostToDevice));
+    // the host batch (page-locked): xyz and conn of the big batch
+    double* host_xyz = hmalloc<double>((size_t)B * jm * 3);
+    int32_t* host_conn = hmalloc<int32_t>((size_t)B * mm * 2);
+    HIP(hipMemcpy(host_xyz, big.xyz, (size_t)B * jm * 24, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(host_conn, big.conn, (size_t)B * mm * 8, hipMemcpyDeviceToHost));
+    const int cp_xyz = dpair("pull xyz", (size_t)Bc * jm * 24), cp_conn = dpair("pull conn", (size_t)Bc * mm * 8);
+    const int ps_u = hpair("push u (host)", (size_t)B * jm * 24, 0), ps_N = hpair("push N (host)", (size_t)B * mm * 8, 0);
+    // what is pushed: rows of the reference results gathered on the device first (bucket-shaped source)
+    double *src_u = dmalloc<double>((size_t)Bc * jm * 3), *src_N = dmalloc<double>((size_t)Bc * mm);
+    std::vector<int> gen_ids;
+    auto gen_pair = [&](const std::string& name, void* out, void* refp, size_t bytes) {
+        Pair p;
+        p.name = name; p.out = out; p.ref = refp; p.bytes = bytes; p.fill = 0; p.job_clears = true;
+        pairs.push_back(p);
+        gen_ids.push_back((int)pairs.size() - 1);
+    };
+    gen_pair("cubegen xyz", g_big2.xyz, g_big.xyz, (size_t)B * jm * 24); gen_pair("cubegen loads", g_big2.loads, g_big.loads, (size_t)B * jm * 24);
+    gen_pair("cubegen conn", g_big2.conn, g_big.conn, (size_t)B * mm * 8); gen_pair("cubegen E", g_big2.E, g_big.E, (size_t)B * mm * 8);
+    gen_pair("cubegen A", g_big2.A, g_big.A, (size_t)B * mm * 8); gen_pair("cubegen rho", g_big2.rho, g_big.rho, (size_t)B * mm * 8);
+    gen_pair("cubegen cbits", g_big2.cbits, g_big.cbits, (size_t)B * jm); gen_pair("cubegen nJ", g_big2.nJ, g_big.nJ, (size_t)B * 4);
+    gen_pair("cubegen nM", g_big2.nM, g_big.nM, (size_t)B * 4); gen_pair("cubegen n_free", g_big2.nfree, g_big.nfree, (size_t)B * 4);
+    auto job_copy_gen = [&](bool ref, hipStream_t st) {
+        {   // pull: live bytes of every row out of the host batch, the rest of the bucket row zeroed
+            const void* src[2] = {host_xyz, host_conn};
+            void* dst[2] = {side(cp_xyz, ref), side(cp_conn, ref)};
+            const size_t sp[2] = {(size_t)jm * 24, (size_t)mm * 8}, dp[2] = {(size_t)jm * 24, (size_t)mm * 8};
+            const size_t width[2] = {(size_t)jm * 24, (size_t)mm * 8}, fill[2] = {(size_t)jm * 24, (size_t)mm * 8};
+            const int32_t* counts[2] = {d_cJ, d_cM};
+            const size_t elem[2] = {24, 8};
+            TRS(api.copy_rows(2, src, sp, dst, dp, width, fill, counts, elem, nullptr, Bc, d_rows, 0, 32, st));
+        }
+        {   // gather the reference results' rows on the device, then push them into the host result arrays
+            const void* src[2] = {pairs[id_u[0]].ref, pairs[id_N[0]].ref};
+            void* dst[2] = {src_u, src_N};
+            const size_t sp[2] = {(size_t)jm * 24, (size_t)mm * 8}, dp[2] = {(size_t)jm * 24, (size_t)mm * 8};
+            const size_t width[2] = {(size_t)jm * 24, (size_t)mm * 8};
+            TRS(api.copy_rows(2, src, sp, dst, dp, width, nullptr, nullptr, nullptr, nullptr, Bc, d_rows, 0, 0, st));
+            const void* psrc[2] = {src_u, src_N};
+            void* pdst[2] = {side(ps_u, ref), side(ps_N, ref)};
+            const size_t fill[2] = {(size_t)jm * 24, (size_t)mm * 8};
+            const int32_t* counts[2] = {d_cJ, d_cM};
+            const size_t elem[2] = {24, 8};
+            TRS(api.copy_rows(2, psrc, sp, pdst, dp, width, fill, counts, elem, nullptr, Bc, d_rows, 1, 8, st));
+        }
+        if (!ref) {   // the generator beside everything else: the whole batch again, into the second set of arrays
+            clear_gen(big, g_big2, st);
+            fill_gen(big, g_big2, seed, st);
+        }
+    };
+
+    // ---- the serial reference: every job, one after the other, on ONE stream ------------------------------------------
+    int* d_bad = dmalloc<int>(256);
+    double* d_sink = dmalloc<double>(1);
+    std::atomic<long long> heartbeat{0};
+    std::atomic<int> finished{0};
+    std::thread watchdog([&]() {
+        long long last = -1;
+        int quiet = 0;
+        while (!finished.load()) {
+            std::this_thread::sleep_for(std::chrono::seconds(1));
+            const long long now = heartbeat.load();
+            quiet = now == last ? quiet + 1 : 0;
+            last = now;
+            if (quiet >= 40) {
+                printf("STALL: no progress for 40 s at heartbeat %lld\nRESULT stall\n", now);
+                fflush(stdout);
+                _exit(3);
+            }
+        }
+    });
+    auto t0 = std::chrono::steady_clock::now();
+    job_ragged(true, s_main);
+    HIP(hipStreamSynchronize(s_main));   // (the features and the push read the reference results of the ragged job)
+    const double ragged_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    job_small(true, s_main);
+    job_features(true, s_main);
+    job_copy_gen(true, s_main);
+    HIP(hipStreamSynchronize(s_main));
+    heartbeat.fetch_add(1);
+    {
+        std::vector<int32_t> hinfo(B), sinfo(Bs);
+        HIP(hipMemcpy(hinfo.data(), pairs[id_info[0]].ref, (size_t)B * 4, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(sinfo.data(), pairs[sm_info].ref, (size_t)Bs * 4, hipMemcpyDeviceToHost));
+        const long f0 = std::count_if(hinfo.begin(), hinfo.end(), [](int v) { return v != 0; });
+        const long f1 = std::count_if(sinfo.begin(), sinfo.end(), [](int v) { return v != 0; });
+        printf("serial reference: ragged job %.1f ms (%zu buckets), %ld + %ld trusses with a non-zero status; %zu outputs compared per step\n",
+               ragged_ms, buckets.size(), f0, f1, pairs.size());
+        if (f0 || f1) { printf("RESULT reference not clean\n"); return 1; }
+    }
+
+    // ---- the concurrent steps ---------------------------------------------------------------------------------------
+    std::vector<hipEvent_t> events;
+    auto new_event = [&]() {
+        hipEvent_t e;
+        HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        events.push_back(e);
+        return e;
+    };
+    const unsigned long long noise_ticks = (unsigned long long)(ragged_ms * 1.2 * 1e5);   // 100 MHz clock
+    struct Side { hipStream_t st; std::function<void(bool, hipStream_t)> job; };
+    std::vector<Side> sides = {{s_small, job_small}, {s_feat, job_features}, {s_masked, job_copy_gen}};
+    long bad_steps = 0, bad_outputs = 0;
+    for (int it = 0; it < steps; ++it) {
+        for (auto& p : pairs) {
+            if (p.job_clears) continue;
+            if (p.host) memset(p.out, p.fill, p.bytes);
+            else HIP(hipMemsetAsync(p.out, p.fill, std::max<size_t>(1, p.bytes), s_main));
+        }
+        hipEvent_t fork = new_event();
+        HIP(hipEventRecord(fork, s_main));
+        hipEvent_t chain = nullptr;
+        if (noise > 0) {
+            HIP(hipStreamWaitEvent(s_noise, fork, 0));
+            hipLaunchKernelGGL(noise_kernel, dim3(noise * n_cu), dim3(64), 0, s_noise, noise_ticks, d_sink);
+            HIP(hipGetLastError());
+        }
+        // the order in which the streams are fed changes from step to step
+        std::vector<int> feed = {0, 1, 2, 3};
+        std::rotate(feed.begin(), feed.begin() + it % 4, feed.end());
+        for (int which : feed) {
+            hipStream_t st = which == 0 ? s_main : sides[which - 1].st;
+            if (which != 0) HIP(hipStreamWaitEvent(st, fork, 0));
+            if (serial && chain) HIP(hipStreamWaitEvent(st, chain, 0));
+            if (which == 0) job_ragged(false, s_main);
+            else sides[which - 1].job(false, st);
+            if (serial) { chain = new_event(); HIP(hipEventRecord(chain, st)); }
+        }
+        for (auto& sd : sides) {
+            hipEvent_t done = new_event();
+            HIP(hipEventRecord(done, sd.st));
+            HIP(hipStreamWaitEvent(s_main, done, 0));
+        }
+        if (noise > 0) {
+            hipEvent_t done = new_event();
+            HIP(hipEventRecord(done, s_noise));
+            HIP(hipStreamWaitEvent(s_main, done, 0));
+        }
+        HIP(hipStreamSynchronize(s_main));
+        for (hipEvent_t e : events) HIP(hipEventDestroy(e));
+        events.clear();
+        heartbeat.fetch_add(1);
+        HIP(hipMemsetAsync(d_bad, 0, 256 * sizeof(int), s_main));
+        for (size_t k = 0; k < pairs.size(); ++k) {
+            hipLaunchKernelGGL(differ_kernel, dim3(512), dim3(256), 0, s_main, (const unsigned char*)pairs[k].out,
+                               (const unsigned char*)pairs[k].ref, pairs[k].bytes, d_bad, (int)k);
+            HIP(hipGetLastError());
+        }
+        std::vector<int> h_bad(256, 0);
+        HIP(hipMemcpyAsync(h_bad.data(), d_bad, 256 * sizeof(int), hipMemcpyDeviceToHost, s_main));
+        HIP(hipStreamSynchronize(s_main));
+        heartbeat.fetch_add(1);
+        int n_bad = 0;
+        for (size_t k = 0; k < pairs.size(); ++k) n_bad += h_bad[k] != 0;
+        if (n_bad) {
+            ++bad_steps;
+            bad_outputs += n_bad;
+            printf("step %d: %d outputs differ from the serial run:", it, n_bad);
+            for (size_t k = 0; k < pairs.size(); ++k)
+                if (h_bad[k]) printf(" [%s]", pairs[k].name.c_str());
+            printf("\n");
+            fflush(stdout);
+        }
+    }
+    finished.store(1);
+    watchdog.join();
+    TRS(api.stream_destroy(s_masked_v));
+    printf("RESULT families noise=%d serial=%d steps=%d: %ld steps with differences, %ld outputs\n", noise, serial, steps,
+           bad_steps, bad_outputs);
+    return bad_steps ? 1 : 0;
+}
