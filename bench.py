@@ -575,7 +575,11 @@ def host_fed_leg(args, device, torch, batch):
     solves, pushes: `batch.solve_batch_streamed`)."""
     import numpy as np
     packed, tensors = cube_workload(args.cube_batch, 0, device=device)
-    pinned, pool = packed.to_packed(tensors).pinned(), batch.ResultPool(tracked=True)   # (results are only read)
+    # the host batch in the TABLE member form (ABI 10: uint16 end joints + one type index per member, 5 instead of 24
+    # bytes per member over PCIe; the generator's trusses use one member type) - what `pack_json(..., members="auto")`
+    # gives for such a batch; results bit for bit those of the general form (tests/test_gpu_member_forms.py)
+    host = packed.to_packed(tensors)
+    pinned, pool = host.table().pinned(), batch.ResultPool(tracked=True)   # (results are only read)
     for _ in range(2):
         first = batch.solve_batch_streamed(pinned, device, reorder=True, pool=pool)
     first_u, first_N = np.array(first.displace), np.array(first.internal)   # (the pool's arrays are re-used by the next call)
@@ -588,7 +592,8 @@ def host_fed_leg(args, device, torch, batch):
     repeat = bool(np.array_equal(first_u, got.displace, equal_nan=True) and np.array_equal(first_N, got.internal, equal_nan=True))
     nJ64, nM64 = packed.nJ.astype(np.int64), packed.nM.astype(np.int64)
     return {"solves_per_s": packed.B / dt, "ms_per_call": dt * 1e3,
-            "h2d_live_bytes": int((nJ64 * 49 + nM64 * 24).sum()),
+            "h2d_live_bytes": int((nJ64 * 49 + nM64 * 5).sum()),
+            "h2d_live_bytes_general_form": int((nJ64 * 49 + nM64 * 24).sum()), "member_form": "table",
             "d2h_live_bytes": int((nJ64 * 48 + nM64 * 8).sum()) + 4 * packed.B,
             "info_nonzero": int((got.info != 0).sum()), "calls_repeat_bitwise": repeat,
             "note": "host arrays in -> host results out per CALL of batch.solve_batch_streamed (set-up "
@@ -683,24 +688,35 @@ def large_truss_leg(args, device, torch, batch):
     find_order = lambda: batch.joint_order_device(torch, tensors, effort=3, out=ordered)
     calls = (("order", find_order), ("dofmap", dev.dofmap), ("assemble", dev.assemble), ("potrf", dev.potrf),
              ("potrs", dev.potrs), ("recover", dev.recover))
-    for _ in range(2):
-        for _, call in calls:
-            call()
-    torch.cuda.synchronize(device)
     reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        for _, call in calls:
-            call()
-    torch.cuda.synchronize(device)
-    dt = (time.perf_counter() - t0) / reps
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in calls] for _ in range(reps)]
-    for r in range(reps):
-        for (name, call), (e0, e1) in zip(calls, ev[r]):
-            e0.record(); call(); e1.record()
-    torch.cuda.synchronize(device)
-    stage_ms = {name: float(np.mean([ev[r][i][0].elapsed_time(ev[r][i][1]) for r in range(reps)]))
-                for i, (name, _) in enumerate(calls)}
+
+    def measure():
+        for _ in range(2):
+            for _, call in calls:
+                call()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for _, call in calls:
+                call()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / reps
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in calls] for _ in range(reps)]
+        for r in range(reps):
+            for (name, call), (e0, e1) in zip(calls, ev[r]):
+                e0.record(); call(); e1.record()
+        torch.cuda.synchronize(device)
+        return dt, {name: float(np.mean([ev[r][i][0].elapsed_time(ev[r][i][1]) for r in range(reps)]))
+                    for i, (name, _) in enumerate(calls)}
+
+    # the other route first: every matrix on the work-group kernels (four waves per matrix: TRS_ASM_ALL_WIDE)
+    dev.options["all_wide"] = True
+    dt_wide, stage_wide = measure()
+    u_wide = dev.u.clone()
+    dev.options["all_wide"] = False
+    dt, stage_ms = measure()
+    scale = dev.u.abs().amax(dim=(1, 2), keepdim=True)
+    routes_agree = float(((u_wide - dev.u).abs() / scale).max().item())
     env = dev.env.cpu().numpy()
     nchm, npan = dev.rows // 16, dev.rows // 64
     narrow = (env[:, nchm + npan] & 0xff) == 1
@@ -729,6 +745,10 @@ def large_truss_leg(args, device, torch, batch):
             "assemble": {"algorithmic_GBps": gbs(asm_b, stage_ms["assemble"]), "frac_of_hbm_peak": gbs(asm_b, stage_ms["assemble"]) / PEAK_HBM_GBS},
             "potrs": {"algorithmic_GBps": gbs(potrs_b, stage_ms["potrs"]), "frac_of_hbm_peak": gbs(potrs_b, stage_ms["potrs"]) / PEAK_HBM_GBS},
             "recover": {"algorithmic_GBps": gbs(rec_b, stage_ms["recover"]), "frac_of_hbm_peak": gbs(rec_b, stage_ms["recover"]) / PEAK_HBM_GBS},
+            "work_group_route": {"solves_per_s": B / dt_wide, "ms_per_step": dt_wide * 1e3, "stages_ms": stage_wide,
+                                 "max_rel_diff_u_vs_default_route": routes_agree,
+                                 "note": "options={'all_wide': True}: every matrix on trs_potrf_kernel / trs_potrs_kernel "
+                                         "(a work-group of four waves per matrix) whatever its envelope"},
             "note": "informational: FLOP = the MFMA work inside the 16x16-tile envelopes (what the kernel executes), bytes = "
                     "stored tiles once per stage + vectors + inputs (`algorithmic_counts`); profile: profiles/r06_large_*"}
 

@@ -43,6 +43,20 @@
  *    never exists in dense form in HBM.  Without the flag every matrix goes through the slab (the default:
  *    measured faster end to end, EXPERIMENTS.md Part II section 3.3 and R4.1).
  *
+ * Member forms (ABI 10).  The reference describes a member as [[j0, j1], [a, e, density]] (truss.py:406-413,
+ *    MemberType type.py:5-27); most workloads draw the (a, e, density) triple from a short list (the generator's
+ *    memberTypes, the GA's type table, generate.py:300-316, ga.py:125-137).
+ *      general form   conn int32 [B][nM_max][2], E and A (and rho where densities are needed) double [B][nM_max]:
+ *                     24 (32) bytes per member.  The entry points without a suffix.
+ *      table form     conn16 uint16 [B][nM_max][2] (the library's size limit is 65 535 joints per truss anyway),
+ *                     type_idx uint8 [B][nM_max] and types double [n_types][3] = (a, e, density), n_types <= 256:
+ *                     5 bytes per member in HBM and over PCIe.  The entry points with the suffix _tab, which take
+ *                     (conn16, type_idx, types) where their twins take (conn, E, A); everything else is the same,
+ *                     and so are the results, bit for bit (E A is formed as e * a from the table: the same product).
+ *    trs_joint_order_tab / trs_joint_order_rows_tab read and write uint16 end joints (and copy the type indices of a
+ *    bucket's rows); trs_copy_rows moves either form (it copies bytes).  The fitness, graph-feature, GA-section and
+ *    generator entry points exist in the general form only.
+ *
  * Streams and threads: the library keeps NO mutable process-wide state that a result depends on (the only static
  * data are "dynamic-LDS ceiling raised" markers of kernels, set once).  Everything that selects a kernel or a data
  * path is an argument of the call (flags / hints below), every kernel works on the buffers of its call only, and no
@@ -71,7 +85,7 @@
 extern "C" {
 #endif
 
-#define TRS_ABI_VERSION 9
+#define TRS_ABI_VERSION 10
 
 /* trs_assemble flags */
 #define TRS_ASM_FULL_SYMMETRIC 1 /* also write the entries left of the diagonal tile (tests); implies the slab form */
@@ -85,6 +99,11 @@ extern "C" {
                                     matrices of the wave-per-matrix kernels leave such tiles unwritten and mark them in
                                     the envelope metadata, csrc/trs_common.h `kmask`: the factorisation takes them as zeros
                                     without reading them; about 30 % of the stored tiles of a cube truss) */
+
+#define TRS_ASM_ALL_WIDE 16      /* every matrix is routed to the work-group kernels (four waves per matrix), whatever its
+                                    envelope: for batches of FEW, LARGE systems - a batch with fewer matrices than the chip
+                                    has SIMDs leaves most of it idle under the wave-per-matrix kernels (bench.py
+                                    `large_truss`).  Not together with TRS_ASM_ALL_NARROW / TRS_ASM_COMPACT */
 
 /* hints of trs_potrf_batched / trs_potrs_batched / trs_solve: what the caller knows about the batch, so that
  * kernels that would find no matrix of theirs are not launched at all (each such launch costs 4-9 us).
@@ -106,6 +125,8 @@ extern "C" {
 #define TRS_HINT_RECOVER_UNSTAGED 32 /* trs_recover / trs_solve: the path for trusses whose tables exceed a CU's LDS
                                         (u, f_ext in the output arrays; the reactions in the same fixed order, bit for
                                         bit those of the staged path), whatever the size */
+#define TRS_HINT_ALL_WIDE 256         /* trs_solve / trs_solve_rows: assemble with TRS_ASM_ALL_WIDE (overrides TRS_HINT_NO_WIDE
+                                        and TRS_HINT_COMPACT) */
 #define TRS_HINT_RECOVER_SCAN 128    /* with TRS_HINT_RECOVER_UNSTAGED (tests): also the fall-back of that path for a truss
                                         with more than 32768 member ends at its supports - no member-end lists, a wave
                                         per constrained joint walks all members; same bits again */
@@ -404,6 +425,49 @@ int trs_solve_rows(int B, int nJ_max, int nM_max, int n_max_bound, const double 
                    double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info, void *work, int32_t *env,
                    const int32_t *joint_out, const int64_t *out_rows, int nJ_out_max, int nM_out_max,
                    int32_t *info_out, int hints, void *stream);
+
+/* ---- table member form (ABI 10, "Member forms" above): the twins of the entry points that read members.  Arguments
+ * as their twins', with (conn16, type_idx, types) in place of (conn, E, A) [and rho: the densities of the fitness
+ * reductions of trs_solve_small_tab come from the table]. ---- */
+int trs_assemble_tab(int B, int nJ_max, int nM_max, const double *xyz, const uint16_t *conn16, const uint8_t *type_idx,
+                     const double *types, const double *loads, const int32_t *free_index, const int32_t *n_free,
+                     const int32_t *nJ, const int32_t *nM, int ld, int slab_rows, double *S, int flags, void *work,
+                     int32_t *env, double *uf, int ld_uf, void *stream);
+int trs_recover_tab(int B, int nJ_max, int nM_max, const double *xyz, const uint16_t *conn16, const uint8_t *type_idx,
+                    const double *types, const double *loads, const int32_t *free_index, const int32_t *nJ,
+                    const int32_t *nM, const double *uf, int ld_uf, double *u, double *f_ext, double *N,
+                    const int32_t *joint_out, int hints, void *stream);
+int trs_recover_rows_tab(int B, int nJ_max, int nM_max, const double *xyz, const uint16_t *conn16,
+                         const uint8_t *type_idx, const double *types, const double *loads, const int32_t *free_index,
+                         const int32_t *nJ, const int32_t *nM, const double *uf, int ld_uf, const int32_t *joint_out,
+                         const int32_t *info, const int64_t *out_rows, int nJ_out_max, int nM_out_max, double *u,
+                         double *f_ext, double *N, int32_t *info_out, int hints, void *stream);
+int trs_solve_small_tab(int B, int nJ_max, int nM_max, int n_max_bound, const double *xyz, const uint16_t *conn16,
+                        const uint8_t *type_idx, const double *types, const uint8_t *cbits, const double *loads,
+                        const int32_t *nJ, const int32_t *nM, double *u, double *f_ext, double *N, int32_t *info,
+                        int32_t *free_index, int32_t *n_free, double allow_stress, double allow_displace,
+                        double *weight /* or NULL */, double *stress_vio, double *disp_vio, void *stream);
+int trs_joint_order_tab(int B, int nJ_max, int nM_max, const double *xyz, const uint16_t *conn16, const uint8_t *cbits,
+                        const double *loads, const int32_t *nJ, const int32_t *nM, int32_t *perm, int32_t *choice,
+                        int32_t *reach, double *xyz_out, uint16_t *conn16_out, uint8_t *cbits_out, double *loads_out,
+                        int effort, void *stream);
+int trs_joint_order_rows_tab(int B, int nJ_max, int nM_max, const int64_t *rows, int nJ_in_max, int nM_in_max,
+                             const double *xyz, const uint16_t *conn16, const uint8_t *cbits, const double *loads,
+                             const uint8_t *type_idx, const int32_t *nJ, const int32_t *nM, int32_t *perm,
+                             int32_t *reach, double *xyz_out, uint16_t *conn16_out, uint8_t *cbits_out,
+                             double *loads_out, uint8_t *type_idx_out, int32_t *nJ_out, int32_t *nM_out, int effort,
+                             void *stream);
+int trs_solve_tab(int B, int nJ_max, int nM_max, int n_max_bound, const double *xyz, const uint16_t *conn16,
+                  const uint8_t *type_idx, const double *types, const uint8_t *cbits, const double *loads,
+                  const int32_t *nJ, const int32_t *nM, int32_t *free_index, int32_t *n_free, int ld, int slab_rows,
+                  double *S, double *uf, int ld_uf, double *u, double *f_ext, double *N, int32_t *info, void *work,
+                  int32_t *env, const int32_t *joint_out, int hints, void *stream);
+int trs_solve_rows_tab(int B, int nJ_max, int nM_max, int n_max_bound, const double *xyz, const uint16_t *conn16,
+                       const uint8_t *type_idx, const double *types, const uint8_t *cbits, const double *loads,
+                       const int32_t *nJ, const int32_t *nM, int32_t *free_index, int32_t *n_free, int ld,
+                       int slab_rows, double *S, double *uf, int ld_uf, double *u, double *f_ext, double *N,
+                       int32_t *info, void *work, int32_t *env, const int32_t *joint_out, const int64_t *out_rows,
+                       int nJ_out_max, int nM_out_max, int32_t *info_out, int hints, void *stream);
 
 #ifdef __cplusplus
 }

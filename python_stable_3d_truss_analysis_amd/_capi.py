@@ -51,10 +51,24 @@ SIGNATURES = {
                             _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),
     "trs_solve": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
                        _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    # table member form (ABI 10): (conn16, type_idx, types) in place of (conn, E, A)
+    "trs_assemble_tab": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "trs_recover_tab": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "trs_recover_rows_tab": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P,
+                                  _I, _P]),
+    "trs_solve_small_tab": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                 _D, _D, _P, _P, _P, _P]),
+    "trs_joint_order_tab": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "trs_joint_order_rows_tab": (_I, [_I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                      _P, _P, _I, _P]),
+    "trs_solve_tab": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
+                           _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "trs_solve_rows_tab": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I,
+                                _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),
 }
 
 #: must equal TRS_ABI_VERSION of include/trs_solver.h
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 

@@ -25,7 +25,12 @@ class PackedBatch:
     xyz [B,nJ_max,3] f64 | conn [B,nM_max,2] i32 | E, A, rho [B,nM_max] f64 |
     cbits [B,nJ_max] u8 (constrained-axis bits x=1,y=2,z=4) | loads [B,nJ_max,3] f64 |
     nJ, nM [B] i32 | dim [B] (2 or 3; 2D trusses are embedded with z fixed) | n_free [B] i32.
-    """
+
+    TABLE member form (`table()`; ABI 10, `include/trs_solver.h` "Member forms"): the members' sections as one uint8
+    `type_idx` [B,nM_max] into a table `types` [T,3] = (a, e, density), T <= 256 - the reference's own description of
+    a member, `[[j0, j1], [a, e, density]]` with the triple drawn from a short list (`MemberType`, type.py:5-27) -
+    and `conn` as uint16 pairs; E, A, rho are then None.  5 instead of 32 bytes per member in host memory, over PCIe
+    and in HBM; the solvers take either form and give the same bits."""
     xyz: np.ndarray
     conn: np.ndarray
     E: np.ndarray
@@ -37,6 +42,11 @@ class PackedBatch:
     nM: np.ndarray
     dim: np.ndarray
     n_free: np.ndarray
+    type_idx: np.ndarray = None
+    types: np.ndarray = None
+
+    #: fields that are per batch, not per truss (never indexed, tiled or trimmed)
+    _SHARED = ("types",)
 
     @property
     def B(self):
@@ -54,37 +64,95 @@ class PackedBatch:
     def n_max(self):
         return int(self.n_free.max()) if self.B else 0
 
+    @property
+    def is_table(self):
+        return self.type_idx is not None
+
+    def _map(self, fn):
+        """A batch whose per-truss arrays are `fn(field name, array)` (absent fields stay absent, the type table is shared)."""
+        vals = {}
+        for f in self.__dataclass_fields__:
+            a = getattr(self, f)
+            vals[f] = a if a is None or f in self._SHARED else fn(f, a)
+        return PackedBatch(**vals)
+
     def replicate(self, times):
         """The same trusses `times` times over, as independent problems (no sharing on device)."""
-        rep = lambda a: np.ascontiguousarray(np.tile(a, (times,) + (1,) * (a.ndim - 1)))
-        return PackedBatch(*(rep(getattr(self, f)) for f in self.__dataclass_fields__))
+        return self._map(lambda f, a: np.ascontiguousarray(np.tile(a, (times,) + (1,) * (a.ndim - 1))))
 
     def take(self, index):
         """Sub-batch (rows `index`, any numpy index) - used to shard a batch over ranks."""
-        return PackedBatch(*(np.ascontiguousarray(getattr(self, f)[index])
-                             for f in self.__dataclass_fields__))
+        return self._map(lambda f, a: np.ascontiguousarray(a[index]))
 
     def pinned(self):
         """The same batch in page-locked host memory (one copy; needs the GPU runtime): `solve_batch`
         then uploads it by DMA at the full PCIe rate instead of through the driver's bounce buffers.
         The arrays are numpy views of pinned torch tensors, which they keep alive."""
         import torch
-        fields = []
-        for f in self.__dataclass_fields__:
-            a = np.ascontiguousarray(getattr(self, f))
+
+        def pin(f, a):
+            a = np.ascontiguousarray(a)
             t = torch.empty(a.shape, dtype=torch.from_numpy(a[:0].copy()).dtype, pin_memory=True)
             v = t.numpy()
             v[...] = a
-            fields.append(v)
-        return PackedBatch(*fields)
+            return v
+        return self._map(pin)
 
     def trimmed(self):
         """The same batch with the joint / member padding cut to this batch's own maxima."""
         jm = max(1, int(self.nJ.max(initial=1)))
         mm = max(1, int(self.nM.max(initial=1)))
-        cut = {"xyz": jm, "loads": jm, "cbits": jm, "conn": mm, "E": mm, "A": mm, "rho": mm}
-        return PackedBatch(*(np.ascontiguousarray(getattr(self, f)[:, :cut[f]]) if f in cut
-                             else getattr(self, f) for f in self.__dataclass_fields__))
+        cut = {"xyz": jm, "loads": jm, "cbits": jm, "conn": mm, "E": mm, "A": mm, "rho": mm, "type_idx": mm}
+        return self._map(lambda f, a: np.ascontiguousarray(a[:, :cut[f]]) if f in cut else a)
+
+    def table(self):
+        """The same batch in the TABLE member form (see the class): raises ValueError when the members use more than
+        256 distinct (a, e, density) triples.  A batch already in that form is returned as it is."""
+        if self.is_table:
+            return self
+        if self.nJ_max > 65535:
+            raise ValueError("table member form: end joints are uint16 (at most 65 535 joints per truss)")
+        live = np.arange(self.nM_max)[None, :] < np.asarray(self.nM)[:, None]
+        # distinct BIT patterns (the table must give back exactly the doubles the batch holds), found without sorting
+        # tens of millions of members: a 64-bit hash per member, the distinct hashes block by block, the hash's index in
+        # their sorted list by binary search, and then the check that every member's triple IS its table row's
+        bits = [np.ascontiguousarray(a, dtype=np.float64).view(np.uint64) for a in (self.A, self.E, self.rho)]
+        with np.errstate(over="ignore"):
+            h = (bits[0] * np.uint64(0x9E3779B97F4A7C15)) ^ (bits[1] * np.uint64(0xC2B2AE3D27D4EB4F) + np.uint64(0x165667B19E3779F9)) \
+                ^ (bits[2] * np.uint64(0xD6E8FEB86659FD93) + np.uint64(0x27D4EB2F165667C5))
+        h = np.where(live, h, h[0, 0] if h.size else 0).ravel()    # (padding members take the first member's type)
+        seen = np.zeros([0], dtype=np.uint64)
+        for k in range(0, h.size, 1 << 22):
+            seen = np.union1d(seen, np.unique(h[k: k + (1 << 22)]))
+            if len(seen) > 256:
+                raise ValueError(f"table member form: more than 256 distinct (a, e, density) triples")
+        idx = np.searchsorted(seen, h)
+        rep = np.zeros([max(1, len(seen))], dtype=np.int64)
+        rep[idx[::-1]] = np.arange(h.size - 1, -1, -1)                 # first member of every hash value
+        flat = [b.ravel() for b in bits]
+        types_bits = np.stack([f[rep] for f in flat], axis=-1)
+        if not all(np.array_equal(np.where(live.ravel(), flat[c], types_bits[idx, c]), types_bits[idx, c]) for c in range(3)):
+            raise ValueError("table member form: hash collision between member types (use the general form)")
+        order = np.lexsort((types_bits[:, 2].view(np.float64), types_bits[:, 1].view(np.float64), types_bits[:, 0].view(np.float64)))
+        rank = np.empty_like(order)
+        rank[order] = np.arange(len(order))
+        types = np.ascontiguousarray(types_bits[order].view(np.float64)) if h.size else np.zeros([1, 3])
+        type_idx = (rank[idx].astype(np.uint8).reshape(self.B, self.nM_max) * live).astype(np.uint8)
+        vals = {f: getattr(self, f) for f in self.__dataclass_fields__}
+        vals.update(conn=np.ascontiguousarray(self.conn, dtype=np.uint16), E=None, A=None, rho=None, type_idx=type_idx,
+                    types=types)
+        return PackedBatch(**vals)
+
+    def general(self):
+        """The same batch in the GENERAL member form (int32 end joints, E / A / rho per member; padding members get
+        the sections of type 0, which no kernel reads)."""
+        if not self.is_table:
+            return self
+        t = np.asarray(self.types, dtype=np.float64)[self.type_idx.astype(np.int64)]
+        vals = {f: getattr(self, f) for f in self.__dataclass_fields__}
+        vals.update(conn=np.ascontiguousarray(self.conn, dtype=np.int32), A=np.ascontiguousarray(t[..., 0]),
+                    E=np.ascontiguousarray(t[..., 1]), rho=np.ascontiguousarray(t[..., 2]), type_idx=None, types=None)
+        return PackedBatch(**vals)
 
 
 @dataclass
@@ -169,9 +237,25 @@ def pack_trusses(trusses):
     return pack_arrays(xyz, conn, mtype, sup, loads, dims)
 
 
-def pack_json(data_list):
+def _member_form(packed, members):
+    """`members`: "general" (E, A, rho per member), "table" (uint16 end joints, uint8 type index, type table; an
+    error beyond 256 distinct triples) or "auto" (the table form whenever the batch allows it)."""
+    if members == "general":
+        return packed
+    if members == "table":
+        return packed.table()
+    if members == "auto":
+        try:
+            return packed.table()
+        except ValueError:
+            return packed
+    raise ValueError(f"members must be 'general', 'table' or 'auto', not {members!r}")
+
+
+def pack_json(data_list, members="general"):
     """List of reference-format JSON dicts (`detail/combine_with_JSON.md:71-163`) -> PackedBatch,
-    without building `Truss` objects (bulk path)."""
+    without building `Truss` objects (bulk path).  `members` = "auto": the table member form (`PackedBatch.table`)
+    when the documents' `[a, e, density]` triples are at most 256 distinct ones."""
     xyz, conn, mtype, sup, loads, dims = [], [], [], [], [], []
     for data in data_list:
         dim = len(data["joint"][0][0])
@@ -186,7 +270,7 @@ def pack_json(data_list):
         conn.append(np.array([c for c, _ in data["member"]], dtype=np.int32).reshape(-1, 2))
         mtype.append(np.array([t for _, t in data["member"]], dtype=float).reshape(-1, 3))
         dims.append(dim)
-    return pack_arrays(xyz, conn, mtype, sup, loads, dims)
+    return _member_form(pack_arrays(xyz, conn, mtype, sup, loads, dims), members)
 
 
 _JSON_ERRORS = {1: "JSON syntax", 2: "inconsistent coordinate / load dimension", 3: "unknown or invalid support type",
@@ -216,10 +300,10 @@ def _pack_json_native(count, call):
     return PackedBatch(xyz, conn, E, A, rho, cbits, loads, nJ, nM, dim, count_free(cbits, nJ))
 
 
-def pack_json_texts(texts):
+def pack_json_texts(texts, members="general"):
     """Reference-format JSON documents (`bytes` or `str`, one truss each) -> `PackedBatch` through the
     native bulk reader (`csrc/jsonpack.c`, OpenMP over the documents): no Python objects per joint or
-    member.  Same arrays as `pack_json([json.loads(t) for t in texts])`."""
+    member.  Same arrays as `pack_json([json.loads(t) for t in texts])`; `members` as there."""
     import ctypes
     from .generate import _load
     lib = _load()
@@ -228,11 +312,11 @@ def pack_json_texts(texts):
     arr = (ctypes.c_char_p * B)(*raw)
     lens = np.array([len(r) for r in raw], dtype=np.int64)
     lib.trs_json_pack.restype = ctypes.c_int
-    return _pack_json_native(B, lambda jm, mm, *rest: lib.trs_json_pack(
-        ctypes.c_int(B), arr, lens.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(jm), ctypes.c_int(mm), *rest))
+    return _member_form(_pack_json_native(B, lambda jm, mm, *rest: lib.trs_json_pack(
+        ctypes.c_int(B), arr, lens.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(jm), ctypes.c_int(mm), *rest)), members)
 
 
-def pack_json_files(paths):
+def pack_json_files(paths, members="general"):
     """Truss JSON FILES -> `PackedBatch`; the files are read (once) and parsed natively, in parallel
     (the bulk form of `Truss.LoadFromJSON`, reference `truss.py:401-421`)."""
     import ctypes
@@ -249,8 +333,9 @@ def pack_json_files(paths):
     try:
         if rc != 0:
             raise ValueError(f"truss JSON #{(-rc) // 1000 - 1}: {_JSON_ERRORS[6]}")
-        return _pack_json_native(B, lambda jm, mm, *rest: lib.trs_json_pack(
-            ctypes.c_int(B), bufs, lens.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(jm), ctypes.c_int(mm), *rest))
+        return _member_form(_pack_json_native(B, lambda jm, mm, *rest: lib.trs_json_pack(
+            ctypes.c_int(B), bufs, lens.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(jm), ctypes.c_int(mm), *rest)),
+                            members)
     finally:
         lib.trs_json_free_files(ctypes.c_int(B), bufs)
 
@@ -283,7 +368,10 @@ def _require_gpu(device):
 #:   fused_substitution  the wave that factors a narrow-envelope matrix substitutes it as well
 #:   recover_unstaged    force trs_recover's path for trusses whose tables exceed a CU's LDS
 #:   recover_scan        with recover_unstaged: also that path's fall-back without member-end lists (tests)
-DEFAULT_OPTIONS = {"compact": False, "fused_substitution": True, "recover_unstaged": False, "recover_scan": False}
+#:   all_wide            every matrix to the work-group factorisation (four waves per matrix), whatever its envelope:
+#:                       for batches of few, large systems, which leave most SIMDs idle under the wave-per-matrix kernel
+DEFAULT_OPTIONS = {"compact": False, "fused_substitution": True, "recover_unstaged": False, "recover_scan": False,
+                   "all_wide": False}
 
 
 def default_options():
@@ -336,6 +424,9 @@ def joint_order_device(torch, tensors, effort=2, apply=True, want_choice=False, 
     of an earlier call with the same shapes: its tensors are written again (no allocation)."""
     lib = _capi.load()
     xyz, conn, cbits, loads = (tensors[k].contiguous() for k in ("xyz", "conn", "cbits", "loads"))
+    # (uint16 end joints = the table member form: the _tab twin reads and writes them)
+    order_fn, what = (lib.trs_joint_order_tab, "trs_joint_order_tab") if conn.dtype == torch.uint16 \
+        else (lib.trs_joint_order, "trs_joint_order")
     dev = xyz.device
     B, nJ_max, nM_max = int(xyz.shape[0]), int(xyz.shape[1]), int(conn.shape[1])
     if out is None:
@@ -348,11 +439,11 @@ def joint_order_device(torch, tensors, effort=2, apply=True, want_choice=False, 
                        loads=torch.empty_like(loads))
     ptr = lambda k: out[k].data_ptr() if k in out else None
     with torch.cuda.device(dev):
-        _capi.check(lib.trs_joint_order(
+        _capi.check(order_fn(
             B, nJ_max, nM_max, xyz.data_ptr(), conn.data_ptr(), cbits.data_ptr(), loads.data_ptr(),
             tensors["nJ"].data_ptr(), tensors["nM"].data_ptr(), out["perm"].data_ptr(), ptr("choice"),
             out["reach"].data_ptr(), ptr("xyz"), ptr("conn"), ptr("cbits"), ptr("loads"), int(effort),
-            torch.cuda.current_stream(dev).cuda_stream), "trs_joint_order")
+            torch.cuda.current_stream(dev).cuda_stream), what)
     return out
 
 
@@ -363,6 +454,9 @@ class DeviceBatch:
     lives on one device; kernels run on the current stream of that device.
     """
     INPUT_FIELDS = ("xyz", "conn", "E", "A", "rho", "cbits", "loads", "nJ", "nM")
+    #: the inputs of a batch in the TABLE member form (`PackedBatch.table`): uint16 end joints, a uint8 type index per
+    #: member and - shared by the batch - the type table `types` [T, 3] = (a, e, density)
+    TABLE_FIELDS = ("xyz", "conn", "type_idx", "cbits", "loads", "nJ", "nM")
 
     def __init__(self, packed: PackedBatch, device=None, use_envelope=True, use_small=True, reorder=False,
                  options=None):
@@ -379,9 +473,15 @@ class DeviceBatch:
             plan = None   # the fused small-system kernel keeps its matrix in LDS: nothing to gain from an order
         perm, resident, ordered = None, packed, None
         if plan is not None and plan[0] != "device":
-            perm = joint_order(packed, plan[1])   # found once, on the host
-            resident = permute_joints(packed, perm)
-        tensors = {f: up(getattr(resident, f)) for f in self.INPUT_FIELDS}
+            perm = joint_order(packed.general(), plan[1])   # found once, on the host
+            resident = permute_joints(packed.general(), perm)
+            if packed.is_table:   # (members keep their order: the type indices stay, the end joints are renumbered)
+                import dataclasses
+                resident = dataclasses.replace(packed, xyz=resident.xyz, cbits=resident.cbits, loads=resident.loads,
+                                               conn=np.ascontiguousarray(resident.conn, dtype=np.uint16))
+        tensors = {f: up(getattr(resident, f)) for f in (self.TABLE_FIELDS if packed.is_table else self.INPUT_FIELDS)}
+        if packed.is_table:
+            tensors["types"] = up(np.asarray(packed.types, dtype=np.float64))
         if plan is not None and plan[0] == "device" and packed.B:
             # found, applied and priced on the GPU (trs_joint_order): no host pass over the batch
             ordered = joint_order_device(torch, tensors, effort=plan[1])
@@ -397,13 +497,14 @@ class DeviceBatch:
                 self.joint_out = ordered["perm"]
                 self.all_narrow = bool(int(ordered["reach"].max().item()) <= NARROW_MAX_BELOW)
             else:
-                self.all_narrow = bool(envelope_reach(resident).max() <= NARROW_MAX_BELOW)
+                self.all_narrow = bool(envelope_reach(resident.general()).max() <= NARROW_MAX_BELOW)
         elif ordered is not None:
             self.joint_out = ordered["perm"]
 
     @classmethod
     def from_device(cls, tensors, n_max, use_envelope=True, use_small=True, joint_out=None, all_narrow=False):
-        """A batch whose inputs already live on the device: `tensors` maps INPUT_FIELDS to contiguous
+        """A batch whose inputs already live on the device: `tensors` maps INPUT_FIELDS (or, table member form,
+        TABLE_FIELDS + "types") to contiguous
         device tensors of the padded shapes (see PackedBatch); `n_max` bounds the free DOFs per truss
         (host-known, it sizes the slab); `joint_out` (int32 [B, nJ_max] on the device, or None): the
         results of joint j go to row joint_out[b, j] (the joint order the caller applied to the inputs)."""
@@ -425,8 +526,12 @@ class DeviceBatch:
         self.torch, self.device = torch, dev
         self.lib = _capi.load()
         self.B, self.nJ_max, self.nM_max, self.n_max = B, nJ_max, nM_max, n_max
-        for f in self.INPUT_FIELDS:
-            setattr(self, f, tensors[f])
+        #: table member form: conn uint16, `type_idx` + `types` in place of E / A / rho (which are then None)
+        self.table = tensors.get("type_idx") is not None
+        for f in self.INPUT_FIELDS + ("type_idx", "types"):
+            setattr(self, f, tensors.get(f))
+        if self.table and (self.conn.dtype != torch.uint16 or self.type_idx.dtype != torch.uint8 or self.types is None):
+            raise ValueError("table member form: conn uint16 [B, nM_max, 2], type_idx uint8 [B, nM_max], types float64 [T, 3]")
         self.ld = self.lib.trs_slab_ld(self.n_max)
         self.rows = self.lib.trs_slab_rows(self.n_max)
         #: the whole batch goes through the fused small-system kernel (n_free <= 128, tables fit the LDS)
@@ -481,37 +586,51 @@ class DeviceBatch:
     def _env_ptr(self):
         return self.env.data_ptr() if self.env is not None else None
 
+    def _members(self, types=None):
+        """The three member arguments of a C call: (conn, E, A), or - table form - (conn16, type_idx, types)."""
+        if self.table:
+            return self.conn.data_ptr(), self.type_idx.data_ptr(), (self.types if types is None else types).data_ptr()
+        return self.conn.data_ptr(), self.E.data_ptr(), self.A.data_ptr()
+
+    def _fn(self, name):
+        """The entry point `name`, or its `_tab` twin for a batch in the table member form."""
+        return getattr(self.lib, name + "_tab" if self.table else name), name + ("_tab" if self.table else "")
+
     def dofmap(self):
         _capi.check(self.lib.trs_dofmap(self.B, self.nJ_max, self.cbits.data_ptr(), self.nJ.data_ptr(),
                                         self.free_index.data_ptr(), self.n_free.data_ptr(),
                                         self._stream()), "trs_dofmap")
 
     def _hints(self, substituted=False):
-        if not self.all_narrow or self.env is None:
+        if not self.all_narrow or self.env is None or self.options["all_wide"]:
             return 0
         # (whether THIS batch's last factorisation ran with the substitution fused in, not the option's value now)
         fused = substituted and self.rows <= 1024 and self._potrf_fused
         return HINT_NO_WIDE | (HINT_SUBSTITUTED if fused else 0)
 
     def _stage_hints(self):
-        return (HINT_COMPACT if self.options["compact"] and self.env is not None else 0) | \
+        return (HINT_COMPACT if self.options["compact"] and self.env is not None and not self.options["all_wide"] else 0) | \
                (0 if self.options["fused_substitution"] else HINT_SEPARATE_STAGES) | \
                (HINT_RECOVER_UNSTAGED if self.options["recover_unstaged"] else 0) | \
                (HINT_RECOVER_SCAN if self.options["recover_scan"] else 0)
 
     def assemble(self, flags=0):
-        if self.all_narrow and self.env is not None:
+        wide = self.options["all_wide"] and self.env is not None
+        if self.all_narrow and self.env is not None and not wide:
             flags |= ASM_ALL_NARROW
-        if self.options["compact"] and self.env is not None:
+        if self.options["compact"] and self.env is not None and not wide:
             flags |= ASM_COMPACT
+        if wide:
+            flags |= ASM_ALL_WIDE
         if self.all_tiles and self.env is not None:
             flags |= ASM_ALL_TILES
-        _capi.check(self.lib.trs_assemble(
-            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
-            self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
+        fn, what = self._fn("trs_assemble")
+        _capi.check(fn(
+            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), *self._members(),
+            self.loads.data_ptr(), self.free_index.data_ptr(),
             self.n_free.data_ptr(), self.nJ.data_ptr(), self.nM.data_ptr(), self.ld, self.rows,
             self.S.data_ptr(), flags, self.work.data_ptr(), self._env_ptr(), self.uf.data_ptr(), self.rows,
-            self._stream()), "trs_assemble")
+            self._stream()), what)
 
     def potrf(self):
         self._potrf_fused = bool(self.options["fused_substitution"])
@@ -528,33 +647,37 @@ class DeviceBatch:
                     "trs_potrs_batched")
 
     def recover(self):
-        _capi.check(self.lib.trs_recover(
-            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
-            self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
+        fn, what = self._fn("trs_recover")
+        _capi.check(fn(
+            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), *self._members(),
+            self.loads.data_ptr(), self.free_index.data_ptr(),
             self.nJ.data_ptr(), self.nM.data_ptr(), self.uf.data_ptr(), self.rows, self.u.data_ptr(),
             self.f_ext.data_ptr(), self.N.data_ptr(),
             self.joint_out.data_ptr() if self.joint_out is not None else None,
-            self._stage_hints() & (HINT_RECOVER_UNSTAGED | HINT_RECOVER_SCAN), self._stream()), "trs_recover")
+            self._stage_hints() & (HINT_RECOVER_UNSTAGED | HINT_RECOVER_SCAN), self._stream()), what)
 
     def recover_rows(self, rows, out, nJ_out_max, nM_out_max):
         """`trs_recover_rows`: the recovery with a ragged batch's bucket scatter folded in - the results of truss b go
         to row rows[b] (int64 device tensor) of `out["u"]`, `out["f_ext"]` [*, nJ_out_max, 3], `out["N"]`
         [*, nM_out_max] and `out["info"]`."""
-        _capi.check(self.lib.trs_recover_rows(
-            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), self.conn.data_ptr(),
-            self.E.data_ptr(), self.A.data_ptr(), self.loads.data_ptr(), self.free_index.data_ptr(),
+        fn, what = self._fn("trs_recover_rows")
+        _capi.check(fn(
+            self.B, self.nJ_max, self.nM_max, self.xyz.data_ptr(), *self._members(),
+            self.loads.data_ptr(), self.free_index.data_ptr(),
             self.nJ.data_ptr(), self.nM.data_ptr(), self.uf.data_ptr(), self.rows,
             self.joint_out.data_ptr() if self.joint_out is not None else None, self.info.data_ptr(),
             rows.data_ptr(), int(nJ_out_max), int(nM_out_max), out["u"].data_ptr(), out["f_ext"].data_ptr(),
             out["N"].data_ptr(), out["info"].data_ptr(), self._stage_hints() & (HINT_RECOVER_UNSTAGED | HINT_RECOVER_SCAN), self._stream()),
-            "trs_recover_rows")
+            what)
 
-    def solve_rows(self, rows, out, nJ_out_max, nM_out_max):
-        """`trs_solve_rows`: the staged pipeline in one C call with `recover_rows` as its last stage."""
+    def solve_rows(self, rows, out, nJ_out_max, nM_out_max, types=None):
+        """`trs_solve_rows`: the staged pipeline in one C call with `recover_rows` as its last stage.  `types` (table
+        member form only): another type table for this solve (e.g. every row the same fixed section)."""
+        fn, what = self._fn("trs_solve_rows")
         with self.torch.cuda.device(self.device):
-            _capi.check(self.lib.trs_solve_rows(
-                self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), self.conn.data_ptr(),
-                self.E.data_ptr(), self.A.data_ptr(), self.cbits.data_ptr(), self.loads.data_ptr(),
+            _capi.check(fn(
+                self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), *self._members(types),
+                self.cbits.data_ptr(), self.loads.data_ptr(),
                 self.nJ.data_ptr(), self.nM.data_ptr(), self.free_index.data_ptr(),
                 self.n_free.data_ptr(), self.ld, self.rows, self.S.data_ptr(), self.uf.data_ptr(),
                 self.rows, out["u"].data_ptr(), out["f_ext"].data_ptr(), out["N"].data_ptr(),
@@ -562,10 +685,10 @@ class DeviceBatch:
                 self.joint_out.data_ptr() if self.joint_out is not None else None, rows.data_ptr(),
                 int(nJ_out_max), int(nM_out_max), out["info"].data_ptr(),
                 (HINT_NO_WIDE if self.all_narrow and self.env is not None else 0) | self._stage_hints() |
-                (HINT_ALL_TILES if self.all_tiles and self.env is not None else 0),
-                self._stream()), "trs_solve_rows")
+                (HINT_ALL_TILES if self.all_tiles and self.env is not None else 0) | self._wide_hint(),
+                self._stream()), what)
 
-    def _solve_small(self, fitness=None, out=None):
+    def _solve_small(self, fitness=None, out=None, types=None):
         """`trs_solve_small`: the whole of `Truss.Solve()` in one kernel (optionally with the GA
         reductions); returns the three reduction tensors (`out`, three float64 [B] device tensors, or new ones) or
         None."""
@@ -575,15 +698,17 @@ class DeviceBatch:
         elif out is None:
             out = [t.empty([self.B], dtype=t.float64, device=self.device) for _ in range(3)]
         ptr = lambda x: None if x is None else x.data_ptr()
+        fn, what = self._fn("trs_solve_small")
+        # (general form: the densities of the fitness reductions are an argument; table form: they are in the table)
+        rho = () if self.table else (self.rho.data_ptr() if fitness is not None else None,)
         with t.cuda.device(self.device):
-            _capi.check(self.lib.trs_solve_small(
-                self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), self.conn.data_ptr(),
-                self.E.data_ptr(), self.A.data_ptr(), self.cbits.data_ptr(), self.loads.data_ptr(),
+            _capi.check(fn(
+                self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), *self._members(types),
+                self.cbits.data_ptr(), self.loads.data_ptr(),
                 self.nJ.data_ptr(), self.nM.data_ptr(), self.u.data_ptr(), self.f_ext.data_ptr(),
-                self.N.data_ptr(), self.info.data_ptr(), self.free_index.data_ptr(), self.n_free.data_ptr(),
-                self.rho.data_ptr() if fitness is not None else None,
+                self.N.data_ptr(), self.info.data_ptr(), self.free_index.data_ptr(), self.n_free.data_ptr(), *rho,
                 float(fitness[0]) if fitness else 0.0, float(fitness[1]) if fitness else 0.0,
-                ptr(out[0]), ptr(out[1]), ptr(out[2]), self._stream()), "trs_solve_small")
+                ptr(out[0]), ptr(out[1]), ptr(out[2]), self._stream()), what)
         return out if fitness is not None else None
 
     def solve_fitness(self, allow_stress, allow_displace, out=None):
@@ -598,20 +723,26 @@ class DeviceBatch:
     def set_sections_from_genes(self, genes, count, n_member, type_table):
         """`trs_ga_sections`: A, E, rho of the resident batch from a GA population's gene matrix (uint8 device tensor
         [count, n_member]) and its type table (float64 device tensor [n_type, 3] = a, e, density)."""
+        if self.table:
+            raise ValueError("set_sections_from_genes needs the general member form")
         _capi.check(self.lib.trs_ga_sections(self.B, self.nM_max, int(count), int(n_member), int(type_table.shape[0]),
                                              genes.data_ptr(), type_table.data_ptr(), self.A.data_ptr(),
                                              self.E.data_ptr(), self.rho.data_ptr(), self._stream()), "trs_ga_sections")
 
-    def solve(self):
+    def _wide_hint(self):
+        return HINT_ALL_WIDE if self.options["all_wide"] and self.env is not None else 0
+
+    def solve(self, types=None):
         """The whole pipeline, asynchronous on the current stream: one kernel for a batch of small
-        trusses (`trs_solve_small`), otherwise one C call that enqueues the five stages."""
+        trusses (`trs_solve_small`), otherwise one C call that enqueues the five stages.  `types` as `solve_rows`."""
         if self.small:
-            self._solve_small()
+            self._solve_small(types=types)
             return
+        fn, what = self._fn("trs_solve")
         with self.torch.cuda.device(self.device):
-            _capi.check(self.lib.trs_solve(
-                self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), self.conn.data_ptr(),
-                self.E.data_ptr(), self.A.data_ptr(), self.cbits.data_ptr(), self.loads.data_ptr(),
+            _capi.check(fn(
+                self.B, self.nJ_max, self.nM_max, self.n_max, self.xyz.data_ptr(), *self._members(types),
+                self.cbits.data_ptr(), self.loads.data_ptr(),
                 self.nJ.data_ptr(), self.nM.data_ptr(), self.free_index.data_ptr(),
                 self.n_free.data_ptr(), self.ld, self.rows, self.S.data_ptr(), self.uf.data_ptr(),
                 self.rows, self.u.data_ptr(), self.f_ext.data_ptr(), self.N.data_ptr(),
@@ -619,12 +750,14 @@ class DeviceBatch:
                 self.joint_out.data_ptr() if self.joint_out is not None else None,
                 # (not on the fused small path here, by shape or by request: the staged pipeline in any case)
                 (HINT_NO_WIDE if self.all_narrow and self.env is not None else 0) | self._stage_hints() | HINT_NO_SMALL |
-                (HINT_ALL_TILES if self.all_tiles and self.env is not None else 0),
-                self._stream()), "trs_solve")
+                (HINT_ALL_TILES if self.all_tiles and self.env is not None else 0) | self._wide_hint(),
+                self._stream()), what)
 
     def fitness(self, allow_stress, allow_displace, out=None):
         """(weight, stress_violation, displacement_violation) per truss, on device."""
         t = self.torch
+        if self.table:
+            raise ValueError("trs_fitness exists in the general member form only (the fused small-system kernel takes either)")
         if out is None:
             out = [t.empty([self.B], dtype=t.float64, device=self.device) for _ in range(3)]
         _capi.check(self.lib.trs_fitness(
@@ -644,17 +777,24 @@ class DeviceBatch:
         self.all_tiles = bool((self.env[:, off] == -1).all().item())
         return self.all_tiles
 
+    @property
+    def fields(self):
+        """Names of this batch's per-truss input tensors (its member form's)."""
+        return self.TABLE_FIELDS if self.table else self.INPUT_FIELDS
+
     def pinned_inputs(self, packed: PackedBatch):
-        """Page-locked host copies of a batch's inputs (same padded shapes as this device batch)."""
+        """Page-locked host copies of a batch's inputs (same padded shapes and member form as this device batch)."""
         t = self.torch
-        return {f: t.from_numpy(np.ascontiguousarray(getattr(packed, f))).pin_memory() for f in self.INPUT_FIELDS}
+        if packed.is_table != self.table:
+            raise ValueError("pinned_inputs: the batch's member form differs from the resident batch's")
+        return {f: t.from_numpy(np.ascontiguousarray(getattr(packed, f))).pin_memory() for f in self.fields}
 
     def upload(self, host_inputs):
         """Replace the resident inputs by another batch of the same padded shapes (asynchronous on
         the current stream when `host_inputs` come from `pinned_inputs`)."""
         self.all_narrow = False   # another topology: the host's knowledge of the envelopes is gone
         self.all_tiles = False
-        for f in self.INPUT_FIELDS:
+        for f in self.fields:
             getattr(self, f).copy_(host_inputs[f], non_blocking=True)
 
     def download(self, out=None):
@@ -669,6 +809,8 @@ class DeviceBatch:
 
     def set_sections(self, A, E, rho):
         """Replace the member sections (host arrays [B,nM_max]); geometry stays resident."""
+        if self.table:
+            raise ValueError("set_sections: a batch in the table member form changes its sections through `types` / `type_idx`")
         for dst, src in ((self.A, A), (self.E, E), (self.rho, rho)):
             dst.copy_(self.torch.from_numpy(np.ascontiguousarray(src, dtype=np.float64)))
 
@@ -847,9 +989,10 @@ NARROW_MAX_BELOW = 24   # csrc/trs_common.h TRS_NARROW_MAX_BELOW: reach up to wh
 # include/trs_solver.h
 HINT_NO_WIDE, HINT_SUBSTITUTED, HINT_COMPACT, HINT_SEPARATE_STAGES, HINT_NO_SMALL, HINT_RECOVER_UNSTAGED = 1, 2, 4, 8, 16, 32
 HINT_RECOVER_SCAN = 128
+HINT_ALL_WIDE = 256
 HINT_ALL_TILES = 64
 ORDER_RCM_BELOW = 128           # csrc/order.hip RCM_BELOW: effort 3 prices Cuthill-McKee below this many free joints
-ASM_FULL_SYMMETRIC, ASM_COMPACT, ASM_ALL_NARROW, ASM_ALL_TILES = 1, 2, 4, 8
+ASM_FULL_SYMMETRIC, ASM_COMPACT, ASM_ALL_NARROW, ASM_ALL_TILES, ASM_ALL_WIDE = 1, 2, 4, 8, 16
 
 
 def envelope_reach(packed: PackedBatch, perm=None):
@@ -1252,6 +1395,7 @@ class RaggedSolver:
     `result()` downloads them.  `reorder` as `order_plan`; a host-side plan is carried out once, at set-up."""
 
     GATHER = ("xyz", "conn", "E", "A", "cbits", "loads", "nJ", "nM")
+    GATHER_TABLE = ("xyz", "conn", "type_idx", "cbits", "loads", "nJ", "nM")   # table member form (`PackedBatch.table`)
     JOINT_ORDERED = ("xyz", "conn", "cbits", "loads")
 
     def __init__(self, packed, device=None, reorder=True, max_slab_bytes=None, granularity=64,
@@ -1287,16 +1431,27 @@ class RaggedSolver:
         self.B = B
         self.host_io = host_io is not None
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        #: table member form (uint16 end joints, a uint8 type index per member, one type table for the batch): the
+        #: batch's own form - a `PackedBatch.table()`, host_io inputs or device tensors that carry `type_idx`
+        source = host_io[0] if self.host_io else tensors
+        self.table = (source.get("type_idx") is not None) if source is not None else bool(getattr(packed, "is_table", False))
+        gather = self.GATHER_TABLE if self.table else self.GATHER
+        self.types = None
+        if self.table:
+            types = source.get("types") if source is not None and source.get("types") is not None else getattr(packed, "types", None)
+            if types is None:
+                raise ValueError("table member form: the type table `types` [T, 3] is missing")
+            self.types = (types if torch.is_tensor(types) else torch.from_numpy(np.ascontiguousarray(types, dtype=np.float64))).to(dev)
         if self.host_io:
             # (the sizes nJ / nM come from `packed` and go up once, with the bucket index lists: they tell the copy
             # kernels how much of a row is live, so that nothing but live bytes crosses the link)
-            self.gather_fields = tuple(f for f in self.GATHER if f not in ("nJ", "nM"))
+            self.gather_fields = tuple(f for f in gather if f not in ("nJ", "nM"))
             self.inputs = {f: host_io[0][f] for f in self.gather_fields}
             if not all(t.is_pinned() and t.is_contiguous() for t in self.inputs.values()):
                 raise ValueError("host_io inputs must be contiguous page-locked tensors (PackedBatch.pinned())")
         else:
-            self.gather_fields = self.GATHER
-            self.inputs = {f: (tensors[f].contiguous() if tensors is not None else up(getattr(packed, f))) for f in self.GATHER}
+            self.gather_fields = gather
+            self.inputs = {f: (tensors[f].contiguous() if tensors is not None else up(getattr(packed, f))) for f in gather}
         plan = order_plan(reorder, nJ_max, nM_max) if B else None
         self.plan = plan
         # A batch whose LARGEST truss does not fit `trs_joint_order` gets a host plan - but its buckets are ordered
@@ -1308,10 +1463,12 @@ class RaggedSolver:
         self.ordered = None        # host plan: renumbered xyz / conn / cbits / loads + perm of the FULL batch
         if plan is not None and plan[0] != "device":
             # (found for the whole batch: the buckets that do not fit the device kernel take their rows from it)
-            host = packed if isinstance(packed, PackedBatch) else packed.to_packed(tensors)
+            host = (packed if isinstance(packed, PackedBatch) else packed.to_packed(tensors)).general()
             perm = joint_order(host, plan[1])
             renum = permute_joints(host, perm)
             self.ordered = {k: up(getattr(renum, k)) for k in self.JOINT_ORDERED}
+            if self.table:
+                self.ordered["conn"] = up(np.ascontiguousarray(renum.conn, dtype=np.uint16))
             self.ordered["perm"] = up(perm)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # padding beyond a bucket's width stays 0
         if self.host_io:
@@ -1356,12 +1513,14 @@ class RaggedSolver:
             nJ_b, nM_b = max(1, int(packed.nJ[idx].max())), max(1, int(packed.nM[idx].max()))
             n_b, Bb = int(packed.n_free[idx].max()), len(idx)
             sub = {"xyz": e([Bb, nJ_b, 3], torch.float64), "loads": e([Bb, nJ_b, 3], torch.float64),
-                   "cbits": e([Bb, nJ_b], torch.uint8), "conn": e([Bb, nM_b, 2], torch.int32),
-                   "E": e([Bb, nM_b], torch.float64), "A": e([Bb, nM_b], torch.float64),
-                   "nJ": e([Bb], torch.int32), "nM": e([Bb], torch.int32)}
+                   "cbits": e([Bb, nJ_b], torch.uint8), "nJ": e([Bb], torch.int32), "nM": e([Bb], torch.int32)}
+            if self.table:
+                sub.update(conn=e([Bb, nM_b, 2], torch.uint16), type_idx=e([Bb, nM_b], torch.uint8), types=self.types)
+            else:
+                sub.update(conn=e([Bb, nM_b, 2], torch.int32), E=e([Bb, nM_b], torch.float64), A=e([Bb, nM_b], torch.float64))
+                sub["rho"] = sub["A"]   # placeholder of the right shape: no kernel of the solve reads the densities
             if self.host_io:
                 sub["nJ"], sub["nM"] = up(packed.nJ[idx].astype(np.int32)), up(packed.nM[idx].astype(np.int32))
-            sub["rho"] = sub["A"]   # placeholder of the right shape: no kernel of the solve reads the densities
             small = bool(self.lib.trs_solve_small_fits(nJ_b, nM_b, n_b))
             renumbered = plan is not None and not small   # the fused small-system kernel gains nothing from an order
             jout = e([Bb, nJ_b], torch.int32) if renumbered else None
@@ -1442,14 +1601,17 @@ class RaggedSolver:
                 if "raw" not in bk:
                     nJ_b, nM_b = db.nJ_max, db.nM_max
                     bk["raw"] = {"xyz": e([Bb, nJ_b, 3], torch.float64), "loads": e([Bb, nJ_b, 3], torch.float64),
-                                 "cbits": e([Bb, nJ_b], torch.uint8), "conn": e([Bb, nM_b, 2], torch.int32),
+                                 "cbits": e([Bb, nJ_b], torch.uint8),
+                                 "conn": e([Bb, nM_b, 2], torch.uint16 if self.table else torch.int32),
                                  "nJ": db.nJ, "nM": db.nM}
             elif bk["order_on_device"]:
                 nJ_b, nM_b = db.nJ_max, db.nM_max
                 bk["raw"] = {"xyz": raw["xyz"][:Bb * nJ_b * 3].view(Bb, nJ_b, 3),
                              "loads": raw["loads"][:Bb * nJ_b * 3].view(Bb, nJ_b, 3),
                              "cbits": raw["cbits"][:Bb * nJ_b].view(Bb, nJ_b),
-                             "conn": raw["conn"][:Bb * nM_b * 2].view(Bb, nM_b, 2), "nJ": db.nJ, "nM": db.nM}
+                             "conn": (raw["conn"][:Bb * nM_b * 2].view(Bb, nM_b, 2) if not self.table else
+                                      raw["conn"][:Bb * nM_b].view(torch.uint16).view(Bb, nM_b, 2)),
+                             "nJ": db.nJ, "nM": db.nM}
             if bk["order_on_device"]:
                 # trs_joint_order writes the renumbered bucket straight into the solver's input tensors
                 bk["ordered"] = {"perm": db.joint_out, "reach": bk["reach"], "xyz": db.xyz, "conn": db.conn,
@@ -1479,7 +1641,7 @@ class RaggedSolver:
                     for o in self.outs]
             # host-fed: only the live part of a row crosses the link - (count array, bytes per element) by field
             per_joint = {"xyz": 24, "loads": 24, "cbits": 1, "u": 24, "f_ext": 24}
-            per_member = {"conn": 8, "E": 8, "A": 8, "N": 8}
+            per_member = {"conn": 4 if self.table else 8, "E": 8, "A": 8, "type_idx": 1, "N": 8}
 
             def pack(pairs, trimmed_is_dst):
                 n = len(pairs)
@@ -1603,32 +1765,50 @@ class RaggedSolver:
                 stream = lanes[bk["lane"]].cuda_stream
                 if bk["fused_io"]:
                     db, inp, ordr = bk["dev"], self.inputs, bk["ordered"]
-                    timed("order", lambda: _capi.check(self.lib.trs_joint_order_rows(
+                    if self.table:
+                        sec_in, sec_out = (inp["type_idx"].data_ptr(),), (db.type_idx.data_ptr(),)
+                        order_rows, what = self.lib.trs_joint_order_rows_tab, "trs_joint_order_rows_tab"
+                    else:
+                        sec_in, sec_out = (inp["E"].data_ptr(), inp["A"].data_ptr()), (db.E.data_ptr(), db.A.data_ptr())
+                        order_rows, what = self.lib.trs_joint_order_rows, "trs_joint_order_rows"
+                    timed("order", lambda: _capi.check(order_rows(
                         bk["count"], db.nJ_max, db.nM_max, bk["rows"].data_ptr(), int(inp["xyz"].shape[1]),
                         int(inp["conn"].shape[1]), inp["xyz"].data_ptr(), inp["conn"].data_ptr(),
-                        inp["cbits"].data_ptr(), inp["loads"].data_ptr(), inp["E"].data_ptr(), inp["A"].data_ptr(),
+                        inp["cbits"].data_ptr(), inp["loads"].data_ptr(), *sec_in,
                         inp["nJ"].data_ptr(), inp["nM"].data_ptr(), ordr["perm"].data_ptr(), ordr["reach"].data_ptr(),
                         db.xyz.data_ptr(), db.conn.data_ptr(), db.cbits.data_ptr(), db.loads.data_ptr(),
-                        db.E.data_ptr(), db.A.data_ptr(), db.nJ.data_ptr(), db.nM.data_ptr(),
-                        int(self.device_effort), stream), "trs_joint_order_rows"))
+                        *sec_out, db.nJ.data_ptr(), db.nM.data_ptr(),
+                        int(self.device_effort), stream), what))
                     for slot in slots:
-                        if sections[slot] is not None:
-                            db.A.fill_(float(sections[slot][0]))
-                            db.E.fill_(float(sections[slot][1]))
-
-                        timed("solve", lambda: db.solve_rows(bk["rows"], self.outs[slot], nJ_full, nM_full))
+                        types = self._section_types(db, sections[slot])
+                        timed("solve", lambda: db.solve_rows(bk["rows"], self.outs[slot], nJ_full, nM_full, types=types))
                     continue
                 timed("gather", lambda: _capi.check(self.lib.trs_copy_rows(
                     *gather, bk["count"], bk["rows"].data_ptr(), 0, 0, stream), "trs_copy_rows (gather)"))
                 if bk["order_on_device"]:
                     timed("order", lambda: joint_order_device(torch, bk["raw"], effort=self.device_effort, out=bk["ordered"]))
                 for slot in slots:
-                    if sections[slot] is not None:
-                        bk["dev"].A.fill_(float(sections[slot][0]))
-                        bk["dev"].E.fill_(float(sections[slot][1]))
-                    timed("solve", bk["dev"].solve)
+                    types = self._section_types(bk["dev"], sections[slot])
+                    timed("solve", lambda: bk["dev"].solve(types=types))
                     timed("scatter", lambda: _capi.check(self.lib.trs_copy_rows(
                         *scatters[slot], bk["count"], bk["rows"].data_ptr(), 1, 0, stream), "trs_copy_rows (scatter)"))
+
+    def _section_types(self, db, section):
+        """A section variant of a step (`section` = None: the members' own, or (a, e, density) for every member): the
+        general form overwrites the bucket's A and E, the table form solves with another type table - every row the
+        fixed triple - and leaves the bucket's type indices alone.  Returns the table to pass on, or None."""
+        if section is None:
+            return None
+        if not db.table:
+            db.A.fill_(float(section[0]))
+            db.E.fill_(float(section[1]))
+            return None
+        key = tuple(float(v) for v in section[:3]) + (0.0,) * (3 - len(section[:3]))
+        cache = self.__dict__.setdefault("_fixed_types", {})
+        if key not in cache:
+            row = self.torch.tensor(key, dtype=self.torch.float64, device=self.device)
+            cache[key] = row.expand(max(1, int(self.types.shape[0])), 3).contiguous()
+        return cache[key]
 
     def _marked(self, stream):
         ev = self.torch.cuda.Event(enable_timing=True)
@@ -1820,7 +2000,9 @@ def solve_batch_streamed(packed: PackedBatch, device=None, reorder=True, pool=No
                            np.zeros([0], dtype=np.int32))
     pool = pool if pool is not None else ResultPool()
     host_out = host_result_arrays(torch, pool, B, nJ_max, nM_max, dev)
-    host_in = {f: torch.from_numpy(getattr(packed, f)) for f in RaggedSolver.GATHER}
+    host_in = {f: torch.from_numpy(getattr(packed, f)) for f in (RaggedSolver.GATHER_TABLE if packed.is_table else RaggedSolver.GATHER)}
+    if packed.is_table:   # (5 instead of 24 bytes per member cross the link: conn uint16 + one type index)
+        host_in["types"] = torch.from_numpy(np.ascontiguousarray(packed.types, dtype=np.float64))
     solver = RaggedSolver(packed, dev, reorder=reorder, max_slab_bytes=max_slab_bytes, host_io=(host_in, host_out))
     solver.step()
     return solver.result()
@@ -1831,7 +2013,7 @@ def _is_pinned(packed):
     import torch
     try:
         return all(getattr(packed, f).flags["C_CONTIGUOUS"] and torch.from_numpy(getattr(packed, f)).is_pinned()
-                   for f in RaggedSolver.GATHER)
+                   for f in (RaggedSolver.GATHER_TABLE if packed.is_table else RaggedSolver.GATHER))
     except (RuntimeError, TypeError, ValueError):
         return False
 
@@ -1875,6 +2057,25 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     torch, dev = _require_gpu(device if device_inputs is None else device_inputs["xyz"].device)
     B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
     variants = [None] if sections is None else list(sections)
+    if isinstance(packed, PackedBatch) and packed.is_table:
+        if on_device or device_inputs is not None:
+            packed = packed.general()   # (device-side consumers - graph features, fitness - read the general form)
+        elif not (pool is not None and B >= STREAMED_FROM and sections is None and options is None and _is_pinned(packed)
+                  and not _capi.load().trs_solve_small_fits(nJ_max, nM_max, packed.n_max)):
+            # the table member form goes through the resident bucket pipeline as it is: 5 bytes per member up,
+            # every kernel reads the table (same bits as the general form)
+            if B == 0:
+                empty = BatchResult(np.zeros([0, nJ_max, 3]), np.zeros([0, nJ_max, 3]), np.zeros([0, nM_max]),
+                                    np.zeros([0], dtype=np.int32))
+                return empty if sections is None else [empty for _ in variants]
+            solver = RaggedSolver(packed, dev, reorder=reorder if reorder is not False else None,
+                                  max_slab_bytes=None if max_slab_bytes >= 64 << 30 else max_slab_bytes,
+                                  options=options, n_variants=len(variants))
+            solver.step(sections=variants)
+            torch.cuda.synchronize(dev)
+            results = [BatchResult(o["u"].cpu().numpy(), o["f_ext"].cpu().numpy(), o["N"].cpu().numpy(),
+                                   o["info"].cpu().numpy()) for o in solver.outs]
+            return results[0] if sections is None else results
     if (pool is not None and B >= STREAMED_FROM and sections is None and not on_device and device_inputs is None
             and isinstance(packed, PackedBatch) and options is None and _is_pinned(packed)
             and not _capi.load().trs_solve_small_fits(nJ_max, nM_max, packed.n_max)):

@@ -73,8 +73,7 @@ __host__ __device__ inline size_t asm_compact_tab_bytes(int n_pad_max) {
 //      more than ~7000 members; the tables then live in L2 / HBM and the kernel is slower)
 template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void trs_assemble_kernel(
-    const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
-    const double* __restrict__ A, const double* __restrict__ loads,
+    const double* __restrict__ xyz, const TrsMembers mem, const double* __restrict__ loads,
     const int* __restrict__ free_index, const int* __restrict__ n_free, const int* __restrict__ nJ_arr,
     const int* __restrict__ nM_arr, const int nJ_max, const int nM_max, const int n_pad_max,
     const int ld, const size_t slab_stride, double* __restrict__ S_all, const int flags,
@@ -131,8 +130,9 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     for (int r = 0; r < MR; ++r) {
         const int m = tid + r * NT;
         const size_t mm = (size_t)b * nM_max + (m < nM ? m : 0);
-        cj0[r] = m < nM ? conn[2 * mm] : 0;
-        cj1[r] = m < nM ? conn[2 * mm + 1] : 0;
+        const int2 c = mem.ends(mm);
+        cj0[r] = m < nM ? c.x : 0;
+        cj1[r] = m < nM ? c.y : 0;
     }
     auto for_members = [&](auto&& body) {  // body(m, j0, j1) for this thread's members
 #pragma unroll
@@ -142,7 +142,8 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         }
         for (int m = tid + MR * NT; m < nM; m += NT) {
             const size_t mm = (size_t)b * nM_max + m;
-            body(m, conn[2 * mm], conn[2 * mm + 1]);
+            const int2 c = mem.ends(mm);
+            body(m, c.x, c.y);
         }
     };
     const double* X = xyz + (size_t)b * 3 * nJ_max;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             len2 += d[a] * d[a];
         }
         const double len = sqrt(len2);
-        mk[m] = E[mm] * A[mm] / len;                             // truss.py:56-58
+        mk[m] = mem.EA(mm) / len;                                // truss.py:56-58
 #pragma unroll
         for (int a = 0; a < 3; ++a) mc[3 * m + a] = d[a] / len;  // truss.py:60-63
         atomicAdd(&cnt[j0], 1);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) widest = max(widest, __shfl_xor(widest, off));
             // which factorisation kernel will take this matrix decides the shape of the stored part
-            const bool narrow = widest <= TRS_NARROW_MAX_BELOW || (flags & TRS_ASM_ALL_NARROW) != 0;
+            const bool narrow = (widest <= TRS_NARROW_MAX_BELOW || (flags & TRS_ASM_ALL_NARROW) != 0) && (flags & TRS_ASM_ALL_WIDE) == 0;
             // narrow envelopes leave as compact entry lists (phase 1c) when the caller asked for them
             // (TRS_ASM_COMPACT) and the lists can be held: the tables fit next to this batch's other tables,
             // and the envelope is narrow by its own reach - a matrix only FORCED narrow (TRS_ASM_ALL_NARROW)
@@ -719,8 +720,8 @@ extern "C" size_t trs_assemble_work_bytes(int nJ_max, int nM_max, int n_max) {
     return asm_plan(nJ_max, nM_max, trs_round_up(n_max < 1 ? 1 : n_max, TRS_NB)).work;
 }
 
-extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
-                                   const double* E, const double* A, const double* loads,
+extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* xyz, const TrsMembers* members,
+                                   const double* loads,
                                    const int* free_index, const int* n_free, const int* nJ,
                                    const int* nM, int ld, size_t slab_stride, int n_pad_max,
                                    double* S, int flags, void* work, int* env, double* uf, int ld_uf,
@@ -740,7 +741,7 @@ extern "C" int trs_assemble_launch(int B, int nJ_max, int nM_max, const double* 
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                     \
         (void)lds_limit_set;                                                                             \
         hipLaunchKernelGGL((trs_assemble_kernel<MODE, NTV>), dim3(B), dim3(NTV), plan.lds, stream, xyz,  \
-                           conn, E, A, loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max, ld, \
+                           *members, loads, free_index, n_free, nJ, nM, nJ_max, nM_max, n_pad_max, ld,   \
                            slab_stride, S, flags, static_cast<unsigned char*>(work), plan.work, env,     \
                            plan.WT, uf, ld_uf, plan.ck_off, compact_ok, plan.WTn);                                 \
     } while (0)

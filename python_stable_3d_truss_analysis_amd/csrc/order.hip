@@ -372,16 +372,19 @@ __device__ void price_order_pair(const Tables& t, int nf, Fwd fwd, unsigned shor
 }
 
 __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
-    const double* __restrict__ xyz, const int* __restrict__ conn, const unsigned char* __restrict__ cbits,
+    const double* __restrict__ xyz, const void* __restrict__ conn, const unsigned char* __restrict__ cbits,
     const double* __restrict__ loads, const int* __restrict__ nJ_arr, const int* __restrict__ nM_arr,
     const int nJ_max, const int nM_max, int* __restrict__ perm_out, int* __restrict__ choice_out,
-    int* __restrict__ reach_out, double* __restrict__ xyz_out, int* __restrict__ conn_out,
+    int* __restrict__ reach_out, double* __restrict__ xyz_out, void* __restrict__ conn_out,
     unsigned char* __restrict__ cbits_out, double* __restrict__ loads_out, const int effort,
     // gather form (trs_joint_order_rows; all null / 0 otherwise): truss b of this launch is row rows[b] of the INPUT
     // arrays, whose rows are nJ_in / nM_in wide; its member sections and counts are copied along
     const long long* __restrict__ rows, const int nJ_in, const int nM_in, const double* __restrict__ E_in,
     const double* __restrict__ A_in, double* __restrict__ E_out, double* __restrict__ A_out,
-    int* __restrict__ nJ_out, int* __restrict__ nM_out) {
+    int* __restrict__ nJ_out, int* __restrict__ nM_out,
+    // table member form (ABI 10; trs_common.h TrsMembers): conn / conn_out are uint16 pairs, and the gather form
+    // copies one type index per member (tidx_in -> tidx_out) instead of E and A
+    const int conn16, const unsigned char* __restrict__ tidx_in, unsigned char* __restrict__ tidx_out) {
     extern __shared__ unsigned char lds[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -414,7 +417,6 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     t.red = reinterpret_cast<unsigned long long*>(lds + lay.red);
 
     const unsigned char* CB = cbits + src * nJ_src;
-    const int* CN = conn + src * 2 * nM_src;
     const double* X = xyz + src * 3 * nJ_src;
     int* P = perm_out + (size_t)b * nJ_max;
 
@@ -426,18 +428,25 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
     double* Xs = reinterpret_cast<double*>(lds + lay.keys);  // [3 nJ_max] staged coordinates, in the shared region (dead before the fill)
     constexpr int MR = 2048 / NT;   // a thread's first members stay in registers (2048 members without a second read)
     int2 cr[MR];
-    const int2* CNI = reinterpret_cast<const int2*>(CN);
+    const size_t mrow = src * (size_t)nM_src;   // first member of the truss in the input arrays
+    auto CNI = [&](int m) {
+        if (conn16) {
+            const ushort2 c = reinterpret_cast<const ushort2*>(conn)[mrow + m];
+            return int2{(int)c.x, (int)c.y};
+        }
+        return reinterpret_cast<const int2*>(conn)[mrow + m];
+    };
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         const int m = tid + r * NT;
-        cr[r] = m < nm ? CNI[m] : int2{0, 0};
+        cr[r] = m < nm ? CNI(m) : int2{0, 0};
     }
     auto for_members = [&](auto&& body) {  // body(a, c) for every member of this thread
 #pragma unroll
         for (int r = 0; r < MR; ++r)
             if (tid + r * NT < nm) body(cr[r].x, cr[r].y);
         for (int m = tid + MR * NT; m < nm; m += NT) {
-            const int2 c = CNI[m];
+            const int2 c = CNI(m);
             body(c.x, c.y);
         }
     };
@@ -878,25 +887,31 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
             FO[3 * k] = f0; FO[3 * k + 1] = f1; FO[3 * k + 2] = f2;
             CO[k] = cb;
         }
-        int2* CNO = reinterpret_cast<int2*>(conn_out + (size_t)b * 2 * nM_max);
         for (int m = tid; m < nM_max; m += NT) {
             int2 c = {0, 0};
             if (m < nm) {
-                c = CNI[m];
+                c = CNI(m);
                 c.x = inverse[c.x];
                 c.y = inverse[c.y];
             }
-            CNO[m] = c;
+            if (conn16) reinterpret_cast<ushort2*>(conn_out)[(size_t)b * nM_max + m] = ushort2{(unsigned short)c.x, (unsigned short)c.y};
+            else reinterpret_cast<int2*>(conn_out)[(size_t)b * nM_max + m] = c;
         }
     }
     if (rows != nullptr) {  // gather form: the member sections and the counts travel with the truss
-        const double* EI = E_in + src * nM_src;
-        const double* AI = A_in + src * nM_src;
-        double* EO = E_out + (size_t)b * nM_max;
-        double* AO = A_out + (size_t)b * nM_max;
-        for (int m = tid; m < nM_max; m += NT) {
-            EO[m] = m < nm ? EI[m] : 0.0;
-            AO[m] = m < nm ? AI[m] : 0.0;
+        if (tidx_in != nullptr) {
+            const unsigned char* TI = tidx_in + src * nM_src;
+            unsigned char* TO = tidx_out + (size_t)b * nM_max;
+            for (int m = tid; m < nM_max; m += NT) TO[m] = m < nm ? TI[m] : (unsigned char)0;
+        } else {
+            const double* EI = E_in + src * nM_src;
+            const double* AI = A_in + src * nM_src;
+            double* EO = E_out + (size_t)b * nM_max;
+            double* AO = A_out + (size_t)b * nM_max;
+            for (int m = tid; m < nM_max; m += NT) {
+                EO[m] = m < nm ? EI[m] : 0.0;
+                AO[m] = m < nm ? AI[m] : 0.0;
+            }
         }
         if (tid == 0) {
             nJ_out[b] = nj;
@@ -925,12 +940,13 @@ extern "C" int trs_joint_order_fits(int nJ_max, int nM_max) {
     return ord_layout(nJ_max, nM_max).total <= 160 * 1024 ? 1 : 0;
 }
 
-extern "C" int trs_joint_order_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
+extern "C" int trs_joint_order_launch(int B, int nJ_max, int nM_max, const double* xyz, const void* conn,
                                       const unsigned char* cbits, const double* loads, const int* nJ, const int* nM,
-                                      int* perm, int* choice, int* reach, double* xyz_out, int* conn_out,
+                                      int* perm, int* choice, int* reach, double* xyz_out, void* conn_out,
                                       unsigned char* cbits_out, double* loads_out, int effort, hipStream_t stream,
                                       const long long* rows, int nJ_in, int nM_in, const double* E_in,
-                                      const double* A_in, double* E_out, double* A_out, int* nJ_out, int* nM_out) {
+                                      const double* A_in, double* E_out, double* A_out, int* nJ_out, int* nM_out,
+                                      int conn16, const unsigned char* tidx_in, unsigned char* tidx_out) {
     if (B <= 0) return 0;
     if (!trs_joint_order_fits(nJ_max, nM_max)) return (int)hipErrorInvalidValue;
     const size_t lds = ord_layout(nJ_max, nM_max).total
@@ -945,6 +961,6 @@ extern "C" int trs_joint_order_launch(int B, int nJ_max, int nM_max, const doubl
     }
     hipLaunchKernelGGL(trs_joint_order_kernel, dim3(B), dim3(NT), lds, stream, xyz, conn, cbits, loads, nJ, nM, nJ_max,
                        nM_max, perm, choice, reach, xyz_out, conn_out, cbits_out, loads_out, effort, rows, nJ_in, nM_in,
-                       E_in, A_in, E_out, A_out, nJ_out, nM_out);
+                       E_in, A_in, E_out, A_out, nJ_out, nM_out, conn16, tidx_in, tidx_out);
     return (int)hipGetLastError();
 }

@@ -49,9 +49,8 @@ __device__ __forceinline__ void add_end_force(double (&r)[3], const double (&c)[
 // Reaction at one constrained joint from its list of member ends ((member << 1) | end): the list is sorted by
 // member id in place (insertion sort: the lists are short) and summed in that order.
 template <class ListPtr>
-__device__ __forceinline__ void joint_reaction(ListPtr list, const int deg, const int2* __restrict__ CNI,
-                                               const double* __restrict__ X, const double* __restrict__ E,
-                                               const double* __restrict__ A, const size_t mbase, const double* u,
+__device__ __forceinline__ void joint_reaction(ListPtr list, const int deg, const TrsMembers& mem,
+                                               const double* __restrict__ X, const size_t mbase, const double* u,
                                                const int* jo, double (&r)[3]) {
     for (int i = 1; i < deg; ++i) {
         const int key = list[i];
@@ -65,9 +64,9 @@ __device__ __forceinline__ void joint_reaction(ListPtr list, const int deg, cons
     r[0] = r[1] = r[2] = 0.0;
     for (int i = 0; i < deg; ++i) {
         const int m = list[i] >> 1, end = list[i] & 1;
-        const int2 c = CNI[m];
+        const int2 c = mem.ends(mbase + m);
         const MemberGeom g = member_geom(X, c.x, c.y);
-        const double axial = member_axial(g, E[mbase + m] * A[mbase + m], u, jo ? jo[c.x] : c.x, jo ? jo[c.y] : c.y);
+        const double axial = member_axial(g, mem.EA(mbase + m), u, jo ? jo[c.x] : c.x, jo ? jo[c.y] : c.y);
         add_end_force(r, g.c, axial, end);
     }
 }
@@ -89,8 +88,7 @@ __device__ __forceinline__ void joint_reaction(ListPtr list, const int deg, cons
 // members in id order.  No floating-point atomics anywhere.
 template <bool STAGED>
 __global__ __launch_bounds__(256) void trs_recover_kernel(
-    const double* __restrict__ xyz, const int* __restrict__ conn, const double* __restrict__ E,
-    const double* __restrict__ A, const double* __restrict__ loads,
+    const double* __restrict__ xyz, const TrsMembers mem, const double* __restrict__ loads,
     const int* __restrict__ free_index, const int* __restrict__ nJ, const int* __restrict__ nM,
     const int nJ_max, const int nM_max, const double* __restrict__ uf, const int ld_uf,
     double* __restrict__ u_out, double* __restrict__ f_out, double* __restrict__ N_out,
@@ -129,11 +127,12 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     // eight trusses per CU the first pass's lines are long gone from L2 (a third of this kernel's excess traffic).
     constexpr int MR = 4;
     int2 cjr[MR];
-    const int2* CNI = reinterpret_cast<const int2*>(conn + (size_t)b * 2 * nM_max);
+    const size_t mbase = (size_t)b * nM_max;
+    auto CNI = [&](int m) { return mem.ends(mbase + m); };
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         const int m = tid + 256 * r;
-        cjr[r] = m < members ? CNI[m] : int2{0, 0};
+        cjr[r] = m < members ? CNI(m) : int2{0, 0};
     }
     // joint_out (optional): results of joint j go to row joint_out[b][j] of u / f_ext - a batch whose joints
     // were renumbered for a narrower envelope delivers its results in the caller's numbering at no cost.
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
     auto slot_get = [&](int j, int k) { return __hip_atomic_load(slot(j) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto slot_set = [&](int j, int k, int v) { __hip_atomic_store(slot(j) + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto ends_of = [&](int r, int m) {   // end joints of member m = tid + 256 r of this thread
-        int2 c = CNI[m < members ? m : 0];
+        int2 c = CNI(m < members ? m : 0);
 #pragma unroll
         for (int q = 0; q < MR; ++q)
             if (r == q) c = cjr[q];
@@ -178,10 +177,10 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         const size_t mm = (size_t)b * nM_max + m;
         double axial = 0.0;
         if (m < members) {
-            const int2 c = r < MR ? ends_of(r, m) : CNI[m];
+            const int2 c = r < MR ? ends_of(r, m) : CNI(m);
             const int j0 = c.x, j1 = c.y;
             const MemberGeom g = member_geom(X, j0, j1);
-            axial = member_axial(g, E[mm] * A[mm], u, J(j0), J(j1));
+            axial = member_axial(g, mem.EA(mm), u, J(j0), J(j1));
             if constexpr (STAGED) {
                 if (constrained(j0)) atomicAdd(&cnt[j0], 1);
                 if (constrained(j1)) atomicAdd(&cnt[j1], 1);
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         for (int j = tid; j < joints; j += 256) cnt[j] = 0;  // reused as the fill cursor
         __syncthreads();
         for (int m = tid, r = 0; m < members; m += 256, ++r) {
-            const int2 c = r < MR ? ends_of(r, m) : CNI[m];
+            const int2 c = r < MR ? ends_of(r, m) : CNI(m);
             const int j0 = c.x, j1 = c.y;
             if (constrained(j0)) ends[start[j0] + atomicAdd(&cnt[j0], 1)] = m << 1;
             if (constrained(j1)) ends[start[j1] + atomicAdd(&cnt[j1], 1)] = (m << 1) | 1;
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
             const int deg = cnt[j];
             if (deg == 0) continue;
             double r[3];
-            joint_reaction(ends + start[j], deg, CNI, X, E, A, (size_t)b * nM_max, u, nullptr, r);
+            joint_reaction(ends + start[j], deg, mem, X, mbase, u, nullptr, r);
 #pragma unroll
             for (int a = 0; a < 3; ++a)
                 if (fi[3 * j + a] < 0) f[3 * j + a] = r[a];
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
         __syncthreads();
         if (base <= TRS_RECOVER_LIST_CAP && scan_only == 0) {
             for (int m = tid, r = 0; m < members; m += 256, ++r) {
-                const int2 c = r < MR ? ends_of(r, m) : CNI[m];
+                const int2 c = r < MR ? ends_of(r, m) : CNI(m);
                 const int j0 = c.x, j1 = c.y;
                 if (constrained(j0)) lists[slot_get(j0, 1) + atomicAdd(slot(j0), 1)] = m << 1;
                 if (constrained(j1)) lists[slot_get(j1, 1) + atomicAdd(slot(j1), 1)] = (m << 1) | 1;
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
             for (int j = tid; j < joints; j += 256) {
                 if (!constrained(j)) continue;
                 double r[3];
-                joint_reaction(lists + slot_get(j, 1), slot_get(j, 0), CNI, X, E, A, (size_t)b * nM_max, u, jo, r);
+                joint_reaction(lists + slot_get(j, 1), slot_get(j, 0), mem, X, mbase, u, jo, r);
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
                     if (fi[3 * j + a] < 0) f[3 * J(j) + a] = r[a];   // (the joint's own slot among them)
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
                 double r[3] = {0.0, 0.0, 0.0};
                 for (int m0 = 0; m0 < members; m0 += 64) {
                     const int m = m0 + lane;
-                    const int2 c = m < members ? CNI[m] : int2{-1, -1};
+                    const int2 c = m < members ? CNI(m) : int2{-1, -1};
                     const bool h0 = c.x == j, h1 = c.y == j;
                     const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
                     unsigned long long any = b0 | b1;
@@ -305,7 +304,7 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
                     if (h0 || h1) {
                         const MemberGeom g = member_geom(X, c.x, c.y);
                         const size_t mm = (size_t)b * nM_max + m;
-                        axial = member_axial(g, E[mm] * A[mm], u, J(c.x), J(c.y));
+                        axial = member_axial(g, mem.EA(mm), u, J(c.x), J(c.y));
 #pragma unroll
                         for (int a = 0; a < 3; ++a) cc[a] = g.c[a];
                     }
@@ -379,8 +378,8 @@ __global__ __launch_bounds__(256) void trs_fitness_kernel(
 
 }  // namespace
 
-extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* xyz, const int* conn,
-                                  const double* E, const double* A, const double* loads,
+extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* xyz, const TrsMembers* members,
+                                  const double* loads,
                                   const int* free_index, const int* nJ, const int* nM,
                                   const double* uf, int ld_uf, double* u, double* f_ext, double* N,
                                   const int* joint_out, int force_unstaged, hipStream_t stream,
@@ -396,7 +395,7 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
             reinterpret_cast<const void*>(trs_recover_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
             160 * 1024);
         (void)lists_limit_set;
-        hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), lds_lists, stream, xyz, conn, E, A, loads,
+        hipLaunchKernelGGL(trs_recover_kernel<false>, dim3(B), dim3(256), lds_lists, stream, xyz, *members, loads,
                            free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out, out_rows, nJ_out,
                            nM_out, info_in, info_out, (force_unstaged & TRS_HINT_RECOVER_SCAN) != 0);
         return (int)hipGetLastError();
@@ -405,7 +404,7 @@ extern "C" int trs_recover_launch(int B, int nJ_max, int nM_max, const double* x
         reinterpret_cast<const void*>(trs_recover_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
         160 * 1024);
     (void)lds_limit_set;
-    hipLaunchKernelGGL(trs_recover_kernel<true>, dim3(B), dim3(256), lds, stream, xyz, conn, E, A, loads,
+    hipLaunchKernelGGL(trs_recover_kernel<true>, dim3(B), dim3(256), lds, stream, xyz, *members, loads,
                        free_index, nJ, nM, nJ_max, nM_max, uf, ld_uf, u, f_ext, N, joint_out, out_rows, nJ_out, nM_out,
                        info_in, info_out, 0);
     return (int)hipGetLastError();

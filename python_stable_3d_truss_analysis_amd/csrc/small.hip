@@ -69,9 +69,7 @@ __device__ __forceinline__ double wg_sum(double v, double* red) {
 
 struct SmallArgs {
     const double* xyz;
-    const int* conn;
-    const double* E;
-    const double* A;
+    TrsMembers mem;   // end joints and sections, general or table form (trs_common.h)
     const uint8_t* cbits;
     const double* loads;
     const int* nJ;
@@ -83,8 +81,7 @@ struct SmallArgs {
     int* info;
     int* free_index;  // optional outputs of the dofmap stage
     int* n_free;
-    const double* rho;  // optional: fitness reductions
-    double allow_stress, allow_displace;
+    double allow_stress, allow_displace;   // (the densities of the fitness reductions travel in `mem`)
     double* weight;
     double* stress_vio;
     double* disp_vio;
@@ -152,10 +149,12 @@ __global__ __launch_bounds__(SNT) void trs_solve_small_kernel(const SmallArgs a)
         for (int x = 2 * tid; x < total; x += 2 * SNT) *reinterpret_cast<d2*>(Kb + x) = d2{0.0, 0.0};
     }
     // ---- member geometry, sorted joint adjacency, joint diagonal blocks (as trs_assemble, phase 0) ----
-    const int* conn = a.conn + (size_t)b * 2 * nM_max;
+    const size_t mbase = (size_t)b * nM_max;
+    auto ends = [&](int m) { return a.mem.ends(mbase + m); };
     for (int m = tid; m < nM; m += SNT) {
-        const size_t mm = (size_t)b * nM_max + m;
-        const int j0 = conn[2 * m], j1 = conn[2 * m + 1];
+        const size_t mm = mbase + m;
+        const int2 c01 = ends(m);
+        const int j0 = c01.x, j1 = c01.y;
         double d[3], len2 = 0.0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(SNT) void trs_solve_small_kernel(const SmallArgs a)
             len2 += d[q] * d[q];
         }
         const double len = sqrt(len2);
-        mk[m] = a.E[mm] * a.A[mm] / len;                           // truss.py:56-58
+        mk[m] = a.mem.EA(mm) / len;                                // truss.py:56-58
 #pragma unroll
         for (int q = 0; q < 3; ++q) mc[3 * m + q] = d[q] / len;    // truss.py:60-63
         atomicAdd(&cnt[j0], 1);
@@ -189,7 +188,8 @@ __global__ __launch_bounds__(SNT) void trs_solve_small_kernel(const SmallArgs a)
     for (int j = tid; j < nJ; j += SNT) fill[j] = 0;
     __syncthreads();
     for (int m = tid; m < nM; m += SNT) {
-        const int j0 = conn[2 * m], j1 = conn[2 * m + 1];
+        const int2 c01 = ends(m);
+        const int j0 = c01.x, j1 = c01.y;
         adj[start[j0] + atomicAdd(&fill[j0], 1)] = ((unsigned)j1 << 16) | (unsigned)m;
         adj[start[j1] + atomicAdd(&fill[j1], 1)] = ((unsigned)j0 << 16) | (unsigned)m;
     }
@@ -388,7 +388,8 @@ __global__ __launch_bounds__(SNT) void trs_solve_small_kernel(const SmallArgs a)
     }
     __syncthreads();
     auto axial_of = [&](int m) {
-        const int j0 = conn[2 * m], j1 = conn[2 * m + 1];
+        const int2 c01 = ends(m);
+        const int j0 = c01.x, j1 = c01.y;
         double proj = 0.0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) proj += mc[3 * m + q] * (uvec[3 * j1 + q] - uvec[3 * j0 + q]);
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(SNT) void trs_solve_small_kernel(const SmallArgs a)
                 for (int i = 0; i < deg; ++i) {
                     const int m = (int)(list[i] & 0xffffu);
                     const double ax = axial_of(m);
-                    const double sgn = conn[2 * m + 1] == j ? 1.0 : -1.0;  // N c on joint1, -N c on joint0
+                    const double sgn = ends(m).y == j ? 1.0 : -1.0;  // N c on joint1, -N c on joint0
 #pragma unroll
                     for (int q = 0; q < 3; ++q) r[q] += sgn * ax * mc[3 * m + q];
                 }
@@ -430,16 +431,17 @@ __global__ __launch_bounds__(SNT) void trs_solve_small_kernel(const SmallArgs a)
         double* red = scratch;
         double w = 0.0, sv = 0.0, dv = 0.0;
         for (int m = tid; m < nM; m += SNT) {
-            const size_t mm = (size_t)b * nM_max + m;
-            const int j0 = conn[2 * m], j1 = conn[2 * m + 1];
+            const size_t mm = mbase + m;
+            const int2 c01 = ends(m);
+            const int j0 = c01.x, j1 = c01.y;
             double len2 = 0.0;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const double dd = X[3 * j1 + q] - X[3 * j0 + q];
                 len2 += dd * dd;
             }
-            const double area = a.A[mm];
-            w += area * sqrt(len2) * a.rho[mm];
+            const double area = a.mem.area(mm);
+            w += area * sqrt(len2) * a.mem.density(mm);
             const double force = axial_of(m);
             if (fabs(force) >= 1e-10) {
                 const double s = fabs(force) / area;
@@ -475,15 +477,15 @@ extern "C" int trs_solve_small_fits(int nJ_max, int nM_max, int n_max_bound) {
 }
 
 extern "C" int trs_solve_small_launch(int B, int nJ_max, int nM_max, int n_max_bound, const double* xyz,
-                                      const int* conn, const double* E, const double* A, const uint8_t* cbits,
+                                      const TrsMembers* members, const uint8_t* cbits,
                                       const double* loads, const int* nJ, const int* nM, double* u,
                                       double* f_ext, double* N, int* info, int* free_index, int* n_free,
-                                      const double* rho, double allow_stress, double allow_displace,
+                                      double allow_stress, double allow_displace,
                                       double* weight, double* stress_vio, double* disp_vio,
                                       hipStream_t stream) {
     if (B <= 0) return 0;
     if (!trs_solve_small_fits(nJ_max, nM_max, n_max_bound)) return (int)hipErrorInvalidValue;
-    if (weight != nullptr && (rho == nullptr || stress_vio == nullptr || disp_vio == nullptr))
+    if (weight != nullptr && ((members->rho == nullptr && members->tidx == nullptr) || stress_vio == nullptr || disp_vio == nullptr))
         return (int)hipErrorInvalidValue;
     const int nb_max = (n_max_bound + 15) / 16;
     const size_t lds = small_lds_layout(nJ_max, nM_max < 1 ? 1 : nM_max, nb_max).total;
@@ -491,9 +493,8 @@ extern "C" int trs_solve_small_launch(int B, int nJ_max, int nM_max, int n_max_b
         reinterpret_cast<const void*>(trs_solve_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
         160 * 1024);
     (void)lds_limit_set;
-    SmallArgs args{xyz,  conn, E,          A,      cbits, loads, nJ,           nM,
-                   nJ_max, nM_max < 1 ? 1 : nM_max, nb_max, u,     f_ext, N,   info,         free_index,
-                   n_free, rho,  allow_stress, allow_displace, weight, stress_vio, disp_vio};
+    SmallArgs args{xyz,    *members, cbits, loads, nJ, nM, nJ_max, nM_max < 1 ? 1 : nM_max, nb_max, u, f_ext, N, info,
+                   free_index, n_free, allow_stress, allow_displace, weight, stress_vio, disp_vio};
     hipLaunchKernelGGL(trs_solve_small_kernel, dim3(B), dim3(SNT), lds, stream, args);
     return (int)hipGetLastError();
 }

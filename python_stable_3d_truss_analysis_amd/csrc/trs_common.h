@@ -27,6 +27,43 @@ __device__ static inline double readlane_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// ---- member description of a batch (ABI 10, include/trs_solver.h "Member forms") ------------------------------------
+// General form: end joints as int32 pairs, E and A (and rho where needed) as one double per member.
+// Table form  : end joints as uint16 pairs (the library's size limit is 65 535 joints anyway), one uint8 type index per
+//               member and a table of (a, e, density) triples - 5 instead of 24 (32 with rho) bytes per member in HBM
+//               and over PCIe.  E A is formed as e * a from the table: the same product, the same bits.
+struct TrsMembers {
+    const void* conn;             // [B][nM_max][2]
+    const double* E;              // [B][nM_max]   general form
+    const double* A;              // [B][nM_max]   general form
+    const double* rho;            // [B][nM_max]   general form, where densities are needed (else null)
+    const unsigned char* tidx;    // [B][nM_max]   table form; null = general form
+    const double* types;          // [n_types][3] = a, e, density
+    __device__ __forceinline__ bool table() const { return tidx != nullptr; }
+    __device__ __forceinline__ int2 ends(size_t mm) const {
+        if (tidx != nullptr) {
+            const ushort2 c = reinterpret_cast<const ushort2*>(conn)[mm];
+            return int2{(int)c.x, (int)c.y};
+        }
+        return reinterpret_cast<const int2*>(conn)[mm];
+    }
+    __device__ __forceinline__ double EA(size_t mm) const {
+        if (tidx != nullptr) {
+            const double* t = types + 3 * (int)tidx[mm];
+            return t[1] * t[0];
+        }
+        return E[mm] * A[mm];
+    }
+    __device__ __forceinline__ double area(size_t mm) const { return tidx != nullptr ? types[3 * (int)tidx[mm]] : A[mm]; }
+    __device__ __forceinline__ double density(size_t mm) const { return tidx != nullptr ? types[3 * (int)tidx[mm] + 2] : rho[mm]; }
+};
+static inline TrsMembers trs_members_general(const int* conn, const double* E, const double* A, const double* rho = nullptr) {
+    return TrsMembers{conn, E, A, rho, nullptr, nullptr};
+}
+static inline TrsMembers trs_members_table(const unsigned short* conn16, const unsigned char* tidx, const double* types) {
+    return TrsMembers{conn16, nullptr, nullptr, nullptr, tidx, types};
+}
+
 // ---- envelope (profile) metadata of the reduced stiffness matrix, per truss ----------------------
 // Written by trs_assemble, read by trs_potrf_batched / trs_potrs_batched (optional: a null pointer
 // means "treat the matrix as dense").  All quantities are in units of 16-row chunks / 16-column

@@ -24,7 +24,8 @@ import numpy as np
 
 from .batch import BatchResult, PackedBatch
 
-_FIELDS = tuple(PackedBatch.__dataclass_fields__)
+#: the arrays a shard crosses to its worker with (the general member form; a batch in the table form is expanded first)
+_FIELDS = tuple(f for f in PackedBatch.__dataclass_fields__ if f not in ("type_idx", "types"))
 
 
 def shard_indices(costs, world_size):
@@ -379,6 +380,7 @@ class ShardedSolver:
         return results[0] if sections is None else results
 
     def _run(self, packed, opts, nsolve, want_fit):
+        packed = packed.general()
         B, nJm, nMm = packed.B, packed.nJ_max, packed.nM_max
         keep = []
         out_desc, outs = {}, {}

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_host_side_helpers_of_the_abi():
     lib = _capi.load()
-    assert lib.trs_abi_version() == _capi.ABI_VERSION == 9
+    assert lib.trs_abi_version() == _capi.ABI_VERSION == 10
     assert lib.trs_assemble_work_bytes(244, 942, 696) % 256 == 0
     assert lib.trs_slab_rows(696) == 704 and lib.trs_slab_ld(696) == 720
     assert lib.trs_slab_rows(64) == 64 and lib.trs_slab_rows(65) == 128 and lib.trs_slab_rows(0) == 64
@@ -51,3 +51,43 @@ def test_host_library_exports_every_symbol_of_its_header():
                      "trs_json_free_files", "trs_json_pack", "trs_json_read_files", "trs_profile_order", "trs_rcm_order"]
     for name in names:
         assert hasattr(lib, name), f"{name} declared in trs_host.h but not exported"
+
+
+def test_table_member_form_twins_mirror_their_general_entry_points():
+    """ABI 10: every `_tab` entry point takes (conn16, type_idx, types) where its twin takes (conn, E, A) - the same
+    number of arguments, except `trs_solve_small_tab` (the densities of its fitness reductions come from the table) and
+    `trs_joint_order_rows_tab` (one type-index array in and out instead of E and A in and out)."""
+    sig = _capi.SIGNATURES
+    twins = sorted(name for name in sig if name.endswith("_tab"))
+    assert twins == ["trs_assemble_tab", "trs_joint_order_rows_tab", "trs_joint_order_tab", "trs_recover_rows_tab",
+                     "trs_recover_tab", "trs_solve_rows_tab", "trs_solve_small_tab", "trs_solve_tab"]
+    fewer = {"trs_solve_small_tab": 1, "trs_joint_order_rows_tab": 2}
+    for name in twins:
+        base = sig[name[:-4]]
+        assert sig[name][0] is base[0] and len(sig[name][1]) == len(base[1]) - fewer.get(name, 0), name
+
+
+def test_packed_batch_member_forms_round_trip():
+    """`PackedBatch.table()` / `.general()`: the type table holds exactly the doubles of the batch (bit patterns), the
+    end joints fit uint16, and the generic batch operations keep the form; more than 256 distinct triples are refused."""
+    import json
+    import numpy as np
+    import pytest
+    from python_stable_3d_truss_analysis_amd import batch
+    datas = [json.load(open(os.path.join(ROOT, "tests", "golden", "data", n + ".json")))
+             for n in ("bar-942_input_0", "bar-25_input_0", "bar-47_input_0")]
+    p = batch.pack_json(datas)
+    t = batch.pack_json(datas, members="auto")
+    assert t.is_table and t.conn.dtype == np.uint16 and t.type_idx.dtype == np.uint8 and t.E is None and len(t.types) <= 256
+    g = t.general()
+    live = np.arange(p.nM_max)[None, :] < p.nM[:, None]
+    for f in ("E", "A", "rho"):
+        np.testing.assert_array_equal(getattr(g, f)[live].view(np.uint64), getattr(p, f)[live].view(np.uint64))
+    np.testing.assert_array_equal(g.conn, p.conn)
+    r = t.replicate(3).take([1, 4, 8]).trimmed()
+    assert r.is_table and r.B == 3 and r.types is t.types and r.type_idx.shape == (3, int(r.nM.max()))
+    many = p.replicate(100)
+    many.A[:, 0] = np.arange(300) + 1.0
+    with pytest.raises(ValueError):
+        many.table()
+    assert not batch._member_form(many, "auto").is_table

@@ -46,7 +46,7 @@ def test_streams_torch_free_bitwise_equal_over_200_steps(lanes):
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(700)
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("noise", [0, 1])
 def test_every_kernel_family_beside_the_others_bitwise_equal_over_200_steps(noise):
     """`tools/repro_families.cpp`: the ragged pipeline, `trs_solve_small` + fitness, a GA generation (`trs_ga_sections`
@@ -54,9 +54,12 @@ def test_every_kernel_family_beside_the_others_bitwise_equal_over_200_steps(nois
     `trs_stream_create_masked` - `trs_copy_rows` pulls / pushes through page-locked host memory and `trs_cubegen_dev`,
     each on a stream of its own at the same time (with and without the spinning noise kernel): every output of every
     step equals, bit for bit, what the same calls give one after the other on one stream."""
-    run = subprocess.run([_binary("repro_families"), os.path.join(PKG, "libtrs_hip.so"), "--trusses", "8192", "--small",
-                          "8192", "--steps", "200", "--noise", str(noise)],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    try:
+        run = subprocess.run([_binary("repro_families"), os.path.join(PKG, "libtrs_hip.so"), "--trusses", "8192", "--small",
+                              "8192", "--steps", "200", "--noise", str(noise)],
+                             capture_output=True, text=True, timeout=240, cwd=ROOT)
+    except subprocess.TimeoutExpired as exc:   # (the tool's own watchdog names the phase of a stall; this is the backstop)
+        raise AssertionError(f"repro_families did not finish: {(exc.stdout or b'')[-2000:]!r}") from None
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]
     result = [l for l in run.stdout.splitlines() if l.startswith("RESULT")]
     assert result and "steps=200: 0 steps with differences, 0 outputs" in result[-1], run.stdout[-2000:]

@@ -1,4 +1,4 @@
-"""`batch.shared_workspace`: one workspace per (device, stream), at most `MAX_SHARED_WORKSPACES` of them alive
+"""`batch.shared_workspace`: one workspace per (device, stream), at most `MAX_SHARED_WORKSPACES` of them alive per device
 (the cache was keyed by raw stream handles and never evicted - tens of GB per entry).  Host logic only:
 a stand-in for the `torch.cuda` stream query, no buffer is allocated."""
 import types
@@ -12,6 +12,8 @@ def _fake_torch(handle_box):
 
 
 def test_shared_workspace_cache_is_bounded_and_lru(monkeypatch):
+    """The bound is PER DEVICE (a process that drives several devices in turn must not evict one device's
+    workspaces for another's)."""
     monkeypatch.setattr(batch, "_SHARED_WORKSPACES", {})
     box = [0]
     torch = _fake_torch(box)
@@ -21,10 +23,17 @@ def test_shared_workspace_cache_is_bounded_and_lru(monkeypatch):
         made[handle] = batch.shared_workspace(torch, "cuda:0")
     box[0] = 2
     assert batch.shared_workspace(torch, "cuda:0") is made[2]          # same stream, same workspace
-    assert batch.shared_workspace(torch, "cuda:1") is not made[2]      # another device: another one - and the
-    assert len(batch._SHARED_WORKSPACES) == batch.MAX_SHARED_WORKSPACES   # least recently used entry (stream 1) went
+    other = batch.shared_workspace(torch, "cuda:1")
+    assert other is not made[2]                                        # another device: another one, and nothing of
+    assert len(batch._SHARED_WORKSPACES) == batch.MAX_SHARED_WORKSPACES + 1   # cuda:0 is evicted for it
     box[0] = 1
-    assert batch.shared_workspace(torch, "cuda:0") is not made[1]
+    assert batch.shared_workspace(torch, "cuda:0") is made[1]
+    box[0] = 99                                                        # a fifth stream of cuda:0: its least recently
+    fifth = batch.shared_workspace(torch, "cuda:0")                    # used entry (stream 3) goes
+    mine = [k for k in batch._SHARED_WORKSPACES if k[0] == "cuda:0"]
+    assert len(mine) == batch.MAX_SHARED_WORKSPACES and ("cuda:0", 3) not in mine and fifth is not made[3]
     box[0] = 2
     assert batch.shared_workspace(torch, "cuda:0") is made[2]          # recently used entries survive the evictions
-    assert len(batch._SHARED_WORKSPACES) == batch.MAX_SHARED_WORKSPACES
+    box[0] = 2
+    assert batch.shared_workspace(torch, "cuda:1") is other            # the other device's entry was never touched
+    assert len(batch._SHARED_WORKSPACES) == batch.MAX_SHARED_WORKSPACES + 1
