@@ -1232,6 +1232,11 @@ _LANE_STREAMS = {}
 #: streams a resident `RaggedSolver` deals its buckets onto unless told otherwise (`lanes=`), and the slab budget per lane
 DEFAULT_LANES = 4
 LANE_SLAB_BYTES = 36 << 30
+#: run streams of the host-fed pipeline (`RaggedSolver(host_io=...)`, `solve_batch_streamed`).  ONE: with two to four the
+#: call is no shorter (67.2 / 67.9 / 67.8 ms per 65 536 cube trusses, EXPERIMENTS R6.4) - the run stream is busy from
+#: the first pull to the last solve either way, and what bounds the call is that device work on the 232 CUs the copy
+#: kernels leave it; `lanes=` stays for other shapes of batch
+HOSTFED_LANES = int(os.environ.get("TRS_HOSTFED_LANES", "1"))
 
 
 def lane_streams(torch, device, count):
@@ -1304,20 +1309,36 @@ class _MaskedStreams:
         self.torch, self.dev = torch, dev
         with torch.cuda.device(dev):
             try:
-                for cus in sets:
+                for k, cus in enumerate(sets):
                     mask = (ctypes.c_uint32 * words)()
                     for c in cus:
                         mask[c // 32] |= 1 << (c % 32)
+                    if k == 1:
+                        self.run_mask = mask
                     handle = ctypes.c_void_p()
                     _capi.check(lib.trs_stream_create_masked(mask, words, ctypes.byref(handle)), "trs_stream_create_masked")
                     self.handles.append(handle)
                     self.streams.append(torch.cuda.ExternalStream(handle.value, device=dev))
+                self.runs = [self.streams[1]]
             except Exception:
                 self.close()   # (a runtime that refuses the 2nd or 3rd mask must not leak the streams made so far)
                 raise
 
     def __iter__(self):
-        return iter(self.streams)
+        return iter(self.streams[:3])
+
+    def run_streams(self, count):
+        """`count` run streams on the solver kernels' CU set (the first is the pipeline's own; more are made on demand
+        and kept): the run lanes of a host-fed `RaggedSolver`."""
+        import ctypes
+        while len(self.runs) < count:
+            handle = ctypes.c_void_p()
+            with self.torch.cuda.device(self.dev):
+                _capi.check(self.lib.trs_stream_create_masked(self.run_mask, len(self.run_mask), ctypes.byref(handle)),
+                            "trs_stream_create_masked")
+            self.handles.append(handle)
+            self.runs.append(self.torch.cuda.ExternalStream(handle.value, device=self.dev))
+        return self.runs[:count]
 
     def close(self):
         """Destroy the streams (after the work queued on them has finished).  The pipeline's own set is created
@@ -1325,7 +1346,7 @@ class _MaskedStreams:
         self.torch.cuda.synchronize(self.dev)
         for handle in self.handles:
             _capi.check(self.lib.trs_stream_destroy(handle), "trs_stream_destroy")
-        self.handles, self.streams = [], []
+        self.handles, self.streams, self.runs = [], [], []
 
 
 def _flow_shop_order(groups, packed, n_pad_of, rule="johnson"):
@@ -1491,7 +1512,10 @@ class RaggedSolver:
                          for _ in range(max(1, int(n_variants)))]
             first = self.outs[0]
             self.u, self.f_ext, self.N, self.info = first["u"], first["f_ext"], first["N"], first["info"]
-        n_lanes = 1 if self.host_io else max(1, int(lanes if lanes is not None else DEFAULT_LANES))
+        # (host-fed: `lanes` = RUN streams of the pull / run / push pipeline - bucket k is ordered and solved on run
+        # stream k mod lanes with that lane's workspace, so that one bucket's latency-bound phases and emptying-chip
+        # tails are filled by the next bucket's kernels, as in the resident step)
+        n_lanes = max(1, int(lanes if lanes is not None else (HOSTFED_LANES if self.host_io else DEFAULT_LANES)))
         if max_slab_bytes is None:
             max_slab_bytes = default_slab_budget(torch, dev, n_lanes, workspace)
         # resident batches: groups cut at whole rounds of the factorisation kernel (3 waves x 4 SIMDs per CU in flight)
@@ -1549,10 +1573,14 @@ class RaggedSolver:
                                  # truss 0.1 + 1.3e-6 rows^2 (EXPERIMENTS R5.6) - the lanes are dealt by it
                                  "cost": Bb * (0.1 + 1.3e-6 * float(db.rows) ** 2)})
         self.workspace = workspace if workspace is not None else SolverWorkspace(torch, dev)
-        self._side_streams = lane_streams(torch, dev, self.lanes - 1) if self.lanes > 1 else []
+        self._side_streams = lane_streams(torch, dev, self.lanes - 1) if self.lanes > 1 and not self.host_io else []
         self._deal_lanes()
         if self.host_io:
             self._streams = _pipeline_streams(torch, dev, self.lib)
+            if isinstance(self._streams, _MaskedStreams):
+                self._run_streams = self._streams.run_streams(self.lanes)
+            else:
+                self._run_streams = [tuple(self._streams)[1]] + list(lane_streams(torch, dev, self.lanes - 1))
 
     def _deal_lanes(self):
         """Deal the buckets onto the lanes - longest processing time first on `bk["cost"]` (a size model; dealing by MEASURED
@@ -1561,8 +1589,12 @@ class RaggedSolver:
         buckets (they run one after the other on its stream) and point the buckets at it.  The buckets are launched in
         the order of `self.buckets`; resident batches keep them by descending cost, so every lane starts with its
         longest bucket and the step ends over the short ones.  Nothing of this solver may be in flight."""
-        if not self.host_io:   # (the host-fed pipeline has its own order: the flow shop's)
-            self.buckets.sort(key=lambda bk: -bk["cost"])
+        if self.host_io:   # (the host-fed pipeline has its own order - the flow shop's -: the run lanes take turns)
+            for k, bk in enumerate(self.buckets):
+                bk["lane"] = k % self.lanes
+            self._bind_lanes()
+            return
+        self.buckets.sort(key=lambda bk: -bk["cost"])
         load = [0.0] * self.lanes
         for bk in self.buckets:
             lane = min(range(self.lanes), key=lambda l: load[l])
@@ -1720,12 +1752,13 @@ class RaggedSolver:
             if sections[0] is not None:
                 raise ValueError("the host-fed pipeline solves the members' own sections")
             # host-fed pipeline: pull of bucket k + 1 | order + solve of bucket k | push of bucket k - 1
-            s_up, s_run, s_down = tuple(self._streams)
+            s_up, _, s_down = tuple(self._streams)
+            runs = self._run_streams
             caller = torch.cuda.current_stream(self.device)
             timing = record is not None
             begin = torch.cuda.Event(enable_timing=timing)
             begin.record(caller)
-            for st in (s_up, s_run, s_down):
+            for st in [s_up, s_down] + list(runs):
                 st.wait_event(begin)
             mark = lambda name, stream: record.append((name, begin, self._marked(stream))) if timing else None
             for k, (bk, (gather, scatters)) in enumerate(zip(self.buckets, self._tables)):
@@ -1737,6 +1770,7 @@ class RaggedSolver:
                     pulled = torch.cuda.Event()
                     pulled.record(s_up)
                     mark(f"bucket {k} pulled", s_up)
+                s_run = runs[bk["lane"]]
                 with torch.cuda.stream(s_run):
                     s_run.wait_event(pulled)
                     mark(f"bucket {k} run begins", s_run)
@@ -1984,15 +2018,15 @@ def host_result_arrays(torch, pool, B, nJ_max, nM_max, device):
     return out
 
 
-def solve_batch_streamed(packed: PackedBatch, device=None, reorder=True, pool=None, max_slab_bytes=48 << 30):
+def solve_batch_streamed(packed: PackedBatch, device=None, reorder=True, pool=None, max_slab_bytes=48 << 30, lanes=None):
     """Host arrays in -> host results out for a LARGE ragged batch held in page-locked memory
     (`PackedBatch.pinned()`), as a pipeline over PCIe with NO staging copy: the batch stays where it is, every
     size bucket's gather pulls its rows straight out of the host arrays (page-locked memory is mapped into the
     device's address space; only the bucket-trimmed prefix of every row crosses the link - for cube trusses
     about 60 % of the padded bytes), the device orders and solves the bucket, and its scatter pushes the results
     into the (page-locked) result arrays - pull of bucket k + 1, device work of bucket k and push of bucket k - 1
-    at the same time on three streams (`RaggedSolver(host_io=...)`).  Same results, bit for bit, as
-    `solve_batch(packed, reorder=...)`.  `solve_batch(..., pool=...)` routes big pinned batches here by itself."""
+    at the same time on three streams (`RaggedSolver(host_io=...)`; `lanes` = run streams, default `HOSTFED_LANES`: the
+    buckets' device work alternates between them).  Same results, bit for bit, as `solve_batch(packed, reorder=...)`.  `solve_batch(..., pool=...)` routes big pinned batches here by itself."""
     torch, dev = _require_gpu(device)
     B, nJ_max, nM_max = packed.B, packed.nJ_max, packed.nM_max
     if B == 0:
@@ -2003,7 +2037,8 @@ def solve_batch_streamed(packed: PackedBatch, device=None, reorder=True, pool=No
     host_in = {f: torch.from_numpy(getattr(packed, f)) for f in (RaggedSolver.GATHER_TABLE if packed.is_table else RaggedSolver.GATHER)}
     if packed.is_table:   # (5 instead of 24 bytes per member cross the link: conn uint16 + one type index)
         host_in["types"] = torch.from_numpy(np.ascontiguousarray(packed.types, dtype=np.float64))
-    solver = RaggedSolver(packed, dev, reorder=reorder, max_slab_bytes=max_slab_bytes, host_io=(host_in, host_out))
+    solver = RaggedSolver(packed, dev, reorder=reorder, max_slab_bytes=max_slab_bytes, host_io=(host_in, host_out),
+                          lanes=lanes)
     solver.step()
     return solver.result()
 

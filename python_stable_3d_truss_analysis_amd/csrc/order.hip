@@ -680,7 +680,10 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
         if (nb_of(axis_of(ax, 0)) > nb_of(axis_of(first_ax, 0)) ||
             (nb_of(axis_of(ax, 0)) == nb_of(axis_of(first_ax, 0)) && nb_of(axis_of(ax, 1)) > nb_of(axis_of(first_ax, 1))))
             first_ax = ax;
-    const int n_sweep = sweeps ? (effort >= 2 ? 6 : 1) : 0;
+#ifndef TRS_ORDER_NSWEEP   // (A/B builds: fewer of the six axis orders - the longest-extent sweep, then its partner with
+#define TRS_ORDER_NSWEEP 6  //  the same slowest axis; EXPERIMENTS R6.5)
+#endif
+    const int n_sweep = sweeps ? (effort >= 2 ? TRS_ORDER_NSWEEP : 1) : 0;
     auto bits_for = [](int count) { int b = 1; while ((1 << b) < count) ++b; return b; };  // values 0 .. count-1
     const int bits0 = bits_for(nb[0]), bits1 = bits_for(nb[1]), bits2 = bits_for(nb[2]);
     auto bits_of = [&](int a) { return a == 0 ? bits0 : (a == 1 ? bits1 : bits2); };  // (no indexed private array)
@@ -721,7 +724,11 @@ __global__ __launch_bounds__(NT, 4) void trs_joint_order_kernel(
         }
         const bool wide_keys = key_bits > 32;
         for (int i = wide_keys ? ((wave & 1) ? n_sweep : wave / 2) : wave; i < n_sweep; i += wide_keys ? NWAVE / 2 : NWAVE) {
+#if TRS_ORDER_NSWEEP < 6
+            const int ax = i == 0 ? first_ax : (first_ax ^ 1);
+#else
             const int ax = i == 0 ? first_ax : (i <= first_ax ? i - 1 : i);
+#endif
             const int a0 = axis_of(ax, 0), a1 = axis_of(ax, 1), a2 = axis_of(ax, 2);
             // lexicographic by (bin a0, bin a1, bin a2, id): ONE rank sort.  x = position in the ascending id
             // list, so (bins, x) orders like (bins, id).  32-bit keys when the three bin fields and x fit (any

@@ -59,7 +59,22 @@ for r in range(rounds):
         torch.cuda.synchronize()
         times[cfg].append((time.perf_counter() - t0) / steps * 1e3)
         ncomp = sum(1 for bk in solver.buckets if bk["dev"].options["compact"] and not bk["dev"].small)
-        info[cfg] = f"{len(solver.buckets)} buckets, {ncomp} compact"
+        if os.environ.get("TILES"):   # stored tiles per truss under this configuration's joint orders (sum of cend[t] - t)
+            tiles = 0
+            for bk in solver.buckets:
+                db = bk["dev"]
+                if db.small:
+                    continue
+                db.dofmap(); db.assemble()
+                env = db.env[:bk["count"]].cpu().numpy()
+                nchm, npan = db.rows // 16, db.rows // 64
+                cend = env[:, nchm + npan + 8: nchm + npan + 8 + nchm].astype(np.int64)
+                nch = (sizes.n_free[bk["idx"]].astype(np.int64) + 63) // 64 * 4
+                t = np.arange(nchm)[None, :]
+                tiles += int(((cend - t) * (t < nch[:, None])).sum())
+            info[cfg] = f"{len(solver.buckets)} buckets, {tiles / sizes.B:.1f} stored tiles per truss"
+        else:
+            info[cfg] = f"{len(solver.buckets)} buckets, {ncomp} compact"
         if ref is None:
             ref = (solver.u.clone(), solver.N.clone(), solver.f_ext.clone())
         same[cfg] = bool(torch.equal(solver.u, ref[0]) and torch.equal(solver.N, ref[1]) and torch.equal(solver.f_ext, ref[2])
