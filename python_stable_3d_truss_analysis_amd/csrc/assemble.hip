@@ -29,6 +29,16 @@
 #include "trs_common.h"
 #include "../../include/trs_solver.h"
 
+// Diagnostic builds only (-DTRS_ASM_STOP_AFTER=k via tools/build_variants.sh, tools/asm_phases.py): the kernel ends
+// behind phase k (wrong results by design), so that timing the truncated kernels gives the CUMULATIVE time of the phases
+// without an instrument inside them (wave-cycle stamps were tried first: their registers spill in the 1024-thread
+// instance and the row loop then takes 8 x as long).  The product library compiles nothing of this.
+#ifdef TRS_ASM_STOP_AFTER
+#define TRS_ASM_PHASE_END(k) do { if (TRS_ASM_STOP_AFTER == (k)) return; } while (0)
+#else
+#define TRS_ASM_PHASE_END(k) do { } while (0)
+#endif
+
 namespace {
 
 #ifndef TRS_ASM_THREADS
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     if (!rank_sort)
         for (int x = tid * 2; x < TR * (WT + 16); x += 2 * NT) *reinterpret_cast<d2*>(T + x) = d2{0.0, 0.0};
     __syncthreads();
+    TRS_ASM_PHASE_END(0);   // inputs staged, tables zeroed
     for_members([&](int m, int j0, int j1) {
         const size_t mm = (size_t)b * nM_max + m;
         double d[3], len2 = 0.0;
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         atomicAdd(&cnt[j1], 1);
     });
     __syncthreads();
+    TRS_ASM_PHASE_END(1);   // member geometry, degree count
     if (tid < 64) {  // exclusive scan of cnt by one wave, 64 joints per step
         int base = 0;
         for (int j0 = 0; j0 < nJ; j0 += 64) {
@@ -205,6 +217,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
     }
     for (int j = tid; j < nJ; j += NT) fill[j] = 0;
     __syncthreads();
+    TRS_ASM_PHASE_END(2);   // scan
     // (the caller may know that skipping does not pay for this batch - TRS_ASM_ALL_TILES -: no mask is formed then)
     const bool want_mask = env_all != nullptr && (flags & (TRS_ASM_ALL_TILES | TRS_ASM_FULL_SYMMETRIC)) == 0;
     // kmask (trs_common.h): which tiles of a chunk's rows hold an entry of K - edge-parallel.  A joint's free rows
@@ -247,6 +260,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             if (hi >= 0 && (hi >> 4) != (lo >> 4)) atomicOr(&kmask[lo >> 4], 2u);
         }
     __syncthreads();
+    TRS_ASM_PHASE_END(3);   // adjacency fill, tile mask
     if (rank_sort) {
         for_members([&](int m, int j0, int j1) {
             const unsigned k0 = ((unsigned)j1 << 16) | (unsigned)m, k1 = ((unsigned)j0 << 16) | (unsigned)m;
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             if (fi[3 * a + s] >= 0) atomicMin(&chunkmin[fi[3 * a + s] / 16], mincol / 16);
     }
     __syncthreads();
+    TRS_ASM_PHASE_END(4);   // rank sort, per-joint diagonal blocks
     const bool full = (flags & TRS_ASM_FULL_SYMMETRIC) != 0;
     const bool has_env = env_all != nullptr;
     if (has_env) {
@@ -400,6 +415,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
         __syncthreads();
     }
 
+    TRS_ASM_PHASE_END(5);   // envelope metadata (one wave; the others wait at the barrier)
     // ---- phase 1c: compact per-tile entry lists (narrow envelopes) -----------------------------------------
     if (has_env && wgflag[0] != 0) {
         const TrsCompactLayout ck = trs_compact_layout(nJ_max, nM_max, n_pad_max);
@@ -660,6 +676,7 @@ __global__ __launch_bounds__(NT) void trs_assemble_kernel(
             __builtin_amdgcn_wave_barrier();
         }
     }
+    TRS_ASM_PHASE_END(6);   // phase 1: the row loop
 }
 
 // tile width, table placement (kernel MODE) and work-group size for a batch shape
