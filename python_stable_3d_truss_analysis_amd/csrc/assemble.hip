@@ -45,7 +45,10 @@ namespace {
 #define TRS_ASM_THREADS 512
 #endif
 constexpr int NT_DEFAULT = TRS_ASM_THREADS;  // threads per work-group (two work-groups per CU)
-constexpr int NT_BIG = 1024;                 // ... when a truss needs a whole CU's LDS (one per CU)
+#ifndef TRS_ASM_BIG_THREADS
+#define TRS_ASM_BIG_THREADS 1024
+#endif
+constexpr int NT_BIG = TRS_ASM_BIG_THREADS;  // ... when a truss needs a whole CU's LDS (one per CU)
 #ifndef TRS_ASM_TPR
 #define TRS_ASM_TPR 16
 #endif
