@@ -941,7 +941,7 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)   # (a timed region of ~75 ms; the 25 repeats of it add ~2 s)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="trusses per GPU")
     ap.add_argument("--case", default="bar-942_input_0")
