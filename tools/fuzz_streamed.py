@@ -31,6 +31,20 @@ for trial in range(TRIALS):
     res = batch.solve_batch(packed, reorder=reorder, sections=sec, device_inputs=t, on_device=True)
     ok2 = all(np.array_equal(r.displace.cpu().numpy(), w.displace) and np.array_equal(r.internal.cpu().numpy(), w.internal)
               and np.array_equal(r.external.cpu().numpy(), w.external) for r, w in zip(res, want))
+    # the table member form (ABI 10; several member types so that the table has more than one row): resident bucket
+    # pipeline with the same section variants and the host-fed pipeline, against the general form's staged results
+    multi = gen.generate_cube_batch(rng.integers(lo, hi + 1, size=min(B, 200)), gridRange=(6, 6, 6), seed=int(rng.integers(1 << 30)),
+                                    memberTypes=((1., 1e7, 0.1), (2.5, 2e7, 0.2), (0.75, 3e7, 0.4)))
+    tab = multi.table()
+    want_t = batch.solve_batch(multi, reorder=reorder, sections=sec)
+    got_t = batch.solve_batch(tab, reorder=reorder, sections=sec)
+    fed_t = batch.solve_batch_streamed(tab.pinned(), reorder=reorder)
+    ok3 = len(tab.types) == len({tuple(r) for r in np.stack([multi.A, multi.E, multi.rho], -1)[np.arange(multi.nM_max)[None, :] < multi.nM[:, None]]}) and \
+        all(np.array_equal(getattr(g, k), getattr(w, k)) for g, w in zip(got_t, want_t) for k in ("displace", "external", "internal", "info")) and \
+        all(np.array_equal(getattr(fed_t, k), getattr(want_t[0], k)) for k in ("displace", "external", "internal", "info"))
+    if not ok3:
+        bad += 1
+        print("MISMATCH (table member form) trial", trial, B, (lo, hi), reorder)
     if not (ok and ok2):
         bad += 1
         print("MISMATCH trial", trial, B, (lo, hi), reorder, ok, ok2)
