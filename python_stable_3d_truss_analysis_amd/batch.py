@@ -1458,6 +1458,7 @@ class RaggedSolver:
         self.table = (source.get("type_idx") is not None) if source is not None else bool(getattr(packed, "is_table", False))
         gather = self.GATHER_TABLE if self.table else self.GATHER
         self.types = None
+        self._fixed_types = {}   # type tables of fixed-section variants (`_section_types`), by (a, e, density)
         if self.table:
             types = source.get("types") if source is not None and source.get("types") is not None else getattr(packed, "types", None)
             if types is None:
@@ -1838,7 +1839,7 @@ class RaggedSolver:
             db.E.fill_(float(section[1]))
             return None
         key = tuple(float(v) for v in section[:3]) + (0.0,) * (3 - len(section[:3]))
-        cache = self.__dict__.setdefault("_fixed_types", {})
+        cache = self._fixed_types
         if key not in cache:
             row = self.torch.tensor(key, dtype=self.torch.float64, device=self.device)
             cache[key] = row.expand(max(1, int(self.types.shape[0])), 3).contiguous()
@@ -2086,7 +2087,11 @@ def solve_batch(trusses_or_packed, device=None, max_slab_bytes=64 << 30, reorder
     (the returned arrays are then views of the pool, valid until its next use).  `options`: per-call switches
     of the pipeline (`DEFAULT_OPTIONS`), for A/B runs and tests.  `device_inputs`: the batch's arrays already
     live on the device (dict by field name, e.g. `generate.generate_cube_batch_device`) - nothing is uploaded and
-    the first argument only carries the sizes (`BatchSizes` or a `PackedBatch`)."""
+    the first argument only carries the sizes (`BatchSizes` or a `PackedBatch`).
+
+    A `PackedBatch` in the TABLE member form (`PackedBatch.table()`, `pack_json(..., members="auto")`: uint16 end joints,
+    a uint8 type index per member, one type table) goes up as it is - 5 instead of 24 bytes per member - and is solved
+    by the resident bucket pipeline (`RaggedSolver`) through the `_tab` entry points: the same bits as the general form."""
     packed = trusses_or_packed if isinstance(trusses_or_packed, (PackedBatch, BatchSizes)) \
         else pack_trusses(list(trusses_or_packed))
     torch, dev = _require_gpu(device if device_inputs is None else device_inputs["xyz"].device)
