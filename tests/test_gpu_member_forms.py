@@ -53,6 +53,29 @@ def test_stages_give_the_same_bits_in_both_member_forms(gpu, name):
     assert H.max_scaled_err(res[1].external[0, :nJ, :dim], ref["f_ext"]) <= 1e-9
 
 
+@pytest.mark.parametrize("reorder", [True, "profile", "rcm", "fast"])
+def test_resident_batch_with_a_joint_order_in_the_table_form(gpu, reorder):
+    """`DeviceBatch(table-form batch, reorder=...)`: the order found on the device (`trs_joint_order_tab`: uint16 end
+    joints read and written) or on the host (the end joints renumbered, the type indices untouched); results in the
+    caller's numbering, bit for bit those of the general form, through one call and through the stages."""
+    datas = [H.load_json(n) for n in ("bar-942_input_0", "bar-120_input_0", "bar-47_input_0")]
+    general, table = gpu.pack_json(datas), gpu.pack_json(datas, members="table")
+    devs = [gpu.DeviceBatch(p, use_small=False, reorder=reorder) for p in (general, table)]
+    assert devs[1].table and devs[1].joint_out is not None
+    np.testing.assert_array_equal(devs[0].joint_out.cpu().numpy(), devs[1].joint_out.cpu().numpy())
+    for d in devs:
+        d.solve()
+    res = [d.result() for d in devs]
+    _equal(res[0], res[1], f"reorder={reorder}")
+    for d in devs:
+        d.u.fill_(float("nan")); d.N.fill_(float("nan"))
+        d.dofmap(); d.assemble(); d.potrf(); d.potrs(); d.recover()
+    _equal(devs[0].result(), devs[1].result(), f"stages, reorder={reorder}")
+    _equal(devs[1].result(), res[0], "stages vs one call")
+    ref = orc.solve(datas[0])
+    assert H.max_scaled_err(res[1].displace[0, :len(datas[0]["joint"])], ref["u"]) <= 1e-9
+
+
 def test_solve_batch_of_the_bundled_cases_in_the_table_form(gpu):
     """All bundled cases in ONE ragged batch through `solve_batch`: small ones on the fused kernel
     (`trs_solve_small_tab`), the rest staged; device joint order, a host joint order ("rcm") and none; two section
