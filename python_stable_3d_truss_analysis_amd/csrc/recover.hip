@@ -228,10 +228,23 @@ __global__ __launch_bounds__(256) void trs_recover_kernel(
                 if (fi[3 * j + a] < 0) f[3 * j + a] = r[a];
         }
         __syncthreads();
-        for (int d = tid; d < ndof_max; d += 256) {
-            const int o = jo ? 3 * jo[d / 3] + d % 3 : d;
-            u_out[orow * odof + o] = u[d];
-            f_out[orow * odof + o] = d < ndof ? f[d] : 0.0;
+        if (jo != nullptr) {
+            // results in the caller's numbering: the output rows are written IN ORDER (whole cache lines) and read out
+            // of LDS through the inverse of the joint map, built in the dead counter table - not scattered joint by
+            // joint (24-byte pieces of 128-byte lines)
+            int* inv = cnt;
+            for (int j = tid; j < nJ_max; j += 256) inv[jo[j]] = j;
+            __syncthreads();
+            for (int o = tid; o < ndof_max; o += 256) {
+                const int d = 3 * inv[o / 3] + o % 3;
+                u_out[orow * odof + o] = u[d];
+                f_out[orow * odof + o] = d < ndof ? f[d] : 0.0;
+            }
+        } else {
+            for (int d = tid; d < ndof_max; d += 256) {
+                u_out[orow * odof + d] = u[d];
+                f_out[orow * odof + d] = d < ndof ? f[d] : 0.0;
+            }
         }
     } else {
         int* lists = reinterpret_cast<int*>(sh);        // [TRS_RECOVER_LIST_CAP] member ends, grouped by joint
