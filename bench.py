@@ -1352,6 +1352,12 @@ def main():
                                   ("; the same wave then substitutes: factor tiles read once more, y in, u out "
                                    "(the trs_potrs launch finds nothing left to do)" if substituted else ""),
                     "fused_substitution": substituted,
+                    # SURVEY 8d's stricter count for the factorisation alone - stiffness tiles read once + factor tiles
+                    # written once, the substitution's read-back of the factor NOT counted - over the same launch (which
+                    # does substitute): the lower bound of what one may call "algorithmic" for this kernel
+                    "hbm_read_k_write_l": {"bytes_per_truss": int(counts["stiffness_tile_bytes"] + counts["slab_tile_bytes"]),
+                                           "frac": (counts["stiffness_tile_bytes"] + counts["slab_tile_bytes"]) * args.batch
+                                           / potrf_s / 1e9 / PEAK_HBM_GBS},
                     "dense_equivalent_tflops": dense_flops * args.batch / potrf_s / 1e12,
                     "dense_flop_per_truss": dense_flops}
         if intensity >= balance:
